@@ -1,0 +1,167 @@
+/*
+ * mmgibbs.h -- C ABI of libmmgibbs.so: the MI355X-native Gibbs hot path of mmseq.
+ *
+ * The reference (eturro/mmseq) has no in-process plugin / FFI boundary: the hot path is
+ * the body of main() in src/mmseq.cpp.  This header is the boundary a maintainer would
+ * bind instead of that body; each entry point cites the reference lines it replaces
+ * (paths relative to the reference tree).  INTEGRATION.md shows the call sequence that
+ * replaces src/mmseq.cpp:833-925 inside the reference's own main().
+ *
+ * Conventions: every function returns 0 on success, non-zero on error (message via
+ * mmg_last_error(), thread-local).  No exceptions cross the boundary.  All host
+ * buffers are caller-owned; handles own their device memory.  One handle is driven by
+ * one host thread at a time.  There is NO CPU fallback: without a HIP device every
+ * compute entry point fails with MMG_ERR_NO_DEVICE.
+ */
+#ifndef MMGIBBS_H
+#define MMGIBBS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMG_ABI_VERSION 1
+
+enum {
+    MMG_OK = 0,
+    MMG_ERR_ARG = 1,       /* invalid argument                                 */
+    MMG_ERR_NO_DEVICE = 2, /* no usable HIP device (no fallback exists)        */
+    MMG_ERR_HIP = 3,       /* a HIP runtime call failed                        */
+    MMG_ERR_STATE = 4,     /* call sequence error (e.g. trace not kept)        */
+    MMG_ERR_IO = 5
+};
+
+/* rows with k <= MMG_K_SMALL draw k categoricals; above, a conditional-binomial chain */
+#define MMG_K_SMALL 8u
+
+typedef struct mmg_problem mmg_problem; /* device-resident CSR hit-set matrix M + k + l */
+typedef struct mmg_sampler mmg_sampler; /* chains' state: mu, counts, trace, moments     */
+
+/* Host description of the sparse problem: the reference's boolMat M (m x n), vector<int> k
+ * and vector<double> l  (src/mmseq.cpp:117, :385, :593-608).  Rows are hit sets (or single
+ * reads, k == NULL => all 1), columns the observed transcripts in first-seen order (:403);
+ * within a row columns ascend (:412). */
+typedef struct mmg_problem_desc {
+    uint64_t m;              /* rows                                                    */
+    uint32_t n;              /* columns (observed transcripts)                          */
+    const uint64_t *row_ptr; /* m+1 offsets into col_idx, row_ptr[0] == 0                */
+    const uint32_t *col_idx; /* row_ptr[m] column indices                                */
+    const uint32_t *k;       /* m multiplicities, or NULL for all ones                   */
+    const double *l;         /* n: effective_length * mapped_reads / 1e9  (:603), > 0    */
+    uint64_t row_id_base;    /* global index of row 0 (read-shard mode: the shard offset;
+                                keys the per-row random stream so shards reproduce the
+                                single-device chain bit for bit)                         */
+} mmg_problem_desc;
+
+/* Synthetic problem generated directly into device CSR (no reference counterpart; the
+ * benchmark inputs of BASELINE.md).  Every row is a pure function of (seed, row id). */
+typedef struct mmg_synth_desc {
+    uint64_t seed;        /* generator seed (1234 = reference default -seed)              */
+    uint64_t rows;        /* rows generated on this device                                */
+    uint64_t row0;        /* global id of the first row (shard offset)                    */
+    uint32_t n;           /* transcripts                                                  */
+    double avg_hits;      /* row length = min(100, 1 + Poisson(avg_hits - 1))             */
+    int32_t uniform;      /* 0: hits inside a +-64 index window; 1: uniform over n        */
+    uint64_t mapped_reads;/* N in l = efflen * N / 1e9; 0 => rows                         */
+} mmg_synth_desc;
+
+typedef struct mmg_problem_info {
+    uint64_t m, nnz, total_k, row_id_base;
+    uint32_t n;
+    uint32_t max_row_len;
+    uint64_t n_tiles;      /* LDS tiles the sample kernel walks                           */
+    uint64_t device_bytes; /* HBM held by the problem                                     */
+    int32_t index_bits;    /* 32 or 64: width of the device row_ptr                       */
+} mmg_problem_info;
+
+/* Parameters of the Gibbs loop: alpha/beta are the Gamma prior (src/mmseq.cpp:184-185),
+ * seed the reference's -seed (:203), gibbs_iter/trace_len as :190-192, :284. */
+typedef struct mmg_config {
+    double alpha, beta;
+    uint64_t seed;
+    int32_t n_chains;   /* independent chains advanced per sweep on this device (>= 1)   */
+    int32_t chain_base; /* global index of chain 0 here (multi-device chains mode)        */
+    int32_t gibbs_iter; /* planned chain length; sample s kept when iter % (gibbs_iter/trace_len) == 0 (:911) */
+    int32_t trace_len;  /* samples per chain: 1024 in the reference (:191)                */
+    int32_t keep_trace; /* !=0: store the samples (n*trace_len doubles per chain); 0: moments only */
+    int32_t timing;     /* !=0: bracket every kernel launch with HIP events               */
+} mmg_config;
+
+typedef struct mmg_timing {
+    double sample_ms, update_ms; /* sums of per-launch HIP-event durations                */
+    uint64_t sample_launches, update_launches;
+} mmg_timing;
+
+const char *mmg_last_error(void);
+int mmg_abi_version(void);
+/* number of HIP devices visible (0 and MMG_OK when none). */
+int mmg_device_count(int *count);
+
+/* ---- problem ------------------------------------------------------------------------ */
+/* Uploads M, k, l (src/mmseq.cpp:456-462, :582-608 produce them) to `device`. */
+int mmg_problem_create(const mmg_problem_desc *desc, int device, mmg_problem **out);
+int mmg_problem_create_synthetic(const mmg_synth_desc *desc, int device, mmg_problem **out);
+int mmg_problem_info_get(const mmg_problem *p, mmg_problem_info *info);
+/* Copies the device CSR back (row_ptr m+1 u64, col_idx nnz u32; either may be NULL). */
+int mmg_problem_download(const mmg_problem *p, uint64_t *row_ptr, uint32_t *col_idx);
+int mmg_problem_get_l(const mmg_problem *p, double *l);
+/* Start values and the unique-hit column, src/mmseq.cpp:617-638: mu0[t] = sum_{i: t in row i}
+ * k_i/|row i| / l[t]; unique_hits[t] = sum of k_i over rows {t} (bit-exact integer). Either
+ * output may be NULL. */
+int mmg_problem_start_values(const mmg_problem *p, double *mu0, int32_t *unique_hits);
+/* EM to convergence from mu (in/out), src/mmseq.cpp:741-811: stop when the log-likelihood
+ * gain <= epsilon or after max_iter sweeps. */
+int mmg_problem_em(const mmg_problem *p, double *mu, int max_iter, double epsilon, int *iters,
+                   double *loglik);
+void mmg_problem_destroy(mmg_problem *p);
+
+/* ---- sampler ------------------------------------------------------------------------ */
+/* mu0: n doubles (every chain starts there, like mu = EM optimum at src/mmseq.cpp:820). */
+int mmg_sampler_create(const mmg_problem *p, const mmg_config *cfg, const double *mu0, mmg_sampler **out);
+/* Launch on a caller-owned hipStream_t (e.g. the framework's current stream) instead of
+ * the sampler's own stream. NULL restores the own stream. */
+int mmg_sampler_set_stream(mmg_sampler *s, void *hip_stream);
+/* n_iter full Gibbs iterations = src/mmseq.cpp:851-918 (sample+scatter, gamma redraw,
+ * trace capture), enqueued asynchronously. */
+int mmg_sampler_run(mmg_sampler *s, int n_iter);
+/* The two halves of one iteration, for read-shard mode where the caller all-reduces the
+ * counts in between:  sample = :857-891 (+ :887 column sums), update = :905-917. */
+int mmg_sampler_sample(mmg_sampler *s);
+int mmg_sampler_update(mmg_sampler *s);
+/* Device pointers for collectives: counts int32 [n_chains][n]; moments double
+ * [2][n_chains][n] (sum log mu, sum log^2 mu over kept samples). */
+int mmg_sampler_counts_devptr(mmg_sampler *s, void **ptr, uint64_t *count);
+int mmg_sampler_moments_devptr(mmg_sampler *s, void **ptr, uint64_t *count);
+int mmg_sampler_sync(mmg_sampler *s);
+int mmg_sampler_iteration(const mmg_sampler *s, int *iter);
+/* Trace of one chain, transcript-major exactly like mu_trace at src/mmseq.cpp:914:
+ * out[t*trace_len + s]. */
+int mmg_sampler_get_trace(mmg_sampler *s, int chain, double *out);
+/* Same samples, sample-major (the row order of .trace_gibbs.gz, :912-916): out[s*n + t]. */
+int mmg_sampler_get_trace_rows(mmg_sampler *s, int chain, int first_sample, int n_samples, double *out);
+int mmg_sampler_get_mu(mmg_sampler *s, int chain, double *mu);
+/* Xcolsum of the last completed iteration (src/mmseq.cpp:896-899). */
+int mmg_sampler_get_counts(mmg_sampler *s, int chain, int32_t *cnt);
+int mmg_sampler_get_moments(mmg_sampler *s, int chain, double *sum_log, double *sum_log2, int64_t *n_samples);
+int mmg_sampler_get_timing(mmg_sampler *s, mmg_timing *t);
+int mmg_sampler_reset_timing(mmg_sampler *s);
+void mmg_sampler_destroy(mmg_sampler *s);
+
+/* ---- self-test hooks (used by tests only) ------------------------------------------- */
+/* Evaluates the library's own log / exp / sqrt / 1/x on x[0..n) (device >= 0: in a kernel
+ * on that device; device == -1: the host instantiation of the same inline code). */
+int mmg_selftest_math(int device, int64_t n, const double *x, double *out_log, double *out_exp,
+                      double *out_sqrt, double *out_rcp);
+/* Philox4x32-10 block: out[4] = philox(ctr[4], key[2]). */
+int mmg_selftest_philox(int device, const uint32_t *ctr, const uint32_t *key, uint32_t *out);
+/* out[i] = shape-`shape` gamma draw of stream (seed, chain 0, iter 0, id i) times scale. */
+int mmg_selftest_gamma(int device, uint64_t seed, double shape, double scale, int64_t n, double *out);
+/* out[i] = Binomial(nn, p) draw of row stream (seed, id i). */
+int mmg_selftest_binomial(int device, uint64_t seed, uint32_t nn, double p, int64_t n, uint32_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMGIBBS_H */

@@ -1,0 +1,104 @@
+"""ctypes loader for libmmgibbs.so (the C ABI declared in include/mmgibbs.h).
+
+The library is built in-tree (mmseq_amd/csrc/Makefile, via __graft_entry__.build()).
+There is no fallback: if the shared object is missing, loading raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmmgibbs.so")
+_lib = None
+
+
+class MMGError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libmmgibbs error %d: %s" % (code, msg))
+        self.code = code
+
+
+class ProblemDesc(C.Structure):
+    _fields_ = [("m", C.c_uint64), ("n", C.c_uint32), ("row_ptr", C.c_void_p), ("col_idx", C.c_void_p),
+                ("k", C.c_void_p), ("l", C.c_void_p), ("row_id_base", C.c_uint64)]
+
+
+class SynthDesc(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("rows", C.c_uint64), ("row0", C.c_uint64), ("n", C.c_uint32),
+                ("avg_hits", C.c_double), ("uniform", C.c_int32), ("mapped_reads", C.c_uint64)]
+
+
+class ProblemInfo(C.Structure):
+    _fields_ = [("m", C.c_uint64), ("nnz", C.c_uint64), ("total_k", C.c_uint64), ("row_id_base", C.c_uint64),
+                ("n", C.c_uint32), ("max_row_len", C.c_uint32), ("n_tiles", C.c_uint64),
+                ("device_bytes", C.c_uint64), ("index_bits", C.c_int32)]
+
+
+class Config(C.Structure):
+    _fields_ = [("alpha", C.c_double), ("beta", C.c_double), ("seed", C.c_uint64), ("n_chains", C.c_int32),
+                ("chain_base", C.c_int32), ("gibbs_iter", C.c_int32), ("trace_len", C.c_int32),
+                ("keep_trace", C.c_int32), ("timing", C.c_int32)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("sample_ms", C.c_double), ("update_ms", C.c_double), ("sample_launches", C.c_uint64),
+                ("update_launches", C.c_uint64)]
+
+
+# every symbol include/mmgibbs.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "mmg_last_error": (C.c_char_p, []),
+    "mmg_abi_version": (C.c_int, []),
+    "mmg_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "mmg_problem_create": (C.c_int, [C.POINTER(ProblemDesc), C.c_int, C.POINTER(C.c_void_p)]),
+    "mmg_problem_create_synthetic": (C.c_int, [C.POINTER(SynthDesc), C.c_int, C.POINTER(C.c_void_p)]),
+    "mmg_problem_info_get": (C.c_int, [C.c_void_p, C.POINTER(ProblemInfo)]),
+    "mmg_problem_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mmg_problem_get_l": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mmg_problem_start_values": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mmg_problem_em": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_int),
+                                 C.POINTER(C.c_double)]),
+    "mmg_problem_destroy": (None, [C.c_void_p]),
+    "mmg_sampler_create": (C.c_int, [C.c_void_p, C.POINTER(Config), C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mmg_sampler_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mmg_sampler_run": (C.c_int, [C.c_void_p, C.c_int]),
+    "mmg_sampler_sample": (C.c_int, [C.c_void_p]),
+    "mmg_sampler_update": (C.c_int, [C.c_void_p]),
+    "mmg_sampler_counts_devptr": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    "mmg_sampler_moments_devptr": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    "mmg_sampler_sync": (C.c_int, [C.c_void_p]),
+    "mmg_sampler_iteration": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "mmg_sampler_get_trace": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "mmg_sampler_get_trace_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mmg_sampler_get_mu": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "mmg_sampler_get_counts": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "mmg_sampler_get_moments": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+    "mmg_sampler_get_timing": (C.c_int, [C.c_void_p, C.POINTER(Timing)]),
+    "mmg_sampler_reset_timing": (C.c_int, [C.c_void_p]),
+    "mmg_sampler_destroy": (None, [C.c_void_p]),
+    "mmg_selftest_math": (C.c_int, [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mmg_selftest_philox": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mmg_selftest_gamma": (C.c_int, [C.c_int, C.c_uint64, C.c_double, C.c_double, C.c_int64, C.c_void_p]),
+    "mmg_selftest_binomial": (C.c_int, [C.c_int, C.c_uint64, C.c_uint32, C.c_double, C.c_int64, C.c_void_p]),
+}
+
+
+def load():
+    """Load libmmgibbs.so and bind every declared symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError("libmmgibbs.so not built at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(there is no CPU fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise MMGError(rc, load().mmg_last_error().decode("utf-8", "replace"))

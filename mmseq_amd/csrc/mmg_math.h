@@ -1,0 +1,329 @@
+// mmg_math.h -- counter-based randomness and reproducible fp64 elementary functions
+// shared by every kernel of libmmgibbs (and by the host-side table builders).
+//
+// Everything here is built from IEEE-754 +,-,*,/,sqrt and integer bit operations, each
+// rounded once (the library is compiled with -ffp-contract=off), so the host and the
+// gfx950 instantiations produce the same bits and a chain is a pure function of
+// (seed, chain, iteration, row | transcript) -- independent of launch geometry, thread
+// count or number of GPUs.  That replaces the reference's thread-count-dependent
+// "one MT19937 per OpenMP thread" (src/mmseq.cpp:834-838).
+//
+// Samplers restate the published algorithms the reference reaches through GSL:
+// gsl_ran_gamma = Marsaglia & Tsang (2000) (src/mmseq.cpp:907), gsl_ran_multinomial =
+// conditional binomials (src/mmseq.cpp:880).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MMG_HD __host__ __device__ __forceinline__
+
+namespace mmg {
+
+// ------------------------------------------------------------------ Philox4x32-10
+struct U4 { uint32_t x, y, z, w; };
+
+MMG_HD uint32_t mulhi32(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32);
+#endif
+}
+
+MMG_HD U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = mulhi32(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const uint32_t hi1 = mulhi32(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        U4 n;
+        n.x = hi1 ^ c.y ^ k0;
+        n.y = lo1;
+        n.z = hi0 ^ c.w ^ k1;
+        n.w = lo0;
+        c = n;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+
+// 52 random bits -> uniform strictly inside (0,1); every step exact
+MMG_HD double u52(uint32_t a, uint32_t b)
+{
+    const uint64_t v = ((uint64_t)(a >> 6) << 26) | (uint64_t)(b >> 6);
+    return ((double)v + 0.5) * 0x1p-52;
+}
+
+enum : uint32_t { TAG_ROW = 1, TAG_GAMMA = 2, TAG_SYNTH_ROW = 3, TAG_SYNTH_TX = 4, TAG_SIMU = 5 };
+
+// A stream = (key from seed/chain/tag, counter words id_lo,id_hi,iter) + running block index.
+struct Stream {
+    uint32_t k0, k1, c0, c1, c2, c3;
+    MMG_HD Stream(uint64_t seed, uint32_t chain, uint32_t tag, uint64_t id, uint32_t iter)
+        : k0((uint32_t)seed), k1((uint32_t)(seed >> 32) ^ (chain & 0x00FFFFFFu) ^ (tag << 24)),
+          c0((uint32_t)id), c1((uint32_t)(id >> 32)), c2(iter), c3(0) {}
+    // one Philox block = one pair of uniforms
+    MMG_HD void pair(double &ua, double &ub)
+    {
+        const U4 r = philox4x32_10(U4{c0, c1, c2, c3}, k0, k1);
+        ++c3;
+        ua = u52(r.x, r.y);
+        ub = u52(r.z, r.w);
+    }
+};
+
+// one-uniform-at-a-time view of a stream (first of each pair, then second)
+struct SeqStream {
+    Stream s;
+    double spare;
+    bool have;
+    MMG_HD SeqStream(const Stream &st) : s(st), spare(0.0), have(false) {}
+    MMG_HD double next()
+    {
+        if (have) { have = false; return spare; }
+        double ua, ub;
+        s.pair(ua, ub);
+        spare = ub; have = true;
+        return ua;
+    }
+};
+
+// ------------------------------------------------------------------ bit casts
+MMG_HD uint64_t bits_of(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint64_t)__double_as_longlong(x);
+#else
+    uint64_t u; __builtin_memcpy(&u, &x, 8); return u;
+#endif
+}
+MMG_HD double double_of(uint64_t u)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __longlong_as_double((long long)u);
+#else
+    double x; __builtin_memcpy(&x, &u, 8); return x;
+#endif
+}
+
+MMG_HD double dsqrt(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __dsqrt_rn(x);
+#else
+    return __builtin_sqrt(x);
+#endif
+}
+
+// ------------------------------------------------------------------ log / exp
+// Classic fdlibm scheme: x = 2^k (1+f), log(1+f) = f - f^2/2 + s*(f^2/2 + R(s^2)), s = f/(2+f).
+MMG_HD double dlog(double x)
+{
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                 Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    uint64_t ix = bits_of(x);
+    uint32_t hx = (uint32_t)(ix >> 32);
+    int k = 0;
+    if (hx < 0x00100000u || (hx >> 31)) {
+        if ((ix << 1) == 0) return -__builtin_huge_val();
+        if (hx >> 31) return __builtin_nan("");
+        k -= 54;
+        x *= 0x1p54;
+        ix = bits_of(x);
+        hx = (uint32_t)(ix >> 32);
+    } else if (hx >= 0x7ff00000u) {
+        return x;
+    } else if (hx == 0x3ff00000u && (ix << 32) == 0) {
+        return 0.0;
+    }
+    hx += 0x3ff00000u - 0x3fe6a09eu;
+    k += (int)(hx >> 20) - 0x3ff;
+    hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
+    x = double_of(((uint64_t)hx << 32) | (ix & 0xffffffffull));
+    const double f = x - 1.0;
+    const double hfsq = 0.5 * f * f;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double R = t2 + t1;
+    const double dk = (double)k;
+    return s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;
+}
+
+MMG_HD double dscalbn(double y, int n)
+{
+    if (n > 1023) {
+        y *= 0x1p1023; n -= 1023;
+        if (n > 1023) { y *= 0x1p1023; n -= 1023; if (n > 1023) n = 1023; }
+    } else if (n < -1022) {
+        y *= 0x1p-1022 * 0x1p53; n += 1022 - 53;
+        if (n < -1022) { y *= 0x1p-1022 * 0x1p53; n += 1022 - 53; if (n < -1022) n = -1022; }
+    }
+    return y * double_of((uint64_t)(0x3ff + n) << 52);
+}
+
+MMG_HD double dexp(double x)
+{
+    const double ln2hi = 6.93147180369123816490e-01, ln2lo = 1.90821492927058770002e-10,
+                 invln2 = 1.44269504088896338700e+00;
+    const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
+                 P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
+                 P5 = 4.13813679705723846039e-08;
+    uint32_t hx = (uint32_t)(bits_of(x) >> 32);
+    const int sign = (int)(hx >> 31);
+    hx &= 0x7fffffffu;
+    double hi, lo;
+    int k;
+    if (hx >= 0x4086232bu) {
+        if (x != x) return x;
+        if (x > 709.782712893383973096) return __builtin_huge_val();
+        if (x < -745.13321910194110842) return 0.0;
+    }
+    if (hx > 0x3fd62e42u) {
+        if (hx >= 0x3ff0a2b2u) k = (int)(invln2 * x + (sign ? -0.5 : 0.5));
+        else k = 1 - sign - sign;
+        hi = x - (double)k * ln2hi;
+        lo = (double)k * ln2lo;
+        x = hi - lo;
+    } else if (hx > 0x3e300000u) {
+        k = 0; hi = x; lo = 0.0;
+    } else {
+        return 1.0 + x;
+    }
+    const double xx = x * x;
+    const double c = x - xx * (P1 + xx * (P2 + xx * (P3 + xx * (P4 + xx * P5))));
+    const double y = 1.0 + (x * c / (2.0 - c) - lo + hi);
+    if (k == 0) return y;
+    return dscalbn(y, k);
+}
+
+MMG_HD double dfloor(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return floor(x);
+#else
+    return __builtin_floor(x);
+#endif
+}
+MMG_HD double dabs(double x) { return double_of(bits_of(x) & 0x7fffffffffffffffull); }
+
+// ------------------------------------------------------------------ samplers
+// N(0,1), Marsaglia polar method; one Philox block per attempt
+MMG_HD double normal(Stream &s)
+{
+    for (;;) {
+        double ua, ub;
+        s.pair(ua, ub);
+        const double v1 = 2.0 * ua - 1.0, v2 = 2.0 * ub - 1.0;
+        const double r2 = v1 * v1 + v2 * v2;
+        if (r2 >= 1.0 || r2 == 0.0) continue;
+        return v1 * dsqrt(-2.0 * dlog(r2) / r2);
+    }
+}
+
+// unit-scale Gamma(a), a > 0: Marsaglia-Tsang; a < 1 via Gamma(a+1) * U^(1/a)
+MMG_HD double gamma_unit(Stream &s, double a_in)
+{
+    const double a = (a_in < 1.0) ? a_in + 1.0 : a_in;
+    const double d = a - 1.0 / 3.0;
+    const double c = (1.0 / 3.0) / dsqrt(d);
+    double v, x, ua, ub;
+    for (;;) {
+        do {
+            x = normal(s);
+            v = 1.0 + c * x;
+        } while (v <= 0.0);
+        v = v * v * v;
+        s.pair(ua, ub);
+        const double x2 = x * x;
+        if (ua < 1.0 - 0.0331 * x2 * x2) break;
+        if (dlog(ua) < 0.5 * x2 + d * (1.0 - v + dlog(v))) break;
+    }
+    double g = d * v;
+    if (a_in < 1.0) {
+        s.pair(ua, ub);
+        g = g * dexp(dlog(ua) / a_in);
+    }
+    return g;
+}
+
+// log(k!) Stirling remainder used by the binomial rejection sampler
+MMG_HD double stirling_tail(double k)
+{
+    if (k <= 9.0) {
+        switch ((int)k) {
+        case 0: return 0.0810614667953272;
+        case 1: return 0.0413406959554092;
+        case 2: return 0.0276779256849983;
+        case 3: return 0.02079067210376509;
+        case 4: return 0.0166446911898211;
+        case 5: return 0.0138761288230707;
+        case 6: return 0.0118967099458917;
+        case 7: return 0.0104112652619720;
+        case 8: return 0.00925546218271273;
+        default: return 0.00833056343336287;
+        }
+    }
+    const double kp1sq = (k + 1.0) * (k + 1.0);
+    return (1.0 / 12.0 - (1.0 / 360.0 - 1.0 / 1260.0 / kp1sq) / kp1sq) / (k + 1.0);
+}
+
+// Binomial(n, p): sequential-search inversion below n*min(p,1-p) < 10, Hormann's BTRS above
+MMG_HD uint32_t binomial(SeqStream &q, uint32_t n, double p)
+{
+    if (n == 0 || !(p > 0.0)) return 0;
+    if (p >= 1.0) return n;
+    bool flip = false;
+    if (p > 0.5) { p = 1.0 - p; flip = true; }
+    const double dn = (double)n;
+    uint32_t res;
+    if (dn * p < 10.0) {
+        const double qq = 1.0 - p, s = p / qq, a = (dn + 1.0) * s;
+        for (;;) {
+            double r = dexp(dn * dlog(qq));
+            double u = q.next();
+            uint32_t x = 0;
+            bool ok = true;
+            while (u > r) {
+                u -= r;
+                x++;
+                if (x > n) { ok = false; break; }
+                r *= (a / (double)x - s);
+            }
+            if (ok) { res = x; break; }
+        }
+    } else {
+        const double qq = 1.0 - p, spq = dsqrt(dn * p * qq);
+        const double b = 1.15 + 2.53 * spq;
+        const double a = -0.0873 + 0.0248 * b + 0.01 * p;
+        const double c = dn * p + 0.5;
+        const double vr = 0.92 - 4.2 / b;
+        const double r = p / qq;
+        const double alpha = (2.83 + 5.1 / b) * spq;
+        const double m = dfloor((dn + 1.0) * p);
+        for (;;) {
+            const double u = q.next() - 0.5;
+            double v = q.next();
+            const double us = 0.5 - dabs(u);
+            const double kf = dfloor((2.0 * a / us + b) * u + c);
+            if (kf < 0.0 || kf > dn) continue;
+            if (us >= 0.07 && v <= vr) { res = (uint32_t)kf; break; }
+            v = dlog(v * alpha / (a / (us * us) + b));
+            const double ub = (m + 0.5) * dlog((m + 1.0) / (r * (dn - m + 1.0))) +
+                              (dn + 1.0) * dlog((dn - m + 1.0) / (dn - kf + 1.0)) +
+                              (kf + 0.5) * dlog(r * (dn - kf + 1.0) / (kf + 1.0)) +
+                              stirling_tail(m) + stirling_tail(dn - m) - stirling_tail(kf) - stirling_tail(dn - kf);
+            if (v <= ub) { res = (uint32_t)kf; break; }
+        }
+    }
+    return flip ? n - res : res;
+}
+
+} // namespace mmg

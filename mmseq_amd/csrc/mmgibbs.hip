@@ -1,0 +1,775 @@
+// mmgibbs.hip -- implementation of the C ABI in include/mmgibbs.h on HIP / gfx950.
+// Host side of the device boundary that replaces src/mmseq.cpp:833-925 of the reference.
+#include "../../include/mmgibbs.h"
+#include "gibbs_kernels.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace mmg;
+
+// ------------------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                         \
+    do {                                                                                                      \
+        hipError_t _e = (expr);                                                                               \
+        if (_e != hipSuccess)                                                                                 \
+            return fail(MMG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                      \
+    } while (0)
+
+extern "C" const char *mmg_last_error(void) { return g_err.c_str(); }
+extern "C" int mmg_abi_version(void) { return MMG_ABI_VERSION; }
+
+extern "C" int mmg_device_count(int *count)
+{
+    if (!count) return fail(MMG_ERR_ARG, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    *count = n;
+    return MMG_OK;
+}
+
+static int require_device(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(MMG_ERR_NO_DEVICE, "no HIP device available: libmmgibbs has no CPU fallback");
+    }
+    if (device < 0 || device >= n) return fail(MMG_ERR_ARG, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    return MMG_OK;
+}
+
+// ------------------------------------------------------------------------------ problem
+struct mmg_problem {
+    int device = 0;
+    uint64_t m = 0, nnz = 0, total_k = 0, row_id_base = 0, n_tiles = 0, device_bytes = 0;
+    uint32_t n = 0, max_row_len = 0;
+    bool idx64 = false;
+    int cu_count = 256;
+    void *d_row_ptr = nullptr;
+    uint32_t *d_col = nullptr;
+    uint32_t *d_k = nullptr;
+    double *d_l = nullptr;
+    uint64_t *d_tile_row = nullptr;
+    std::vector<double> h_l;
+};
+
+static void problem_free(mmg_problem *p)
+{
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    if (p->d_row_ptr) (void)hipFree(p->d_row_ptr);
+    if (p->d_col) (void)hipFree(p->d_col);
+    if (p->d_k) (void)hipFree(p->d_k);
+    if (p->d_l) (void)hipFree(p->d_l);
+    if (p->d_tile_row) (void)hipFree(p->d_tile_row);
+    delete p;
+}
+
+// Tiles of consecutive rows: <= K1_TILE_NNZ hits and <= K1_TILE_NNZ rows; a longer row is alone.
+static void build_tiles(const uint64_t *row_ptr, uint64_t m, std::vector<uint64_t> &tile_row, uint32_t &max_len)
+{
+    tile_row.clear();
+    tile_row.push_back(0);
+    uint64_t cur_nnz = 0, cur_rows = 0;
+    max_len = 0;
+    for (uint64_t r = 0; r < m; ++r) {
+        const uint64_t L = row_ptr[r + 1] - row_ptr[r];
+        if (L > max_len) max_len = (uint32_t)std::min<uint64_t>(L, 0xffffffffu);
+        if (cur_rows > 0 && (cur_nnz + L > (uint64_t)K1_TILE_NNZ || cur_rows >= (uint64_t)K1_TILE_NNZ)) {
+            tile_row.push_back(r);
+            cur_nnz = 0;
+            cur_rows = 0;
+        }
+        cur_nnz += L;
+        cur_rows += 1;
+    }
+    if (m > 0) tile_row.push_back(m);
+}
+
+// uploads row_ptr (narrowed to u32 when nnz fits), tiles; fills sizes
+static int problem_finish(mmg_problem *p, const uint64_t *h_row_ptr)
+{
+    std::vector<uint64_t> tiles;
+    build_tiles(h_row_ptr, p->m, tiles, p->max_row_len);
+    p->n_tiles = tiles.empty() ? 0 : tiles.size() - 1;
+    p->idx64 = p->nnz >= 0xffffffffull;
+    if (p->idx64) {
+        HIP_TRY(hipMalloc(&p->d_row_ptr, (p->m + 1) * sizeof(uint64_t)));
+        HIP_TRY(hipMemcpy(p->d_row_ptr, h_row_ptr, (p->m + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+        p->device_bytes += (p->m + 1) * 8;
+    } else {
+        std::vector<uint32_t> rp32(p->m + 1);
+        for (uint64_t i = 0; i <= p->m; ++i) rp32[i] = (uint32_t)h_row_ptr[i];
+        HIP_TRY(hipMalloc(&p->d_row_ptr, (p->m + 1) * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy(p->d_row_ptr, rp32.data(), (p->m + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+        p->device_bytes += (p->m + 1) * 4;
+    }
+    const size_t tb = std::max<size_t>(tiles.size(), 1) * sizeof(uint64_t);
+    HIP_TRY(hipMalloc((void **)&p->d_tile_row, tb));
+    if (!tiles.empty()) HIP_TRY(hipMemcpy(p->d_tile_row, tiles.data(), tiles.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    p->device_bytes += tb;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, p->device));
+    p->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    return MMG_OK;
+}
+
+extern "C" int mmg_problem_create(const mmg_problem_desc *d, int device, mmg_problem **out)
+{
+    if (!d || !out) return fail(MMG_ERR_ARG, "NULL argument");
+    if (!d->row_ptr || !d->l || d->n == 0) return fail(MMG_ERR_ARG, "row_ptr/l missing or n == 0");
+    if (d->row_ptr[0] != 0) return fail(MMG_ERR_ARG, "row_ptr[0] must be 0");
+    const uint64_t nnz = d->row_ptr[d->m];
+    if (nnz > 0 && !d->col_idx) return fail(MMG_ERR_ARG, "col_idx missing");
+    for (uint64_t r = 0; r < d->m; ++r)
+        if (d->row_ptr[r + 1] < d->row_ptr[r]) return fail(MMG_ERR_ARG, "row_ptr must be non-decreasing");
+    for (uint64_t j = 0; j < nnz; ++j)
+        if (d->col_idx[j] >= d->n) return fail(MMG_ERR_ARG, "col_idx entry out of range");
+    for (uint32_t t = 0; t < d->n; ++t)
+        if (!(d->l[t] > 0.0)) return fail(MMG_ERR_ARG, "l[t] must be > 0 (src/mmseq.cpp:604)");
+    int rc = require_device(device);
+    if (rc) return rc;
+    mmg_problem *p = new mmg_problem();
+    p->device = device;
+    p->m = d->m; p->n = d->n; p->nnz = nnz; p->row_id_base = d->row_id_base;
+    p->h_l.assign(d->l, d->l + d->n);
+    if (d->k) { for (uint64_t r = 0; r < d->m; ++r) p->total_k += d->k[r]; } else p->total_k = d->m;
+    auto bail = [&](int code) { problem_free(p); return code; };
+    const size_t col_bytes = (nnz + 8) * sizeof(uint32_t); // padded: the 16-byte stream may over-read
+    if (hipMalloc((void **)&p->d_col, col_bytes) != hipSuccess) return bail(fail(MMG_ERR_HIP, "hipMalloc col_idx"));
+    if (hipMemset(p->d_col, 0, col_bytes) != hipSuccess) return bail(fail(MMG_ERR_HIP, "hipMemset col_idx"));
+    if (nnz && hipMemcpy(p->d_col, d->col_idx, nnz * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
+        return bail(fail(MMG_ERR_HIP, "hipMemcpy col_idx"));
+    p->device_bytes += col_bytes;
+    if (d->k && d->m) {
+        if (hipMalloc((void **)&p->d_k, d->m * sizeof(uint32_t)) != hipSuccess) return bail(fail(MMG_ERR_HIP, "hipMalloc k"));
+        if (hipMemcpy(p->d_k, d->k, d->m * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
+            return bail(fail(MMG_ERR_HIP, "hipMemcpy k"));
+        p->device_bytes += d->m * 4;
+    }
+    if (hipMalloc((void **)&p->d_l, d->n * sizeof(double)) != hipSuccess) return bail(fail(MMG_ERR_HIP, "hipMalloc l"));
+    if (hipMemcpy(p->d_l, d->l, d->n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+        return bail(fail(MMG_ERR_HIP, "hipMemcpy l"));
+    p->device_bytes += d->n * 8;
+    rc = problem_finish(p, d->row_ptr);
+    if (rc) return bail(rc);
+    *out = p;
+    return MMG_OK;
+}
+
+// Host-built transcript tables of the synthetic generator.
+static void synth_tables(uint64_t seed, uint32_t T, double lambda, std::vector<double> &efflen, std::vector<double> &cdf,
+                         std::vector<double> &len_cdf)
+{
+    efflen.resize(T);
+    cdf.resize(T);
+    double run = 0.0;
+    for (uint32_t t = 0; t < T; ++t) {
+        Stream s(seed, 0, TAG_SYNTH_TX, (uint64_t)t, 0);
+        const double z1 = normal(s), z2 = normal(s);
+        double ua, ub;
+        s.pair(ua, ub);
+        double e = dfloor(dexp(7.3132203870903014 + 0.6 * z1) + 0.5);
+        if (e < 50.0) e = 50.0;
+        const double th = (ua < 0.3) ? 0.0 : dexp(2.0 * z2);
+        efflen[t] = e;
+        run += th * e;
+        cdf[t] = run;
+    }
+    len_cdf.resize(99);
+    double p = dexp(-lambda), acc = 0.0;
+    for (int j = 0; j < 99; ++j) {
+        acc += p;
+        len_cdf[j] = acc;
+        p = p * lambda / (double)(j + 1);
+    }
+}
+
+extern "C" int mmg_problem_create_synthetic(const mmg_synth_desc *d, int device, mmg_problem **out)
+{
+    if (!d || !out) return fail(MMG_ERR_ARG, "NULL argument");
+    if (d->n == 0 || d->rows == 0 || !(d->avg_hits >= 1.0)) return fail(MMG_ERR_ARG, "bad synthetic spec");
+    int rc = require_device(device);
+    if (rc) return rc;
+    std::vector<double> efflen, cdf, len_cdf;
+    synth_tables(d->seed, d->n, d->avg_hits - 1.0, efflen, cdf, len_cdf);
+    if (!(cdf[d->n - 1] > 0.0)) return fail(MMG_ERR_ARG, "synthetic abundance table is all zero");
+    mmg_problem *p = new mmg_problem();
+    p->device = device;
+    p->m = d->rows; p->n = d->n; p->row_id_base = d->row0; p->total_k = d->rows;
+    const double N = (double)(d->mapped_reads ? d->mapped_reads : d->rows);
+    p->h_l.resize(d->n);
+    for (uint32_t t = 0; t < d->n; ++t) p->h_l[t] = efflen[t] * N / 1000000000.0; // src/mmseq.cpp:603
+    double *d_cdf = nullptr, *d_len_cdf = nullptr;
+    uint32_t *d_lens = nullptr;
+    auto cleanup = [&]() { if (d_cdf) (void)hipFree(d_cdf); if (d_len_cdf) (void)hipFree(d_len_cdf); if (d_lens) (void)hipFree(d_lens); };
+    auto bail = [&](int code) { cleanup(); problem_free(p); return code; };
+#define SYN_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return bail(fail(MMG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); } while (0)
+    SYN_TRY(hipMalloc((void **)&d_cdf, d->n * sizeof(double)));
+    SYN_TRY(hipMalloc((void **)&d_len_cdf, 99 * sizeof(double)));
+    SYN_TRY(hipMalloc((void **)&d_lens, d->rows * sizeof(uint32_t)));
+    SYN_TRY(hipMemcpy(d_cdf, cdf.data(), d->n * sizeof(double), hipMemcpyHostToDevice));
+    SYN_TRY(hipMemcpy(d_len_cdf, len_cdf.data(), 99 * sizeof(double), hipMemcpyHostToDevice));
+    SynthArgs sa{d->seed, d->row0, d->rows, d->n, d->uniform, d_cdf, d_len_cdf};
+    const unsigned gb = (unsigned)((d->rows + 255) / 256);
+    hipLaunchKernelGGL(k_synth_len, dim3(gb), dim3(256), 0, 0, sa, d_lens);
+    SYN_TRY(hipGetLastError());
+    std::vector<uint32_t> lens(d->rows);
+    SYN_TRY(hipMemcpy(lens.data(), d_lens, d->rows * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::vector<uint64_t> rp(d->rows + 1);
+    rp[0] = 0;
+    for (uint64_t r = 0; r < d->rows; ++r) rp[r + 1] = rp[r] + lens[r];
+    std::vector<uint32_t>().swap(lens);
+    p->nnz = rp[d->rows];
+    const size_t col_bytes = (p->nnz + 8) * sizeof(uint32_t);
+    SYN_TRY(hipMalloc((void **)&p->d_col, col_bytes));
+    SYN_TRY(hipMemset(p->d_col, 0, col_bytes));
+    p->device_bytes += col_bytes;
+    SYN_TRY(hipMalloc((void **)&p->d_l, d->n * sizeof(double)));
+    SYN_TRY(hipMemcpy(p->d_l, p->h_l.data(), d->n * sizeof(double), hipMemcpyHostToDevice));
+    p->device_bytes += d->n * 8;
+    rc = problem_finish(p, rp.data());
+    if (rc) return bail(rc);
+    if (p->idx64) hipLaunchKernelGGL(k_synth_fill<uint64_t>, dim3(gb), dim3(256), 0, 0, sa, (const uint64_t *)p->d_row_ptr, p->d_col);
+    else hipLaunchKernelGGL(k_synth_fill<uint32_t>, dim3(gb), dim3(256), 0, 0, sa, (const uint32_t *)p->d_row_ptr, p->d_col);
+    SYN_TRY(hipGetLastError());
+    SYN_TRY(hipDeviceSynchronize());
+#undef SYN_TRY
+    cleanup();
+    *out = p;
+    return MMG_OK;
+}
+
+extern "C" int mmg_problem_info_get(const mmg_problem *p, mmg_problem_info *info)
+{
+    if (!p || !info) return fail(MMG_ERR_ARG, "NULL argument");
+    info->m = p->m; info->nnz = p->nnz; info->total_k = p->total_k; info->row_id_base = p->row_id_base;
+    info->n = p->n; info->max_row_len = p->max_row_len; info->n_tiles = p->n_tiles;
+    info->device_bytes = p->device_bytes; info->index_bits = p->idx64 ? 64 : 32;
+    return MMG_OK;
+}
+
+extern "C" int mmg_problem_download(const mmg_problem *p, uint64_t *row_ptr, uint32_t *col_idx)
+{
+    if (!p) return fail(MMG_ERR_ARG, "NULL problem");
+    HIP_TRY(hipSetDevice(p->device));
+    if (row_ptr) {
+        if (p->idx64) {
+            HIP_TRY(hipMemcpy(row_ptr, p->d_row_ptr, (p->m + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        } else {
+            std::vector<uint32_t> rp32(p->m + 1);
+            HIP_TRY(hipMemcpy(rp32.data(), p->d_row_ptr, (p->m + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            for (uint64_t i = 0; i <= p->m; ++i) row_ptr[i] = rp32[i];
+        }
+    }
+    if (col_idx && p->nnz) HIP_TRY(hipMemcpy(col_idx, p->d_col, p->nnz * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return MMG_OK;
+}
+
+extern "C" int mmg_problem_get_l(const mmg_problem *p, double *l)
+{
+    if (!p || !l) return fail(MMG_ERR_ARG, "NULL argument");
+    std::memcpy(l, p->h_l.data(), p->n * sizeof(double));
+    return MMG_OK;
+}
+
+extern "C" int mmg_problem_start_values(const mmg_problem *p, double *mu0, int32_t *unique_hits)
+{
+    if (!p) return fail(MMG_ERR_ARG, "NULL problem");
+    HIP_TRY(hipSetDevice(p->device));
+    double *d_acc = nullptr;
+    int32_t *d_uh = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_acc, p->n * sizeof(double)));
+    if (hipMalloc((void **)&d_uh, p->n * sizeof(int32_t)) != hipSuccess) { (void)hipFree(d_acc); return fail(MMG_ERR_HIP, "hipMalloc"); }
+    int rc = MMG_OK;
+    do {
+        if (hipMemset(d_acc, 0, p->n * sizeof(double)) != hipSuccess || hipMemset(d_uh, 0, p->n * sizeof(int32_t)) != hipSuccess) { rc = fail(MMG_ERR_HIP, "hipMemset"); break; }
+        if (p->m) {
+            const unsigned gb = (unsigned)((p->m + 255) / 256);
+            if (p->idx64) hipLaunchKernelGGL(k_start_values<uint64_t>, dim3(gb), dim3(256), 0, 0, (const uint64_t *)p->d_row_ptr, p->d_col, p->d_k, p->m, d_acc, d_uh);
+            else hipLaunchKernelGGL(k_start_values<uint32_t>, dim3(gb), dim3(256), 0, 0, (const uint32_t *)p->d_row_ptr, p->d_col, p->d_k, p->m, d_acc, d_uh);
+        }
+        hipLaunchKernelGGL(k_div, dim3((p->n + 255) / 256), dim3(256), 0, 0, d_acc, p->d_l, p->n);
+        if (hipGetLastError() != hipSuccess) { rc = fail(MMG_ERR_HIP, "start_values launch"); break; }
+        if (mu0 && hipMemcpy(mu0, d_acc, p->n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(MMG_ERR_HIP, "hipMemcpy mu0"); break; }
+        if (unique_hits && hipMemcpy(unique_hits, d_uh, p->n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(MMG_ERR_HIP, "hipMemcpy uh"); break; }
+    } while (0);
+    (void)hipFree(d_acc);
+    (void)hipFree(d_uh);
+    return rc;
+}
+
+extern "C" int mmg_problem_em(const mmg_problem *p, double *mu, int max_iter, double epsilon, int *iters, double *loglik)
+{
+    if (!p || !mu) return fail(MMG_ERR_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(p->device));
+    double *d_mu = nullptr, *d_acc = nullptr, *d_ll = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_mu, p->n * sizeof(double)));
+    if (hipMalloc((void **)&d_acc, p->n * sizeof(double)) != hipSuccess || hipMalloc((void **)&d_ll, sizeof(double)) != hipSuccess) {
+        (void)hipFree(d_mu); if (d_acc) (void)hipFree(d_acc);
+        return fail(MMG_ERR_HIP, "hipMalloc");
+    }
+    int rc = MMG_OK, it = 0;
+    double ll_prev = 0.0;
+    const unsigned gr = (unsigned)std::max<uint64_t>((p->m + 255) / 256, 1), gc = (p->n + 255) / 256;
+    auto rows_pass = [&]() {
+        if (p->idx64) hipLaunchKernelGGL(k_em_rows<uint64_t>, dim3(gr), dim3(256), 0, 0, (const uint64_t *)p->d_row_ptr, p->d_col, p->d_k, p->m, d_mu, d_acc, d_ll);
+        else hipLaunchKernelGGL(k_em_rows<uint32_t>, dim3(gr), dim3(256), 0, 0, (const uint32_t *)p->d_row_ptr, p->d_col, p->d_k, p->m, d_mu, d_acc, d_ll);
+    };
+    do {
+#define EM_TRY(expr) if ((expr) != hipSuccess) { rc = fail(MMG_ERR_HIP, #expr); break; }
+        EM_TRY(hipMemcpy(d_mu, mu, p->n * sizeof(double), hipMemcpyHostToDevice));
+        EM_TRY(hipMemset(d_acc, 0, p->n * sizeof(double)));
+        EM_TRY(hipMemset(d_ll, 0, sizeof(double)));
+        rows_pass();
+        hipLaunchKernelGGL(k_em_cols, dim3(gc), dim3(256), 0, 0, d_mu, d_acc, p->d_l, p->n, d_ll, 0);
+        EM_TRY(hipMemcpy(&ll_prev, d_ll, sizeof(double), hipMemcpyDeviceToHost));
+        double llr = epsilon + 1.0;
+        bool err = false;
+        while (it < max_iter && llr > epsilon) {
+            if (hipMemset(d_ll, 0, sizeof(double)) != hipSuccess) { err = true; break; }
+            hipLaunchKernelGGL(k_em_cols, dim3(gc), dim3(256), 0, 0, d_mu, d_acc, p->d_l, p->n, d_ll, 1);
+            rows_pass();
+            double ll = 0.0;
+            if (hipMemcpy(&ll, d_ll, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { err = true; break; }
+            llr = ll - ll_prev;
+            ll_prev = ll;
+            ++it;
+        }
+        if (err) { rc = fail(MMG_ERR_HIP, "EM sweep failed"); break; }
+        EM_TRY(hipMemcpy(mu, d_mu, p->n * sizeof(double), hipMemcpyDeviceToHost));
+#undef EM_TRY
+    } while (0);
+    (void)hipFree(d_mu); (void)hipFree(d_acc); (void)hipFree(d_ll);
+    if (iters) *iters = it;
+    if (loglik) *loglik = ll_prev;
+    return rc;
+}
+
+extern "C" void mmg_problem_destroy(mmg_problem *p) { problem_free(p); }
+
+// ------------------------------------------------------------------------------ sampler
+struct mmg_sampler {
+    const mmg_problem *p = nullptr;
+    mmg_config cfg{};
+    hipStream_t own = nullptr, cur = nullptr;
+    double *d_mu = nullptr, *d_scale = nullptr, *d_trace = nullptr, *d_mom = nullptr; // mom: [2][C][n]
+    int32_t *d_cnt = nullptr, *d_cnt_last = nullptr;
+    int iter = 0;          // completed iterations
+    bool sampled = false;  // sample() issued for the current iteration, update() pending
+    int64_t n_kept = 0;
+    int grid_sample = 0;
+    // timing
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<std::pair<int, int>> ev_sample, ev_update; // indices into ev_pool
+    size_t ev_used = 0;
+    double acc_sample_ms = 0, acc_update_ms = 0;
+    uint64_t acc_sample_n = 0, acc_update_n = 0;
+};
+
+static void sampler_free(mmg_sampler *s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->p->device);
+    if (s->own) { (void)hipStreamSynchronize(s->own); }
+    for (auto e : s->ev_pool) (void)hipEventDestroy(e);
+    if (s->d_mu) (void)hipFree(s->d_mu);
+    if (s->d_scale) (void)hipFree(s->d_scale);
+    if (s->d_trace) (void)hipFree(s->d_trace);
+    if (s->d_mom) (void)hipFree(s->d_mom);
+    if (s->d_cnt) (void)hipFree(s->d_cnt);
+    if (s->d_cnt_last) (void)hipFree(s->d_cnt_last);
+    if (s->own) (void)hipStreamDestroy(s->own);
+    delete s;
+}
+
+extern "C" int mmg_sampler_create(const mmg_problem *p, const mmg_config *cfg, const double *mu0, mmg_sampler **out)
+{
+    if (!p || !cfg || !mu0 || !out) return fail(MMG_ERR_ARG, "NULL argument");
+    if (cfg->n_chains < 1 || cfg->n_chains > 4096) return fail(MMG_ERR_ARG, "n_chains out of range");
+    if (!(cfg->alpha > 0.0) || !(cfg->beta > 0.0)) return fail(MMG_ERR_ARG, "alpha, beta must be > 0");
+    if (cfg->trace_len < 1 || cfg->gibbs_iter < 1) return fail(MMG_ERR_ARG, "gibbs_iter and trace_len must be >= 1 (src/mmseq.cpp:286)");
+    if (cfg->gibbs_iter % cfg->trace_len != 0) return fail(MMG_ERR_ARG, "gibbs_iter must be a multiple of trace_len (src/mmseq.cpp:278-284)");
+    for (uint32_t t = 0; t < p->n; ++t)
+        if (!(mu0[t] >= 0.0)) return fail(MMG_ERR_ARG, "mu0 must be finite and >= 0");
+    int rc = require_device(p->device);
+    if (rc) return rc;
+    mmg_sampler *s = new mmg_sampler();
+    s->p = p;
+    s->cfg = *cfg;
+    const size_t C = (size_t)cfg->n_chains, n = p->n;
+    auto bail = [&](int code) { sampler_free(s); return code; };
+#define S_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return bail(fail(MMG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); } while (0)
+    S_TRY(hipStreamCreateWithFlags(&s->own, hipStreamNonBlocking));
+    s->cur = s->own;
+    S_TRY(hipMalloc((void **)&s->d_mu, C * n * sizeof(double)));
+    S_TRY(hipMalloc((void **)&s->d_scale, n * sizeof(double)));
+    S_TRY(hipMalloc((void **)&s->d_mom, 2 * C * n * sizeof(double)));
+    S_TRY(hipMalloc((void **)&s->d_cnt, C * n * sizeof(int32_t)));
+    S_TRY(hipMalloc((void **)&s->d_cnt_last, C * n * sizeof(int32_t)));
+    if (cfg->keep_trace) S_TRY(hipMalloc((void **)&s->d_trace, C * n * (size_t)cfg->trace_len * sizeof(double)));
+    std::vector<double> scale(n);
+    for (size_t t = 0; t < n; ++t) scale[t] = 1.0 / (cfg->beta + p->h_l[t]); // src/mmseq.cpp:907 second argument
+    S_TRY(hipMemcpy(s->d_scale, scale.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    for (size_t c = 0; c < C; ++c) S_TRY(hipMemcpy(s->d_mu + c * n, mu0, n * sizeof(double), hipMemcpyHostToDevice));
+    S_TRY(hipMemset(s->d_mom, 0, 2 * C * n * sizeof(double)));
+    S_TRY(hipMemset(s->d_cnt, 0, C * n * sizeof(int32_t)));
+    S_TRY(hipMemset(s->d_cnt_last, 0, C * n * sizeof(int32_t)));
+    if (s->d_trace) S_TRY(hipMemset(s->d_trace, 0, C * n * (size_t)cfg->trace_len * sizeof(double)));
+#undef S_TRY
+    // persistent grid: 3 workgroups per CU (48 KiB LDS each), striding over the tiles
+    const uint64_t want = (uint64_t)p->cu_count * 3;
+    s->grid_sample = (int)std::max<uint64_t>(1, std::min<uint64_t>(p->n_tiles, want));
+    *out = s;
+    return MMG_OK;
+}
+
+extern "C" int mmg_sampler_set_stream(mmg_sampler *s, void *hip_stream)
+{
+    if (!s) return fail(MMG_ERR_ARG, "NULL sampler");
+    s->cur = hip_stream ? (hipStream_t)hip_stream : s->own;
+    return MMG_OK;
+}
+
+static int ev_get(mmg_sampler *s, int &idx)
+{
+    if (s->ev_used == s->ev_pool.size()) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        s->ev_pool.push_back(e);
+    }
+    idx = (int)s->ev_used++;
+    return MMG_OK;
+}
+
+extern "C" int mmg_sampler_sample(mmg_sampler *s)
+{
+    if (!s) return fail(MMG_ERR_ARG, "NULL sampler");
+    if (s->sampled) return fail(MMG_ERR_STATE, "sample() already issued for this iteration; call update()");
+    const mmg_problem *p = s->p;
+    HIP_TRY(hipSetDevice(p->device));
+    int e0 = -1, e1 = -1;
+    if (s->cfg.timing) {
+        int rc = ev_get(s, e0); if (rc) return rc;
+        rc = ev_get(s, e1); if (rc) return rc;
+        HIP_TRY(hipEventRecord(s->ev_pool[e0], s->cur));
+    }
+    if (p->n_tiles > 0) {
+        for (int c = 0; c < s->cfg.n_chains; ++c) {
+            SampleArgs a;
+            a.row_ptr = p->d_row_ptr; a.col_idx = p->d_col; a.k = p->d_k; a.tile_row = p->d_tile_row;
+            a.n_tiles = p->n_tiles;
+            a.mu = s->d_mu + (size_t)c * p->n;
+            a.cnt = s->d_cnt + (size_t)c * p->n;
+            a.seed = s->cfg.seed; a.row_id_base = p->row_id_base;
+            a.chain = (uint32_t)(s->cfg.chain_base + c);
+            a.iter = (uint32_t)s->iter;
+            const dim3 g(s->grid_sample), b(K1_BLOCK);
+            if (p->idx64) {
+                if (p->d_k) hipLaunchKernelGGL((k_sample<uint64_t, true>), g, b, 0, s->cur, a);
+                else hipLaunchKernelGGL((k_sample<uint64_t, false>), g, b, 0, s->cur, a);
+            } else {
+                if (p->d_k) hipLaunchKernelGGL((k_sample<uint32_t, true>), g, b, 0, s->cur, a);
+                else hipLaunchKernelGGL((k_sample<uint32_t, false>), g, b, 0, s->cur, a);
+            }
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    if (s->cfg.timing) {
+        HIP_TRY(hipEventRecord(s->ev_pool[e1], s->cur));
+        s->ev_sample.push_back({e0, e1});
+    }
+    s->sampled = true;
+    return MMG_OK;
+}
+
+extern "C" int mmg_sampler_update(mmg_sampler *s)
+{
+    if (!s) return fail(MMG_ERR_ARG, "NULL sampler");
+    if (!s->sampled) return fail(MMG_ERR_STATE, "update() without a preceding sample()");
+    const mmg_problem *p = s->p;
+    HIP_TRY(hipSetDevice(p->device));
+    const int ss = s->cfg.gibbs_iter / s->cfg.trace_len; // src/mmseq.cpp:284
+    int sample_idx = -1;
+    if (s->iter % ss == 0 && s->iter / ss < s->cfg.trace_len) sample_idx = s->iter / ss; // :911, :914
+    const size_t C = (size_t)s->cfg.n_chains, n = p->n;
+    UpdateArgs a;
+    a.cnt = s->d_cnt; a.cnt_last = s->d_cnt_last; a.scale = s->d_scale; a.mu = s->d_mu; a.trace = s->d_trace;
+    a.sum_log = s->d_mom; a.sum_log2 = s->d_mom + C * n;
+    a.seed = s->cfg.seed; a.alpha = s->cfg.alpha; a.n = p->n; a.n_chains = (uint32_t)C;
+    a.chain_base = (uint32_t)s->cfg.chain_base; a.iter = (uint32_t)s->iter; a.sample_idx = sample_idx;
+    a.trace_len = (uint32_t)s->cfg.trace_len;
+    int e0 = -1, e1 = -1;
+    if (s->cfg.timing) {
+        int rc = ev_get(s, e0); if (rc) return rc;
+        rc = ev_get(s, e1); if (rc) return rc;
+        HIP_TRY(hipEventRecord(s->ev_pool[e0], s->cur));
+    }
+    const unsigned gb = (unsigned)((C * n + 255) / 256);
+    hipLaunchKernelGGL(k_update, dim3(gb), dim3(256), 0, s->cur, a);
+    HIP_TRY(hipGetLastError());
+    if (s->cfg.timing) {
+        HIP_TRY(hipEventRecord(s->ev_pool[e1], s->cur));
+        s->ev_update.push_back({e0, e1});
+    }
+    if (sample_idx >= 0) s->n_kept++;
+    s->iter++;
+    s->sampled = false;
+    return MMG_OK;
+}
+
+extern "C" int mmg_sampler_run(mmg_sampler *s, int n_iter)
+{
+    if (!s || n_iter < 0) return fail(MMG_ERR_ARG, "bad argument");
+    for (int i = 0; i < n_iter; ++i) {
+        int rc = mmg_sampler_sample(s);
+        if (rc) return rc;
+        rc = mmg_sampler_update(s);
+        if (rc) return rc;
+    }
+    return MMG_OK;
+}
+
+extern "C" int mmg_sampler_counts_devptr(mmg_sampler *s, void **ptr, uint64_t *count)
+{
+    if (!s || !ptr) return fail(MMG_ERR_ARG, "NULL argument");
+    *ptr = s->d_cnt;
+    if (count) *count = (uint64_t)s->cfg.n_chains * s->p->n;
+    return MMG_OK;
+}
+
+extern "C" int mmg_sampler_moments_devptr(mmg_sampler *s, void **ptr, uint64_t *count)
+{
+    if (!s || !ptr) return fail(MMG_ERR_ARG, "NULL argument");
+    *ptr = s->d_mom;
+    if (count) *count = 2ull * (uint64_t)s->cfg.n_chains * s->p->n;
+    return MMG_OK;
+}
+
+extern "C" int mmg_sampler_sync(mmg_sampler *s)
+{
+    if (!s) return fail(MMG_ERR_ARG, "NULL sampler");
+    HIP_TRY(hipSetDevice(s->p->device));
+    HIP_TRY(hipStreamSynchronize(s->cur));
+    return MMG_OK;
+}
+
+extern "C" int mmg_sampler_iteration(const mmg_sampler *s, int *iter)
+{
+    if (!s || !iter) return fail(MMG_ERR_ARG, "NULL argument");
+    *iter = s->iter;
+    return MMG_OK;
+}
+
+static int check_chain(const mmg_sampler *s, int chain)
+{
+    if (!s) return fail(MMG_ERR_ARG, "NULL sampler");
+    if (chain < 0 || chain >= s->cfg.n_chains) return fail(MMG_ERR_ARG, "chain index out of range");
+    return MMG_OK;
+}
+
+extern "C" int mmg_sampler_get_trace(mmg_sampler *s, int chain, double *out)
+{
+    int rc = check_chain(s, chain);
+    if (rc) return rc;
+    if (!out) return fail(MMG_ERR_ARG, "NULL out");
+    if (!s->d_trace) return fail(MMG_ERR_STATE, "sampler was created with keep_trace == 0");
+    HIP_TRY(hipSetDevice(s->p->device));
+    const size_t n = s->p->n, S = (size_t)s->cfg.trace_len;
+    double *d_tmp = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_tmp, n * S * sizeof(double)));
+    const dim3 g((unsigned)((n + 31) / 32), (unsigned)((S + 31) / 32));
+    hipLaunchKernelGGL(k_transpose, g, dim3(256), 0, s->cur, s->d_trace + (size_t)chain * S * n, d_tmp, (uint32_t)n, (uint32_t)S);
+    hipError_t e = hipStreamSynchronize(s->cur);
+    if (e == hipSuccess) e = hipMemcpy(out, d_tmp, n * S * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(d_tmp);
+    if (e != hipSuccess) return fail(MMG_ERR_HIP, std::string("get_trace: ") + hipGetErrorString(e));
+    return MMG_OK;
+}
+
+extern "C" int mmg_sampler_get_trace_rows(mmg_sampler *s, int chain, int first, int count, double *out)
+{
+    int rc = check_chain(s, chain);
+    if (rc) return rc;
+    if (!out || first < 0 || count < 0 || first + count > s->cfg.trace_len) return fail(MMG_ERR_ARG, "bad sample range");
+    if (!s->d_trace) return fail(MMG_ERR_STATE, "sampler was created with keep_trace == 0");
+    HIP_TRY(hipSetDevice(s->p->device));
+    HIP_TRY(hipStreamSynchronize(s->cur));
+    const size_t n = s->p->n, S = (size_t)s->cfg.trace_len;
+    HIP_TRY(hipMemcpy(out, s->d_trace + ((size_t)chain * S + (size_t)first) * n, (size_t)count * n * sizeof(double), hipMemcpyDeviceToHost));
+    return MMG_OK;
+}
+
+extern "C" int mmg_sampler_get_mu(mmg_sampler *s, int chain, double *mu)
+{
+    int rc = check_chain(s, chain);
+    if (rc) return rc;
+    if (!mu) return fail(MMG_ERR_ARG, "NULL out");
+    HIP_TRY(hipSetDevice(s->p->device));
+    HIP_TRY(hipStreamSynchronize(s->cur));
+    HIP_TRY(hipMemcpy(mu, s->d_mu + (size_t)chain * s->p->n, s->p->n * sizeof(double), hipMemcpyDeviceToHost));
+    return MMG_OK;
+}
+
+extern "C" int mmg_sampler_get_counts(mmg_sampler *s, int chain, int32_t *cnt)
+{
+    int rc = check_chain(s, chain);
+    if (rc) return rc;
+    if (!cnt) return fail(MMG_ERR_ARG, "NULL out");
+    HIP_TRY(hipSetDevice(s->p->device));
+    HIP_TRY(hipStreamSynchronize(s->cur));
+    // between sample() and update() the live counts are the interesting ones
+    const int32_t *src = (s->sampled ? s->d_cnt : s->d_cnt_last) + (size_t)chain * s->p->n;
+    HIP_TRY(hipMemcpy(cnt, src, s->p->n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return MMG_OK;
+}
+
+extern "C" int mmg_sampler_get_moments(mmg_sampler *s, int chain, double *sum_log, double *sum_log2, int64_t *n_samples)
+{
+    int rc = check_chain(s, chain);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(s->p->device));
+    HIP_TRY(hipStreamSynchronize(s->cur));
+    const size_t C = (size_t)s->cfg.n_chains, n = s->p->n;
+    if (sum_log) HIP_TRY(hipMemcpy(sum_log, s->d_mom + (size_t)chain * n, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (sum_log2) HIP_TRY(hipMemcpy(sum_log2, s->d_mom + (C + (size_t)chain) * n, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (n_samples) *n_samples = s->n_kept;
+    return MMG_OK;
+}
+
+static int drain_events(mmg_sampler *s)
+{
+    HIP_TRY(hipSetDevice(s->p->device));
+    HIP_TRY(hipStreamSynchronize(s->cur));
+    for (auto &pr : s->ev_sample) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, s->ev_pool[pr.first], s->ev_pool[pr.second]));
+        s->acc_sample_ms += ms; s->acc_sample_n++;
+    }
+    for (auto &pr : s->ev_update) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, s->ev_pool[pr.first], s->ev_pool[pr.second]));
+        s->acc_update_ms += ms; s->acc_update_n++;
+    }
+    s->ev_sample.clear(); s->ev_update.clear(); s->ev_used = 0;
+    return MMG_OK;
+}
+
+extern "C" int mmg_sampler_get_timing(mmg_sampler *s, mmg_timing *t)
+{
+    if (!s || !t) return fail(MMG_ERR_ARG, "NULL argument");
+    int rc = drain_events(s);
+    if (rc) return rc;
+    t->sample_ms = s->acc_sample_ms; t->update_ms = s->acc_update_ms;
+    t->sample_launches = s->acc_sample_n; t->update_launches = s->acc_update_n;
+    return MMG_OK;
+}
+
+extern "C" int mmg_sampler_reset_timing(mmg_sampler *s)
+{
+    if (!s) return fail(MMG_ERR_ARG, "NULL sampler");
+    int rc = drain_events(s);
+    if (rc) return rc;
+    s->acc_sample_ms = s->acc_update_ms = 0; s->acc_sample_n = s->acc_update_n = 0;
+    return MMG_OK;
+}
+
+extern "C" void mmg_sampler_destroy(mmg_sampler *s) { sampler_free(s); }
+
+// ------------------------------------------------------------------------------ self tests
+extern "C" int mmg_selftest_math(int device, int64_t n, const double *x, double *ol, double *oe, double *os, double *orc)
+{
+    if (n < 0 || !x || !ol || !oe || !os || !orc) return fail(MMG_ERR_ARG, "bad argument");
+    if (device < 0) {
+        for (int64_t i = 0; i < n; ++i) { ol[i] = dlog(x[i]); oe[i] = dexp(x[i]); os[i] = dsqrt(x[i]); orc[i] = 1.0 / x[i]; }
+        return MMG_OK;
+    }
+    int rc = require_device(device);
+    if (rc) return rc;
+    double *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, 5 * (size_t)n * sizeof(double) + 8));
+    hipError_t e = hipMemcpy(d, x, n * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess && n) {
+        hipLaunchKernelGGL(k_selftest_math, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, n, d, d + n, d + 2 * n, d + 3 * n, d + 4 * n);
+        e = hipDeviceSynchronize();
+    }
+    if (e == hipSuccess) e = hipMemcpy(ol, d + n, n * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(oe, d + 2 * n, n * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(os, d + 3 * n, n * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(orc, d + 4 * n, n * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(MMG_ERR_HIP, std::string("selftest_math: ") + hipGetErrorString(e));
+    return MMG_OK;
+}
+
+extern "C" int mmg_selftest_philox(int device, const uint32_t *ctr, const uint32_t *key, uint32_t *out)
+{
+    if (!ctr || !key || !out) return fail(MMG_ERR_ARG, "NULL argument");
+    if (device < 0) {
+        const U4 r = philox4x32_10(U4{ctr[0], ctr[1], ctr[2], ctr[3]}, key[0], key[1]);
+        out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+        return MMG_OK;
+    }
+    int rc = require_device(device);
+    if (rc) return rc;
+    uint32_t *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, 10 * sizeof(uint32_t)));
+    hipError_t e = hipMemcpy(d, ctr, 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + 4, key, 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) { hipLaunchKernelGGL(k_selftest_philox, dim3(1), dim3(1), 0, 0, d, d + 4, d + 6); e = hipDeviceSynchronize(); }
+    if (e == hipSuccess) e = hipMemcpy(out, d + 6, 16, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(MMG_ERR_HIP, std::string("selftest_philox: ") + hipGetErrorString(e));
+    return MMG_OK;
+}
+
+extern "C" int mmg_selftest_gamma(int device, uint64_t seed, double shape, double scale, int64_t n, double *out)
+{
+    if (n < 0 || !out || !(shape > 0.0)) return fail(MMG_ERR_ARG, "bad argument");
+    if (device < 0) {
+        for (int64_t i = 0; i < n; ++i) { Stream s(seed, 0, TAG_GAMMA, (uint64_t)i, 0); out[i] = gamma_unit(s, shape) * scale; }
+        return MMG_OK;
+    }
+    int rc = require_device(device);
+    if (rc) return rc;
+    double *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, (size_t)n * sizeof(double) + 8));
+    hipError_t e = hipSuccess;
+    if (n) { hipLaunchKernelGGL(k_selftest_gamma, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, seed, shape, scale, n, d); e = hipDeviceSynchronize(); }
+    if (e == hipSuccess) e = hipMemcpy(out, d, n * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(MMG_ERR_HIP, std::string("selftest_gamma: ") + hipGetErrorString(e));
+    return MMG_OK;
+}
+
+extern "C" int mmg_selftest_binomial(int device, uint64_t seed, uint32_t nn, double p, int64_t n, uint32_t *out)
+{
+    if (n < 0 || !out) return fail(MMG_ERR_ARG, "bad argument");
+    if (device < 0) {
+        for (int64_t i = 0; i < n; ++i) { SeqStream q(Stream(seed, 0, TAG_ROW, (uint64_t)i, 0)); out[i] = binomial(q, nn, p); }
+        return MMG_OK;
+    }
+    int rc = require_device(device);
+    if (rc) return rc;
+    uint32_t *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, (size_t)n * sizeof(uint32_t) + 8));
+    hipError_t e = hipSuccess;
+    if (n) { hipLaunchKernelGGL(k_selftest_binomial, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, seed, nn, p, n, d); e = hipDeviceSynchronize(); }
+    if (e == hipSuccess) e = hipMemcpy(out, d, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(MMG_ERR_HIP, std::string("selftest_binomial: ") + hipGetErrorString(e));
+    return MMG_OK;
+}

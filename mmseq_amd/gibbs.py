@@ -1,0 +1,228 @@
+"""Host-side view of the Gibbs hot path (thin mirror of include/mmgibbs.h).
+
+`Problem` is the reference's (M, k, l) triple (src/mmseq.cpp:117, :385, :593-608) resident in
+HBM; `Sampler` is the state of the loop at src/mmseq.cpp:851-918.  All compute happens in
+libmmgibbs.so's HIP kernels; this module only marshals numpy arrays across the C ABI.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Config, ProblemDesc, ProblemInfo, SynthDesc, Timing, check
+
+
+def device_count():
+    n = C.c_int(0)
+    check(_lib.load().mmg_device_count(C.byref(n)))
+    return n.value
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Problem:
+    """Device-resident CSR hit-set matrix + multiplicities + l."""
+
+    def __init__(self, handle):
+        self._h = handle
+        self._lib = _lib.load()
+
+    @classmethod
+    def from_csr(cls, row_ptr, col_idx, l, k=None, row_id_base=0, device=0):
+        lib = _lib.load()
+        row_ptr = np.ascontiguousarray(row_ptr, np.uint64)
+        col_idx = np.ascontiguousarray(col_idx, np.uint32)
+        l = np.ascontiguousarray(l, np.float64)
+        k = None if k is None else np.ascontiguousarray(k, np.uint32)
+        if row_ptr.size < 1:
+            raise ValueError("row_ptr needs m+1 >= 1 entries")
+        if k is not None and k.size != row_ptr.size - 1:
+            raise ValueError("k must have one entry per row")
+        d = ProblemDesc(row_ptr.size - 1, l.size, _ptr(row_ptr), _ptr(col_idx), _ptr(k), _ptr(l), row_id_base)
+        h = C.c_void_p()
+        check(lib.mmg_problem_create(C.byref(d), device, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def synthetic(cls, rows, n, avg_hits, seed=1234, row0=0, uniform=False, mapped_reads=0, device=0):
+        lib = _lib.load()
+        d = SynthDesc(seed, rows, row0, n, float(avg_hits), int(uniform), mapped_reads)
+        h = C.c_void_p()
+        check(lib.mmg_problem_create_synthetic(C.byref(d), device, C.byref(h)))
+        return cls(h)
+
+    @property
+    def info(self):
+        inf = ProblemInfo()
+        check(self._lib.mmg_problem_info_get(self._h, C.byref(inf)))
+        return inf
+
+    def download(self):
+        inf = self.info
+        rp = np.empty(inf.m + 1, np.uint64)
+        ci = np.empty(inf.nnz, np.uint32)
+        check(self._lib.mmg_problem_download(self._h, _ptr(rp), _ptr(ci)))
+        return rp, ci
+
+    def l(self):
+        out = np.empty(self.info.n, np.float64)
+        check(self._lib.mmg_problem_get_l(self._h, _ptr(out)))
+        return out
+
+    def start_values(self):
+        """(mu0, unique_hits) of src/mmseq.cpp:617-638."""
+        n = self.info.n
+        mu0 = np.empty(n, np.float64)
+        uh = np.empty(n, np.int32)
+        check(self._lib.mmg_problem_start_values(self._h, _ptr(mu0), _ptr(uh)))
+        return mu0, uh
+
+    def em(self, mu, max_iter=1000, epsilon=0.1):
+        """EM of src/mmseq.cpp:741-811. Returns (mu, iterations, loglik)."""
+        mu = np.array(mu, np.float64, copy=True)
+        it = C.c_int(0)
+        ll = C.c_double(0.0)
+        check(self._lib.mmg_problem_em(self._h, _ptr(mu), max_iter, epsilon, C.byref(it), C.byref(ll)))
+        return mu, it.value, ll.value
+
+    def close(self):
+        if self._h:
+            self._lib.mmg_problem_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Sampler:
+    """Chains of the Gibbs loop (src/mmseq.cpp:851-918) on one device."""
+
+    def __init__(self, problem, mu0, alpha=0.1, beta=0.1, seed=1234, n_chains=1, chain_base=0,
+                 gibbs_iter=1024, trace_len=1024, keep_trace=True, timing=False):
+        self._lib = _lib.load()
+        self.problem = problem
+        self.n = problem.info.n
+        self.n_chains = n_chains
+        self.trace_len = trace_len
+        mu0 = np.ascontiguousarray(mu0, np.float64)
+        if mu0.size != self.n:
+            raise ValueError("mu0 must have n entries")
+        cfg = Config(alpha, beta, seed, n_chains, chain_base, gibbs_iter, trace_len, int(keep_trace), int(timing))
+        h = C.c_void_p()
+        check(self._lib.mmg_sampler_create(problem._h, C.byref(cfg), _ptr(mu0), C.byref(h)))
+        self._h = h
+
+    def set_stream(self, hip_stream):
+        check(self._lib.mmg_sampler_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None))
+
+    def run(self, n_iter):
+        check(self._lib.mmg_sampler_run(self._h, n_iter))
+
+    def sample(self):
+        check(self._lib.mmg_sampler_sample(self._h))
+
+    def update(self):
+        check(self._lib.mmg_sampler_update(self._h))
+
+    def sync(self):
+        check(self._lib.mmg_sampler_sync(self._h))
+
+    @property
+    def iteration(self):
+        it = C.c_int(0)
+        check(self._lib.mmg_sampler_iteration(self._h, C.byref(it)))
+        return it.value
+
+    def counts_devptr(self):
+        p = C.c_void_p()
+        cnt = C.c_uint64()
+        check(self._lib.mmg_sampler_counts_devptr(self._h, C.byref(p), C.byref(cnt)))
+        return p.value, cnt.value
+
+    def moments_devptr(self):
+        p = C.c_void_p()
+        cnt = C.c_uint64()
+        check(self._lib.mmg_sampler_moments_devptr(self._h, C.byref(p), C.byref(cnt)))
+        return p.value, cnt.value
+
+    def trace(self, chain=0):
+        """Transcript-major trace [n, trace_len], the reference's mu_trace (src/mmseq.cpp:914)."""
+        out = np.empty((self.n, self.trace_len), np.float64)
+        check(self._lib.mmg_sampler_get_trace(self._h, chain, _ptr(out)))
+        return out
+
+    def trace_rows(self, chain=0, first=0, count=None):
+        count = self.trace_len - first if count is None else count
+        out = np.empty((count, self.n), np.float64)
+        check(self._lib.mmg_sampler_get_trace_rows(self._h, chain, first, count, _ptr(out)))
+        return out
+
+    def mu(self, chain=0):
+        out = np.empty(self.n, np.float64)
+        check(self._lib.mmg_sampler_get_mu(self._h, chain, _ptr(out)))
+        return out
+
+    def counts(self, chain=0):
+        out = np.empty(self.n, np.int32)
+        check(self._lib.mmg_sampler_get_counts(self._h, chain, _ptr(out)))
+        return out
+
+    def moments(self, chain=0):
+        sl = np.empty(self.n, np.float64)
+        sl2 = np.empty(self.n, np.float64)
+        ns = C.c_int64(0)
+        check(self._lib.mmg_sampler_get_moments(self._h, chain, _ptr(sl), _ptr(sl2), C.byref(ns)))
+        return sl, sl2, ns.value
+
+    def timing(self):
+        t = Timing()
+        check(self._lib.mmg_sampler_get_timing(self._h, C.byref(t)))
+        return dict(sample_ms=t.sample_ms, update_ms=t.update_ms, sample_launches=t.sample_launches,
+                    update_launches=t.update_launches)
+
+    def reset_timing(self):
+        check(self._lib.mmg_sampler_reset_timing(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mmg_sampler_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- self-test hooks -----------------------------------------------------------------------
+def selftest_math(x, device):
+    x = np.ascontiguousarray(x, np.float64)
+    outs = [np.empty_like(x) for _ in range(4)]
+    check(_lib.load().mmg_selftest_math(device, x.size, _ptr(x), *[_ptr(o) for o in outs]))
+    return dict(log=outs[0], exp=outs[1], sqrt=outs[2], rcp=outs[3])
+
+
+def selftest_philox(ctr, key, device):
+    ctr = np.ascontiguousarray(ctr, np.uint32)
+    key = np.ascontiguousarray(key, np.uint32)
+    out = np.zeros(4, np.uint32)
+    check(_lib.load().mmg_selftest_philox(device, _ptr(ctr), _ptr(key), _ptr(out)))
+    return out
+
+
+def selftest_gamma(seed, shape, scale, n, device):
+    out = np.empty(n, np.float64)
+    check(_lib.load().mmg_selftest_gamma(device, seed, shape, scale, n, _ptr(out)))
+    return out
+
+
+def selftest_binomial(seed, nn, p, n, device):
+    out = np.empty(n, np.uint32)
+    check(_lib.load().mmg_selftest_binomial(device, seed, nn, p, n, _ptr(out)))
+    return out

@@ -1,0 +1,244 @@
+"""ctypes binding of oracle/liboracle.so (built by oracle/Makefile from mmseq_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_SOKAL_REF = None
+
+u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+
+
+def build():
+    """(Re)build liboracle.so (and oracle/_ref when the reference tree is present)."""
+    subprocess.check_call(["make", "-C", _HERE, "-s"])
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = os.path.join(_HERE, "liboracle.so")
+    if not os.path.exists(path):
+        build()
+    L = C.CDLL(path)
+    L.orc_philox.argtypes = [u32p, u32p, u32p]
+    L.orc_log_v.argtypes = [C.c_int64, f64p, f64p]
+    L.orc_exp_v.argtypes = [C.c_int64, f64p, f64p]
+    L.orc_gamma_draw.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_double, C.c_double]
+    L.orc_gamma_draw.restype = C.c_double
+    L.orc_binomial_keyed.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_double]
+    L.orc_binomial_keyed.restype = C.c_uint32
+    L.orc_sample_counts.argtypes = [C.c_uint64, C.c_uint32, u64p, u32p, C.c_void_p, f64p, C.c_uint64,
+                                    C.c_uint32, C.c_uint32, C.c_uint64, i32p]
+    L.orc_gamma_update.argtypes = [C.c_uint32, i32p, f64p, C.c_double, C.c_double, C.c_uint64, C.c_uint32,
+                                   C.c_uint32, f64p]
+    L.orc_gibbs_keyed.argtypes = [C.c_uint64, C.c_uint32, u64p, u32p, C.c_void_p, f64p, f64p, C.c_double,
+                                  C.c_double, C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_uint64,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_gibbs_keyed.restype = C.c_int
+    L.orc_gibbs_ref.argtypes = [C.c_uint64, C.c_uint32, u64p, u32p, C.c_void_p, f64p, f64p, C.c_double,
+                                C.c_double, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.POINTER(C.c_double)]
+    L.orc_gibbs_ref.restype = C.c_int
+    L.orc_mt19937.argtypes = [C.c_uint32, C.c_int64, u32p]
+    L.orc_mt_gamma_v.argtypes = [C.c_uint32, C.c_double, C.c_double, C.c_int64, f64p]
+    L.orc_mt_binomial_v.argtypes = [C.c_uint32, C.c_uint32, C.c_double, C.c_int64, u32p]
+    L.orc_keyed_gamma_v.argtypes = [C.c_uint64, C.c_double, C.c_double, C.c_int64, f64p]
+    L.orc_keyed_binomial_v.argtypes = [C.c_uint64, C.c_uint32, C.c_double, C.c_int64, u32p]
+    L.orc_keyed_normal_v.argtypes = [C.c_uint64, C.c_int64, f64p]
+    L.orc_start_values.argtypes = [C.c_uint64, C.c_uint32, u64p, u32p, C.c_void_p, f64p, f64p, i32p]
+    L.orc_em.argtypes = [C.c_uint64, C.c_uint32, u64p, u32p, C.c_void_p, f64p, f64p, C.c_int, C.c_double,
+                         C.POINTER(C.c_double)]
+    L.orc_em.restype = C.c_int
+    L.orc_uh.argtypes = [C.c_uint64, C.c_uint32, u64p, u32p, C.c_void_p, C.c_uint32, u8p, i32p]
+    L.orc_sokal.argtypes = [C.c_int, f64p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    L.orc_sokal.restype = C.c_int
+    L.orc_synth_transcripts.argtypes = [C.c_uint64, C.c_uint32, f64p, f64p, f64p]
+    L.orc_synth_len_cdf.argtypes = [C.c_double, f64p]
+    L.orc_synth_row_len.argtypes = [C.c_uint64, C.c_uint64, f64p]
+    L.orc_synth_row_len.restype = C.c_uint32
+    L.orc_synth_csr.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, f64p, f64p, C.c_int, u64p,
+                                C.c_void_p]
+    _LIB = L
+    return L
+
+
+def _kptr(k):
+    return None if k is None else k.ctypes.data_as(C.c_void_p)
+
+
+def _optr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+# ----------------------------------------------------------------------------- primitives
+def philox(ctr, key):
+    out = np.zeros(4, np.uint32)
+    lib().orc_philox(np.asarray(ctr, np.uint32), np.asarray(key, np.uint32), out)
+    return out
+
+
+def log_v(x):
+    x = np.ascontiguousarray(x, np.float64)
+    out = np.empty_like(x)
+    lib().orc_log_v(x.size, x, out)
+    return out
+
+
+def exp_v(x):
+    x = np.ascontiguousarray(x, np.float64)
+    out = np.empty_like(x)
+    lib().orc_exp_v(x.size, x, out)
+    return out
+
+
+def mt19937(seed, n):
+    out = np.empty(n, np.uint32)
+    lib().orc_mt19937(seed, n, out)
+    return out
+
+
+# ----------------------------------------------------------------------------- Gibbs
+class Problem:
+    """CSR hit-set problem: rows = hit sets (or reads, k=1), columns = observed transcripts."""
+
+    def __init__(self, row_ptr, col_idx, l, k=None, mu0=None, n=None):
+        self.row_ptr = np.ascontiguousarray(row_ptr, np.uint64)
+        self.col_idx = np.ascontiguousarray(col_idx, np.uint32)
+        self.l = np.ascontiguousarray(l, np.float64)
+        self.k = None if k is None else np.ascontiguousarray(k, np.uint32)
+        self.m = self.row_ptr.size - 1
+        self.n = int(self.l.size if n is None else n)
+        self.mu0 = None if mu0 is None else np.ascontiguousarray(mu0, np.float64)
+        assert int(self.row_ptr[-1]) == self.col_idx.size
+
+    @property
+    def nnz(self):
+        return int(self.col_idx.size)
+
+    def total_k(self):
+        return int(self.m if self.k is None else self.k.sum(dtype=np.int64))
+
+
+def sample_counts(p, mu, seed, chain, it, row_id_base=0):
+    cnt = np.zeros(p.n, np.int32)
+    lib().orc_sample_counts(p.m, p.n, p.row_ptr, p.col_idx, _kptr(p.k), np.ascontiguousarray(mu, np.float64),
+                            seed, chain, it, row_id_base, cnt)
+    return cnt
+
+
+def gamma_update(cnt, l, alpha, beta, seed, chain, it):
+    mu = np.empty(len(l), np.float64)
+    lib().orc_gamma_update(len(l), np.ascontiguousarray(cnt, np.int32), np.ascontiguousarray(l, np.float64),
+                           alpha, beta, seed, chain, it, mu)
+    return mu
+
+
+def gibbs_keyed(p, mu0, alpha=0.1, beta=0.1, seed=1234, chain=0, n_iter=1024, trace_len=1024,
+                row_id_base=0, want_trace=True):
+    """Full keyed chain; returns dict(trace[n,trace_len], cnt, sum_log, sum_log2, mu)."""
+    trace = np.empty((p.n, trace_len), np.float64) if want_trace else None
+    cnt = np.empty(p.n, np.int32)
+    sl = np.empty(p.n, np.float64)
+    sl2 = np.empty(p.n, np.float64)
+    mu = np.empty(p.n, np.float64)
+    rc = lib().orc_gibbs_keyed(p.m, p.n, p.row_ptr, p.col_idx, _kptr(p.k), p.l,
+                               np.ascontiguousarray(mu0, np.float64), alpha, beta, seed, chain, n_iter,
+                               trace_len, row_id_base, _optr(trace), _optr(cnt), _optr(sl), _optr(sl2),
+                               _optr(mu))
+    if rc != 0:
+        raise ValueError("orc_gibbs_keyed rc=%d" % rc)
+    return dict(trace=trace, cnt=cnt, sum_log=sl, sum_log2=sl2, mu=mu)
+
+
+def gibbs_ref(p, mu0, alpha=0.1, beta=0.1, seed=1234, n_iter=1024, trace_len=1024, threads=1,
+              want_trace=True):
+    """Reference-structured chain (MT19937 per thread). Returns dict incl. loop seconds."""
+    trace = np.empty((p.n, trace_len), np.float64) if want_trace else None
+    cnt = np.empty(p.n, np.int32)
+    mu = np.empty(p.n, np.float64)
+    secs = C.c_double(0.0)
+    rc = lib().orc_gibbs_ref(p.m, p.n, p.row_ptr, p.col_idx, _kptr(p.k), p.l,
+                             np.ascontiguousarray(mu0, np.float64), alpha, beta, seed, n_iter, trace_len,
+                             threads, _optr(trace), _optr(cnt), _optr(mu), C.byref(secs))
+    if rc != 0:
+        raise ValueError("orc_gibbs_ref rc=%d" % rc)
+    return dict(trace=trace, cnt=cnt, mu=mu, seconds=secs.value)
+
+
+def start_values(p):
+    mu0 = np.empty(p.n, np.float64)
+    uh = np.empty(p.n, np.int32)
+    lib().orc_start_values(p.m, p.n, p.row_ptr, p.col_idx, _kptr(p.k), p.l, mu0, uh)
+    return mu0, uh
+
+
+def em(p, mu, max_iter=1000, epsilon=0.1):
+    mu = np.array(mu, np.float64, copy=True)
+    ll = C.c_double(0.0)
+    it = lib().orc_em(p.m, p.n, p.row_ptr, p.col_idx, _kptr(p.k), p.l, mu, max_iter, epsilon, C.byref(ll))
+    return mu, it, ll.value
+
+
+def uh(p, member):
+    member = np.ascontiguousarray(member, np.uint8)
+    G = member.shape[1]
+    res = np.empty(G, np.int32)
+    lib().orc_uh(p.m, p.n, p.row_ptr, p.col_idx, _kptr(p.k), G, member, res)
+    return res
+
+
+def sokal(x):
+    """Oracle restatement of src/sokal.cc:33-87. Returns (rc, var, tau, m)."""
+    x = np.array(x, np.float64, copy=True)
+    var, tau, m = C.c_double(0), C.c_double(0), C.c_int(0)
+    rc = lib().orc_sokal(x.size, x, C.byref(var), C.byref(tau), C.byref(m))
+    return rc, var.value, tau.value, m.value
+
+
+def sokal_ref(x):
+    """The compiled REFERENCE sokal (oracle/_ref/libsokal_ref.so); None if absent."""
+    global _SOKAL_REF
+    path = os.path.join(_HERE, "_ref", "libsokal_ref.so")
+    if not os.path.exists(path):
+        return None
+    if _SOKAL_REF is None:
+        _SOKAL_REF = C.CDLL(path)
+        _SOKAL_REF.sokal.argtypes = [C.POINTER(C.c_int), f64p, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                     C.POINTER(C.c_int)]
+        _SOKAL_REF.sokal.restype = C.c_int
+    x = np.array(x, np.float64, copy=True)
+    n = C.c_int(x.size)
+    var, tau, m = C.c_double(0), C.c_double(0), C.c_int(0)
+    rc = _SOKAL_REF.sokal(C.byref(n), x, C.byref(var), C.byref(tau), C.byref(m))
+    return rc, var.value, tau.value, m.value
+
+
+# ----------------------------------------------------------------------------- synthetic input
+def synth_problem(R, T, avg_hits, seed=1234, uniform=False, row0=0, mapped_reads=None):
+    """Synthetic problem of SURVEY.md App. D: rows [row0,row0+R), k=1. Returns (Problem, efflen)."""
+    L = lib()
+    efflen = np.empty(T, np.float64)
+    theta = np.empty(T, np.float64)
+    cdf = np.empty(T, np.float64)
+    L.orc_synth_transcripts(seed, T, efflen, theta, cdf)
+    len_cdf = np.empty(99, np.float64)
+    L.orc_synth_len_cdf(float(avg_hits) - 1.0, len_cdf)
+    row_ptr = np.empty(R + 1, np.uint64)
+    L.orc_synth_csr(seed, row0, R, T, cdf, len_cdf, int(uniform), row_ptr, None)
+    col = np.empty(int(row_ptr[-1]), np.uint32)
+    L.orc_synth_csr(seed, row0, R, T, cdf, len_cdf, int(uniform), row_ptr, col.ctypes.data_as(C.c_void_p))
+    nreads = R if mapped_reads is None else mapped_reads
+    l = efflen * float(nreads) / 1e9  # src/mmseq.cpp:603
+    return Problem(row_ptr, col, l), dict(efflen=efflen, theta=theta, cdf=cdf, len_cdf=len_cdf)

@@ -1,0 +1,189 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs.  Integer outputs and -- because both sides implement the same keyed-stream spec
+with once-rounded fp64 arithmetic -- fp64 traces are required to be BIT-IDENTICAL."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(orc, R, T, avg, seed=1234, **kw):
+    p, aux = orc.synth_problem(R=R, T=T, avg_hits=avg, seed=seed, **kw)
+    mu0, uh = orc.start_values(p)
+    return p, mu0, uh
+
+
+def test_device_math_matches_oracle(gpu, orc):
+    rng = np.random.default_rng(3)
+    x = np.concatenate([np.exp(rng.uniform(-700, 700, 300000)), rng.uniform(-745, 709, 300000),
+                        rng.uniform(0, 4, 100000), [5e-324, 1e-310, 1.0, 0.5, 2.0, 1e300]])
+    r = gpu.selftest_math(x, 0)
+    assert np.array_equal(r["log"], orc.log_v(x), equal_nan=True)
+    assert np.array_equal(r["exp"], orc.exp_v(x), equal_nan=True)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        assert np.array_equal(r["sqrt"], np.sqrt(x), equal_nan=True)      # correctly rounded on both
+        assert np.array_equal(r["rcp"], 1.0 / x, equal_nan=True)
+
+
+def test_device_philox_kat(gpu):
+    assert [hex(v) for v in gpu.selftest_philox([0, 0, 0, 0], [0, 0], 0)] == \
+        ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    assert [hex(v) for v in gpu.selftest_philox([0xffffffff] * 4, [0xffffffff] * 2, 0)] == \
+        ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+
+
+@pytest.mark.parametrize("shape", [0.1, 0.9, 1.0, 1.1, 7.3, 1234.1])
+def test_device_gamma_bit_exact(gpu, orc, shape):
+    n = 50000
+    got = gpu.selftest_gamma(99, shape, 0.37, n, 0)
+    ref = np.empty(n)
+    orc.lib().orc_keyed_gamma_v(99, shape, 0.37, n, ref)
+    assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("nn,p", [(1, 0.3), (9, 0.5), (40, 0.2), (1000, 0.31), (100000, 0.93), (77, 1e-4)])
+def test_device_binomial_bit_exact(gpu, orc, nn, p):
+    n = 20000
+    got = gpu.selftest_binomial(5, nn, p, n, 0)
+    ref = np.empty(n, np.uint32)
+    orc.lib().orc_keyed_binomial_v(5, nn, p, n, ref)
+    assert np.array_equal(got, ref)
+
+
+def test_sample_counts_bit_exact_single_sweep(gpu, orc):
+    p, mu0, _ = _mk(orc, 50000, 3000, 6)
+    prob = gpu.Problem.from_csr(p.row_ptr, p.col_idx, p.l)
+    s = gpu.Sampler(prob, mu0, seed=42, gibbs_iter=4, trace_len=4)
+    s.sample()
+    cnt = s.counts(0)
+    ref = orc.sample_counts(p, mu0, 42, 0, 0)
+    assert np.array_equal(cnt, ref)
+    assert int(cnt.sum()) == p.total_k()
+    s.update()
+    mu1 = s.mu(0)
+    assert np.array_equal(mu1, orc.gamma_update(ref, p.l, 0.1, 0.1, 42, 0, 0))
+
+
+@pytest.mark.parametrize("R,T,avg", [(10000, 1000, 4), (30000, 500, 12), (2000, 4000, 2)])
+def test_full_chain_bit_exact(gpu, orc, R, T, avg):
+    p, mu0, _ = _mk(orc, R, T, avg)
+    prob = gpu.Problem.from_csr(p.row_ptr, p.col_idx, p.l)
+    s = gpu.Sampler(prob, mu0, seed=1234, gibbs_iter=128, trace_len=64)
+    s.run(128)
+    ref = orc.gibbs_keyed(p, mu0, seed=1234, n_iter=128, trace_len=64)
+    assert np.array_equal(s.counts(0), ref["cnt"])
+    assert np.array_equal(s.trace(0), ref["trace"])
+    assert np.array_equal(s.mu(0), ref["mu"])
+    sl, sl2, ns = s.moments(0)
+    assert ns == 64
+    assert np.array_equal(sl, ref["sum_log"]) and np.array_equal(sl2, ref["sum_log2"])
+    rows = s.trace_rows(0)
+    assert np.array_equal(rows.T, ref["trace"])
+
+
+def test_rows_with_multiplicity_bit_exact(gpu, orc):
+    """k > 1 rows: k <= 8 -> repeated categorical draws; k > 8 -> conditional-binomial chain."""
+    p, mu0, _ = _mk(orc, 5000, 400, 5)
+    rng = np.random.default_rng(7)
+    k = rng.choice([1, 2, 3, 8, 9, 50, 1000, 20000], size=p.m).astype(np.uint32)
+    pk = orc.Problem(p.row_ptr, p.col_idx, p.l * 50, k=k)
+    mu0, uh = orc.start_values(pk)
+    prob = gpu.Problem.from_csr(pk.row_ptr, pk.col_idx, pk.l, k=pk.k)
+    s = gpu.Sampler(prob, mu0, seed=9, gibbs_iter=32, trace_len=32)
+    s.run(32)
+    ref = orc.gibbs_keyed(pk, mu0, seed=9, n_iter=32, trace_len=32)
+    cnt = s.counts(0)
+    assert int(cnt.sum()) == pk.total_k()
+    assert np.array_equal(cnt, ref["cnt"])
+    assert np.array_equal(s.trace(0), ref["trace"])
+
+
+def test_edge_rows(gpu, orc):
+    """Empty rows, single-hit rows, a row longer than a tile (> 4096 hits), ragged tail."""
+    T = 6000
+    rows = [[], [5], [1, 2], list(range(0, 5000)), [7], [], [3, 4, 5], list(range(100, 4300)), [T - 1, ]]
+    rp = np.cumsum([0] + [len(r) for r in rows]).astype(np.uint64)
+    ci = np.concatenate([np.asarray(r, np.uint32) for r in rows])
+    l = np.linspace(0.5, 2.0, T)
+    k = np.array([3, 4, 1, 9, 1, 1, 30, 2, 1], np.uint32)
+    p = orc.Problem(rp, ci, l, k=k)
+    mu0 = np.full(T, 0.25)
+    mu0[::7] = 1e-300
+    prob = gpu.Problem.from_csr(rp, ci, l, k=k)
+    assert prob.info.max_row_len == 5000
+    s = gpu.Sampler(prob, mu0, seed=5, gibbs_iter=16, trace_len=16)
+    s.run(16)
+    ref = orc.gibbs_keyed(p, mu0, seed=5, n_iter=16, trace_len=16)
+    assert np.array_equal(s.counts(0), ref["cnt"])
+    assert np.array_equal(s.trace(0), ref["trace"])
+    assert int(s.counts(0).sum()) == int(k[[1, 2, 3, 4, 6, 7, 8]].sum())
+
+
+def test_chains_and_shards_reproduce_single_chain(gpu, orc):
+    """(a) chain c of a multi-chain sampler == a single-chain sampler with chain_base=c;
+    (b) read-sharding: two shards' counts summed (the all-reduce) == the unsharded chain."""
+    p, mu0, _ = _mk(orc, 20000, 800, 5)
+    prob = gpu.Problem.from_csr(p.row_ptr, p.col_idx, p.l)
+    multi = gpu.Sampler(prob, mu0, seed=11, n_chains=3, gibbs_iter=32, trace_len=32)
+    multi.run(32)
+    for c in range(3):
+        ref = orc.gibbs_keyed(p, mu0, seed=11, chain=c, n_iter=32, trace_len=32)
+        assert np.array_equal(multi.trace(c), ref["trace"])
+    # (b) shard rows [0,h) and [h,m) with row_id_base; emulate the int32 all-reduce on the host
+    h = p.m // 3
+    nz = int(p.row_ptr[h])
+    pa = gpu.Problem.from_csr(p.row_ptr[:h + 1], p.col_idx[:nz], p.l)
+    pb = gpu.Problem.from_csr(p.row_ptr[h:] - p.row_ptr[h], p.col_idx[nz:], p.l, row_id_base=h)
+    ref = orc.gibbs_keyed(p, mu0, seed=11, chain=0, n_iter=1, trace_len=1)
+    sa = gpu.Sampler(pa, mu0, seed=11, gibbs_iter=1, trace_len=1)
+    sb = gpu.Sampler(pb, mu0, seed=11, gibbs_iter=1, trace_len=1)
+    sa.sample(); sb.sample()
+    assert np.array_equal(sa.counts(0) + sb.counts(0), ref["cnt"])
+
+
+def test_device_generator_matches_oracle_generator(gpu, orc):
+    for (R, T, avg, uni, row0) in [(30000, 2000, 8, False, 0), (5000, 300, 20, False, 12345), (4000, 5000, 3, True, 7),
+                                   (1000, 50, 20, False, 0)]:
+        prob = gpu.Problem.synthetic(R, T, avg, seed=1234, row0=row0, uniform=uni, mapped_reads=R)
+        rp, ci = prob.download()
+        p, aux = orc.synth_problem(R=R, T=T, avg_hits=avg, seed=1234, uniform=uni, row0=row0)
+        assert np.array_equal(rp, p.row_ptr)
+        assert np.array_equal(ci, p.col_idx)
+        assert np.array_equal(prob.l(), p.l)
+        lens = np.diff(rp.astype(np.int64))
+        assert lens.min() >= 1 and lens.max() <= 100
+        # rows ascend strictly (distinct transcripts, sorted)
+        d = np.diff(ci.astype(np.int64))
+        inner = np.ones(ci.size - 1, bool)
+        inner[(rp[1:-1] - 1).astype(np.int64)] = False
+        assert (d[inner] > 0).all()
+
+
+def test_start_values_and_em_match_oracle(gpu, orc):
+    p, mu0, uh = _mk(orc, 40000, 1500, 4)
+    prob = gpu.Problem.from_csr(p.row_ptr, p.col_idx, p.l)
+    g_mu0, g_uh = prob.start_values()
+    assert np.array_equal(g_uh, uh)                       # integer: bit-exact
+    np.testing.assert_allclose(g_mu0, mu0, rtol=1e-12, atol=0)
+    em_o, it_o, ll_o = orc.em(p, mu0)
+    em_g, it_g, ll_g = prob.em(mu0)
+    assert it_g == it_o
+    np.testing.assert_allclose(ll_g, ll_o, rtol=1e-10)
+    pos = em_o > 1e-200
+    np.testing.assert_allclose(em_g[pos], em_o[pos], rtol=1e-9)
+
+
+def test_errors_are_loud(gpu):
+    with pytest.raises(Exception):
+        gpu.Problem.from_csr(np.array([0, 2], np.uint64), np.array([0, 9], np.uint32), np.ones(3))
+    with pytest.raises(Exception):
+        gpu.Problem.from_csr(np.array([0, 1], np.uint64), np.array([0], np.uint32), np.array([1.0, 0.0]))
+    prob = gpu.Problem.from_csr(np.array([0, 1], np.uint64), np.array([0], np.uint32), np.ones(2))
+    with pytest.raises(Exception):
+        gpu.Sampler(prob, np.ones(2), gibbs_iter=100, trace_len=64)
+    s = gpu.Sampler(prob, np.ones(2), gibbs_iter=4, trace_len=4, keep_trace=False)
+    s.run(4)
+    with pytest.raises(Exception):
+        s.trace(0)
+    with pytest.raises(Exception):
+        s.update()
