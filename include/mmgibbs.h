@@ -64,6 +64,9 @@ typedef struct mmg_synth_desc {
     uint32_t n;           /* transcripts                                                  */
     double avg_hits;      /* row length = min(100, 1 + Poisson(avg_hits - 1))             */
     int32_t uniform;      /* 0: hits inside a +-64 index window; 1: uniform over n        */
+    int32_t sorted;       /* 1: rows stably ordered by leading transcript (the order hit-set
+                             collapse yields; what the sample kernel's LDS window wants);
+                             0: generator order (a name-sorted BAM's order)               */
     uint64_t mapped_reads;/* N in l = efflen * N / 1e9; 0 => rows                         */
 } mmg_synth_desc;
 

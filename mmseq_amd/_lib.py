@@ -24,7 +24,8 @@ class ProblemDesc(C.Structure):
 
 class SynthDesc(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("rows", C.c_uint64), ("row0", C.c_uint64), ("n", C.c_uint32),
-                ("avg_hits", C.c_double), ("uniform", C.c_int32), ("mapped_reads", C.c_uint64)]
+                ("avg_hits", C.c_double), ("uniform", C.c_int32), ("sorted", C.c_int32),
+                ("mapped_reads", C.c_uint64)]
 
 
 class ProblemInfo(C.Structure):

@@ -17,36 +17,39 @@
 namespace mmg {
 
 constexpr int K1_BLOCK = 256;
-constexpr int K1_TILE_NNZ = 4096;            // hits staged per tile (LDS: 4096 * 12 B = 48 KiB)
-constexpr int K1_LDS_ELEMS = K1_TILE_NNZ + 8; // + alignment slack of the 16-byte stream
+constexpr int K1_LDS_ELEMS = 4096;            // LDS column-id staging buffer (16 KiB)
+constexpr int K1_TILE_NNZ = K1_LDS_ELEMS - 8; // hits per tile: leaves the alignment slack of the 16-byte stream
+                                              // (16 + 16 + 8 KiB = 40 KiB LDS per workgroup -> 4 workgroups per CU)
+constexpr int K1_WIN = 2048;                  // transcripts covered by the LDS window (mu 16 KiB + counts 8 KiB)
+constexpr uint32_t K1_WIN_MARGIN = 160;       // hits are expected within this many ids above a row's first hit
 constexpr uint32_t K_SMALL = 8u;              // == MMG_K_SMALL
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 struct SampleArgs {
-    const void *row_ptr;      // IdxT[m+1]
-    const uint32_t *col_idx;  // nnz (+ 16 B padding)
-    const uint32_t *k;        // m or nullptr
-    const uint64_t *tile_row; // n_tiles+1
-    uint64_t n_tiles;
-    const double *mu;         // n
-    int32_t *cnt;             // n
+    const void *row_ptr;        // IdxT[m+1]
+    const uint32_t *col_idx;    // nnz (+ 32 B padding)
+    const uint32_t *k;          // m or nullptr
+    const uint64_t *tile_row;   // n_tiles+1
+    const uint64_t *chunk_tile; // n_chunks+1 : contiguous tile ranges, one per workgroup visit
+    uint64_t n_chunks;
+    const double *mu;           // n
+    int32_t *cnt;               // n
     uint64_t seed;
     uint64_t row_id_base;
+    uint32_t n;
     uint32_t chain;
     uint32_t iter;
 };
 
-// One row: cols/w point at the row's segment (LDS or global-gathered), counts added atomically.
-template <bool HAS_K, typename ColAt, typename WAt>
-__device__ __forceinline__ void allocate_row(ColAt col_at, WAt w_at, uint32_t L, uint32_t kk, const SampleArgs &a,
+// One row.  col_at(j) / w_at(j) read the j-th hit and its weight, add(col, v) adds v to the count
+// of transcript col (LDS window or global).  Restates src/mmseq.cpp:871-889 for the row.
+template <bool HAS_K, typename ColAt, typename WAt, typename Add>
+__device__ __forceinline__ void allocate_row(ColAt col_at, WAt w_at, Add add, uint32_t L, uint32_t kk, const SampleArgs &a,
                                              uint64_t row_id)
 {
     if (L == 0 || kk == 0) return;
-    if (L == 1) {
-        __hip_atomic_fetch_add(&a.cnt[col_at(0)], (int32_t)kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
+    if (L == 1) { add(col_at(0), (int32_t)kk); return; }
     double total = 0.0;
     for (uint32_t j = 0; j < L; ++j) total += w_at(j);
     const bool degenerate = !(total > 0.0) || !(total < __builtin_huge_val());
@@ -69,7 +72,7 @@ __device__ __forceinline__ void allocate_row(ColAt col_at, WAt w_at, uint32_t L,
                     if (target < acc) { sel = j; break; }
                 }
             }
-            __hip_atomic_fetch_add(&a.cnt[col_at(sel)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            add(col_at(sel), 1);
         }
         return;
     }
@@ -82,60 +85,112 @@ __device__ __forceinline__ void allocate_row(ColAt col_at, WAt w_at, uint32_t L,
         double p = degenerate ? 1.0 / (double)(L - j) : (rem_w > 0.0 ? w / rem_w : 1.0);
         if (p > 1.0) p = 1.0;
         const uint32_t x = binomial(q, remaining, p);
-        if (x) __hip_atomic_fetch_add(&a.cnt[col_at(j)], (int32_t)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (x) add(col_at(j), (int32_t)x);
         remaining -= x;
         rem_w -= w;
     }
-    if (remaining > 0)
-        __hip_atomic_fetch_add(&a.cnt[col_at(L - 1)], (int32_t)remaining, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (remaining > 0) add(col_at(L - 1), (int32_t)remaining);
 }
 
+__device__ __forceinline__ void global_count_add(int32_t *cnt, uint32_t col, int32_t v)
+{
+    __hip_atomic_fetch_add(&cnt[col], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// K1.  A workgroup walks a contiguous chunk of tiles.  Rows arrive sorted by leading transcript
+// (the order hit-set collapse produces), so consecutive tiles touch a slowly advancing band of
+// transcripts: that band's mu and counts live in an LDS window [base, base+K1_WIN); hits outside
+// the window fall back to the L2 gather / global atomic, so any row order is CORRECT, sorted
+// order is FAST (global int32 atomics cap at ~26 G/s on MI355X, LDS atomics at >100 G/s).
 template <typename IdxT, bool HAS_K>
 __global__ __launch_bounds__(K1_BLOCK) void k_sample(SampleArgs a)
 {
-    __shared__ __attribute__((aligned(16))) double s_w[K1_LDS_ELEMS];
     __shared__ __attribute__((aligned(16))) uint32_t s_col[K1_LDS_ELEMS];
+    __shared__ __attribute__((aligned(16))) double s_mu[K1_WIN];
+    __shared__ int32_t s_cnt[K1_WIN];
     const IdxT *__restrict__ row_ptr = (const IdxT *)a.row_ptr;
     const int tid = threadIdx.x;
 
-    for (uint64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-        const uint64_t r0 = a.tile_row[tile], r1 = a.tile_row[tile + 1];
-        const uint64_t nz0 = (uint64_t)row_ptr[r0], nz1 = (uint64_t)row_ptr[r1];
-        const uint64_t nt = nz1 - nz0;
-        if (nt > (uint64_t)K1_TILE_NNZ) {
-            // a single row longer than a tile: one lane walks it straight from global memory
-            if (tid == 0) {
-                const uint32_t *cols = a.col_idx + nz0;
-                const double *mu = a.mu;
-                allocate_row<HAS_K>([&](uint32_t j) { return cols[j]; }, [&](uint32_t j) { return mu[cols[j]]; },
-                                    (uint32_t)nt, HAS_K ? a.k[r0] : 1u, a, a.row_id_base + r0);
+    for (int i = tid; i < K1_WIN; i += K1_BLOCK) s_cnt[i] = 0;
+    uint32_t base = 0xffffffffu; // no window yet (every lookup misses)
+    bool win_valid = false;
+
+    auto flush_window = [&]() {
+        if (!win_valid) return;
+        for (int i = tid; i < K1_WIN; i += K1_BLOCK) {
+            const int32_t v = s_cnt[i];
+            if (v) { global_count_add(a.cnt, base + (uint32_t)i, v); s_cnt[i] = 0; }
+        }
+    };
+
+    for (uint64_t chunk = blockIdx.x; chunk < a.n_chunks; chunk += gridDim.x) {
+        const uint64_t tile_end = a.chunk_tile[chunk + 1];
+        for (uint64_t tile = a.chunk_tile[chunk]; tile < tile_end; ++tile) {
+            const uint64_t r0 = a.tile_row[tile], r1 = a.tile_row[tile + 1];
+            const uint64_t nz0 = (uint64_t)row_ptr[r0], nz1 = (uint64_t)row_ptr[r1];
+            const uint64_t nt = nz1 - nz0;
+            if (nt > (uint64_t)K1_TILE_NNZ) {
+                // a single row longer than a tile: one lane walks it straight from global memory
+                if (tid == 0) {
+                    const uint32_t *cols = a.col_idx + nz0;
+                    const double *mu = a.mu;
+                    int32_t *cnt = a.cnt;
+                    allocate_row<HAS_K>([&](uint32_t j) { return cols[j]; }, [&](uint32_t j) { return mu[cols[j]]; },
+                                        [&](uint32_t c, int32_t v) { global_count_add(cnt, c, v); }, (uint32_t)nt,
+                                        HAS_K ? a.k[r0] : 1u, a, a.row_id_base + r0);
+                }
+                continue;
             }
-            continue;
+            if (nt == 0) continue; // only empty rows
+            // ---- phase 1: stream the tile's column ids into LDS (16-byte aligned, non-temporal)
+            const uint64_t abase = nz0 & ~(uint64_t)3;
+            const uint32_t shift = (uint32_t)(nz0 - abase);
+            const uint32_t nchunks = (uint32_t)((nz1 - abase + 3) >> 2);
+            const u32x4 *__restrict__ src = (const u32x4 *)(a.col_idx + abase);
+            for (uint32_t ch = tid; ch < nchunks; ch += K1_BLOCK)
+                *(u32x4 *)(s_col + 4 * ch) = __builtin_nontemporal_load(src + ch);
+            __syncthreads();
+            // ---- window decision (uniform): first hit of the first / last non-empty row
+            const uint32_t cmin = s_col[shift];
+            uint64_t rl = r1 - 1;
+            while (rl > r0 && (uint64_t)row_ptr[rl] == nz1) --rl; // skip trailing empty rows
+            const uint32_t clast = s_col[(uint32_t)((uint64_t)row_ptr[rl] - nz0) + shift];
+            const bool keep = win_valid && cmin >= base && (uint64_t)clast + K1_WIN_MARGIN <= (uint64_t)base + K1_WIN;
+            if (!keep) {
+                flush_window();
+                base = cmin & ~15u;
+                win_valid = true;
+                for (int i = tid; i < K1_WIN; i += K1_BLOCK) {
+                    const uint32_t c = base + (uint32_t)i;
+                    s_mu[i] = c < a.n ? a.mu[c] : 0.0;
+                }
+                __syncthreads();
+            }
+            // ---- phase 2: one lane per row walks its LDS segment
+            const uint32_t wbase = base;
+            const double *__restrict__ gmu = a.mu;
+            int32_t *gcnt = a.cnt;
+            for (uint64_t r = r0 + tid; r < r1; r += K1_BLOCK) {
+                const uint32_t b = (uint32_t)((uint64_t)row_ptr[r] - nz0) + shift;
+                const uint32_t L = (uint32_t)((uint64_t)row_ptr[r + 1] - (uint64_t)row_ptr[r]);
+                const uint32_t *cl = s_col + b;
+                allocate_row<HAS_K>(
+                    [&](uint32_t j) { return cl[j]; },
+                    [&](uint32_t j) {
+                        const uint32_t c = cl[j], d = c - wbase;
+                        return d < (uint32_t)K1_WIN ? s_mu[d] : gmu[c];
+                    },
+                    [&](uint32_t c, int32_t v) {
+                        const uint32_t d = c - wbase;
+                        if (d < (uint32_t)K1_WIN) atomicAdd(&s_cnt[d], v);
+                        else global_count_add(gcnt, c, v);
+                    },
+                    L, HAS_K ? a.k[r] : 1u, a, a.row_id_base + r);
+            }
+            __syncthreads();
         }
-        // ---- phase 1: stream the tile's hits (16-byte aligned chunks), gather weights -> LDS
-        const uint64_t abase = nz0 & ~(uint64_t)3;
-        const uint32_t shift = (uint32_t)(nz0 - abase);
-        const uint32_t nchunks = (uint32_t)((nz1 - abase + 3) >> 2);
-        const u32x4 *__restrict__ src = (const u32x4 *)(a.col_idx + abase);
-        for (uint32_t ch = tid; ch < nchunks; ch += K1_BLOCK) {
-            const u32x4 c = __builtin_nontemporal_load(src + ch);
-            const double w0 = a.mu[c.x], w1 = a.mu[c.y], w2 = a.mu[c.z], w3 = a.mu[c.w];
-            *(u32x4 *)(s_col + 4 * ch) = c;
-            *(f64x2 *)(s_w + 4 * ch) = f64x2{w0, w1};
-            *(f64x2 *)(s_w + 4 * ch + 2) = f64x2{w2, w3};
-        }
-        __syncthreads();
-        // ---- phase 2: one lane per row walks its LDS segment
-        for (uint64_t r = r0 + tid; r < r1; r += K1_BLOCK) {
-            const uint32_t b = (uint32_t)((uint64_t)row_ptr[r] - nz0) + shift;
-            const uint32_t L = (uint32_t)((uint64_t)row_ptr[r + 1] - (uint64_t)row_ptr[r]);
-            const double *w = s_w + b;
-            const uint32_t *cl = s_col + b;
-            allocate_row<HAS_K>([&](uint32_t j) { return cl[j]; }, [&](uint32_t j) { return w[j]; }, L,
-                                HAS_K ? a.k[r] : 1u, a, a.row_id_base + r);
-        }
-        __syncthreads();
     }
+    flush_window();
 }
 
 struct UpdateArgs {
@@ -291,7 +346,20 @@ __host__ __device__ __forceinline__ uint32_t synth_len_from_u(const double *len_
     return 1 + j;
 }
 
-__global__ __launch_bounds__(256) void k_synth_len(SynthArgs a, uint32_t *lens)
+__device__ __forceinline__ uint32_t synth_first(const SynthArgs &a, double ub)
+{
+    const uint32_t T = a.n;
+    const double target = ub * a.cdf[T - 1];
+    uint32_t lo = 0, hi = T - 1;
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (target < a.cdf[mid]) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+// lens[r] = row length, keys[r] = leading (smallest) transcript of generator row row0 + r
+__global__ __launch_bounds__(256) void k_synth_len(SynthArgs a, uint32_t *lens, uint32_t *keys)
 {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= a.rows) return;
@@ -301,27 +369,55 @@ __global__ __launch_bounds__(256) void k_synth_len(SynthArgs a, uint32_t *lens)
     uint32_t L = synth_len_from_u(a.len_cdf, ua);
     if (L > a.n) L = a.n;
     lens[r] = L;
+    if (!keys) return;
+    // the leading transcript is min(t0, smallest window pick): replay the walk
+    const uint32_t T = a.n, t0 = synth_first(a, ub);
+    uint32_t best = t0;
+    if (L > 1) {
+        const uint32_t W = a.uniform ? T : (T < 129u ? T : 129u);
+        uint32_t wb = 0;
+        if (!a.uniform) {
+            int64_t b = (int64_t)t0 - 64;
+            if (b < 0) b = 0;
+            if (b + (int64_t)W > (int64_t)T) b = (int64_t)T - (int64_t)W;
+            wb = (uint32_t)b;
+        }
+        const uint32_t nslots = W - 1;
+        uint32_t Wp = 1;
+        while (Wp < nslots) Wp <<= 1;
+        double uc, ud;
+        s.pair(uc, ud);
+        const uint32_t start = (uint32_t)(uc * (double)Wp);
+        const uint32_t stride = ((uint32_t)(ud * (double)(Wp / 2 ? Wp / 2 : 1)) << 1) | 1u;
+        uint32_t got = 1, pos = start & (Wp - 1);
+        while (got < L) {
+            if (pos < nslots) {
+                uint32_t t = wb + pos;
+                if (t >= t0) t += 1;
+                if (t < best) best = t;
+                ++got;
+            }
+            pos = (pos + stride) & (Wp - 1);
+        }
+    }
+    keys[r] = best;
 }
 
 template <typename IdxT>
-__global__ __launch_bounds__(256) void k_synth_fill(SynthArgs a, const IdxT *__restrict__ row_ptr, uint32_t *col_idx)
+__global__ __launch_bounds__(256) void k_synth_fill(SynthArgs a, const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ perm,
+                                                    uint32_t *col_idx)
 {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= a.rows) return;
-    Stream s(a.seed, 0, TAG_SYNTH_ROW, a.row0 + r, 0);
+    // stored row r holds generator row perm[r] (identity when unsorted)
+    Stream s(a.seed, 0, TAG_SYNTH_ROW, a.row0 + (perm ? (uint64_t)perm[r] : r), 0);
     double ua, ub;
     s.pair(ua, ub);
     uint32_t L = synth_len_from_u(a.len_cdf, ua);
     const uint32_t T = a.n;
     if (L > T) L = T;
     uint32_t *cols = col_idx + (uint64_t)row_ptr[r];
-    const double target = ub * a.cdf[T - 1];
-    uint32_t lo = 0, hi = T - 1;
-    while (lo < hi) {
-        const uint32_t mid = lo + (hi - lo) / 2;
-        if (target < a.cdf[mid]) hi = mid; else lo = mid + 1;
-    }
-    const uint32_t t0 = lo;
+    const uint32_t t0 = synth_first(a, ub);
     cols[0] = t0;
     if (L <= 1) return;
     const uint32_t W = a.uniform ? T : (T < 129u ? T : 129u);

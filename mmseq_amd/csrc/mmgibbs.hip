@@ -63,6 +63,9 @@ struct mmg_problem {
     uint32_t *d_k = nullptr;
     double *d_l = nullptr;
     uint64_t *d_tile_row = nullptr;
+    uint64_t *d_chunk_tile = nullptr;
+    uint64_t n_chunks = 0;
+    int grid_sample = 1;
     std::vector<double> h_l;
 };
 
@@ -75,6 +78,7 @@ static void problem_free(mmg_problem *p)
     if (p->d_k) (void)hipFree(p->d_k);
     if (p->d_l) (void)hipFree(p->d_l);
     if (p->d_tile_row) (void)hipFree(p->d_tile_row);
+    if (p->d_chunk_tile) (void)hipFree(p->d_chunk_tile);
     delete p;
 }
 
@@ -124,6 +128,23 @@ static int problem_finish(mmg_problem *p, const uint64_t *h_row_ptr)
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, p->device));
     p->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    // Persistent grid: every resident workgroup (4 per CU at 40 KiB LDS) walks q contiguous
+    // chunks of tiles, so its LDS window slides monotonically over the sorted rows.
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sample<uint32_t, false>, K1_BLOCK, 0) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 4;
+    }
+    const uint64_t resident = (uint64_t)p->cu_count * (uint64_t)std::min(per_cu, 4);
+    const uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>(p->n_tiles, resident));
+    const uint64_t q = std::max<uint64_t>(1, std::min<uint64_t>(8, p->n_tiles / (grid * 32)));
+    p->n_chunks = p->n_tiles ? grid * q : 0;
+    p->grid_sample = (int)grid;
+    std::vector<uint64_t> chunk(p->n_chunks + 1, 0);
+    for (uint64_t c = 0; c <= p->n_chunks; ++c)
+        chunk[c] = p->n_chunks ? (uint64_t)(((unsigned __int128)p->n_tiles * c) / p->n_chunks) : 0;
+    HIP_TRY(hipMalloc((void **)&p->d_chunk_tile, chunk.size() * sizeof(uint64_t)));
+    HIP_TRY(hipMemcpy(p->d_chunk_tile, chunk.data(), chunk.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
     return MMG_OK;
 }
 
@@ -214,8 +235,10 @@ extern "C" int mmg_problem_create_synthetic(const mmg_synth_desc *d, int device,
     p->h_l.resize(d->n);
     for (uint32_t t = 0; t < d->n; ++t) p->h_l[t] = efflen[t] * N / 1000000000.0; // src/mmseq.cpp:603
     double *d_cdf = nullptr, *d_len_cdf = nullptr;
-    uint32_t *d_lens = nullptr;
-    auto cleanup = [&]() { if (d_cdf) (void)hipFree(d_cdf); if (d_len_cdf) (void)hipFree(d_len_cdf); if (d_lens) (void)hipFree(d_lens); };
+    uint32_t *d_lens = nullptr, *d_keys = nullptr, *d_perm = nullptr;
+    auto cleanup = [&]() { if (d_cdf) (void)hipFree(d_cdf); if (d_len_cdf) (void)hipFree(d_len_cdf); if (d_lens) (void)hipFree(d_lens);
+                           if (d_keys) (void)hipFree(d_keys); if (d_perm) (void)hipFree(d_perm); };
+    if (d->sorted && d->rows >= 0xffffffffull) return fail(MMG_ERR_ARG, "sorted synthetic problems need rows < 2^32 per device");
     auto bail = [&](int code) { cleanup(); problem_free(p); return code; };
 #define SYN_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return bail(fail(MMG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); } while (0)
     SYN_TRY(hipMalloc((void **)&d_cdf, d->n * sizeof(double)));
@@ -225,16 +248,30 @@ extern "C" int mmg_problem_create_synthetic(const mmg_synth_desc *d, int device,
     SYN_TRY(hipMemcpy(d_len_cdf, len_cdf.data(), 99 * sizeof(double), hipMemcpyHostToDevice));
     SynthArgs sa{d->seed, d->row0, d->rows, d->n, d->uniform, d_cdf, d_len_cdf};
     const unsigned gb = (unsigned)((d->rows + 255) / 256);
-    hipLaunchKernelGGL(k_synth_len, dim3(gb), dim3(256), 0, 0, sa, d_lens);
+    if (d->sorted) SYN_TRY(hipMalloc((void **)&d_keys, d->rows * sizeof(uint32_t)));
+    hipLaunchKernelGGL(k_synth_len, dim3(gb), dim3(256), 0, 0, sa, d_lens, d_keys);
     SYN_TRY(hipGetLastError());
     std::vector<uint32_t> lens(d->rows);
     SYN_TRY(hipMemcpy(lens.data(), d_lens, d->rows * sizeof(uint32_t), hipMemcpyDeviceToHost));
     std::vector<uint64_t> rp(d->rows + 1);
     rp[0] = 0;
-    for (uint64_t r = 0; r < d->rows; ++r) rp[r + 1] = rp[r] + lens[r];
+    if (d->sorted) {
+        // stable counting sort of the rows by leading transcript (keys < n): deterministic order
+        std::vector<uint32_t> keys(d->rows), perm(d->rows);
+        SYN_TRY(hipMemcpy(keys.data(), d_keys, d->rows * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        std::vector<uint64_t> pos((size_t)d->n + 1, 0);
+        for (uint64_t r = 0; r < d->rows; ++r) pos[(size_t)keys[r] + 1]++;
+        for (uint32_t t = 0; t < d->n; ++t) pos[t + 1] += pos[t];
+        for (uint64_t r = 0; r < d->rows; ++r) perm[pos[keys[r]]++] = (uint32_t)r;
+        for (uint64_t r = 0; r < d->rows; ++r) rp[r + 1] = rp[r] + lens[perm[r]];
+        SYN_TRY(hipMalloc((void **)&d_perm, d->rows * sizeof(uint32_t)));
+        SYN_TRY(hipMemcpy(d_perm, perm.data(), d->rows * sizeof(uint32_t), hipMemcpyHostToDevice));
+    } else {
+        for (uint64_t r = 0; r < d->rows; ++r) rp[r + 1] = rp[r] + lens[r];
+    }
     std::vector<uint32_t>().swap(lens);
     p->nnz = rp[d->rows];
-    const size_t col_bytes = (p->nnz + 8) * sizeof(uint32_t);
+    const size_t col_bytes = (p->nnz + 16) * sizeof(uint32_t);
     SYN_TRY(hipMalloc((void **)&p->d_col, col_bytes));
     SYN_TRY(hipMemset(p->d_col, 0, col_bytes));
     p->device_bytes += col_bytes;
@@ -243,8 +280,8 @@ extern "C" int mmg_problem_create_synthetic(const mmg_synth_desc *d, int device,
     p->device_bytes += d->n * 8;
     rc = problem_finish(p, rp.data());
     if (rc) return bail(rc);
-    if (p->idx64) hipLaunchKernelGGL(k_synth_fill<uint64_t>, dim3(gb), dim3(256), 0, 0, sa, (const uint64_t *)p->d_row_ptr, p->d_col);
-    else hipLaunchKernelGGL(k_synth_fill<uint32_t>, dim3(gb), dim3(256), 0, 0, sa, (const uint32_t *)p->d_row_ptr, p->d_col);
+    if (p->idx64) hipLaunchKernelGGL(k_synth_fill<uint64_t>, dim3(gb), dim3(256), 0, 0, sa, (const uint64_t *)p->d_row_ptr, (const uint32_t *)d_perm, p->d_col);
+    else hipLaunchKernelGGL(k_synth_fill<uint32_t>, dim3(gb), dim3(256), 0, 0, sa, (const uint32_t *)p->d_row_ptr, (const uint32_t *)d_perm, p->d_col);
     SYN_TRY(hipGetLastError());
     SYN_TRY(hipDeviceSynchronize());
 #undef SYN_TRY
@@ -371,7 +408,6 @@ struct mmg_sampler {
     int iter = 0;          // completed iterations
     bool sampled = false;  // sample() issued for the current iteration, update() pending
     int64_t n_kept = 0;
-    int grid_sample = 0;
     // timing
     std::vector<hipEvent_t> ev_pool;
     std::vector<std::pair<int, int>> ev_sample, ev_update; // indices into ev_pool
@@ -430,9 +466,6 @@ extern "C" int mmg_sampler_create(const mmg_problem *p, const mmg_config *cfg, c
     S_TRY(hipMemset(s->d_cnt_last, 0, C * n * sizeof(int32_t)));
     if (s->d_trace) S_TRY(hipMemset(s->d_trace, 0, C * n * (size_t)cfg->trace_len * sizeof(double)));
 #undef S_TRY
-    // persistent grid: 3 workgroups per CU (48 KiB LDS each), striding over the tiles
-    const uint64_t want = (uint64_t)p->cu_count * 3;
-    s->grid_sample = (int)std::max<uint64_t>(1, std::min<uint64_t>(p->n_tiles, want));
     *out = s;
     return MMG_OK;
 }
@@ -471,13 +504,13 @@ extern "C" int mmg_sampler_sample(mmg_sampler *s)
         for (int c = 0; c < s->cfg.n_chains; ++c) {
             SampleArgs a;
             a.row_ptr = p->d_row_ptr; a.col_idx = p->d_col; a.k = p->d_k; a.tile_row = p->d_tile_row;
-            a.n_tiles = p->n_tiles;
+            a.chunk_tile = p->d_chunk_tile; a.n_chunks = p->n_chunks; a.n = p->n;
             a.mu = s->d_mu + (size_t)c * p->n;
             a.cnt = s->d_cnt + (size_t)c * p->n;
             a.seed = s->cfg.seed; a.row_id_base = p->row_id_base;
             a.chain = (uint32_t)(s->cfg.chain_base + c);
             a.iter = (uint32_t)s->iter;
-            const dim3 g(s->grid_sample), b(K1_BLOCK);
+            const dim3 g(p->grid_sample), b(K1_BLOCK);
             if (p->idx64) {
                 if (p->d_k) hipLaunchKernelGGL((k_sample<uint64_t, true>), g, b, 0, s->cur, a);
                 else hipLaunchKernelGGL((k_sample<uint64_t, false>), g, b, 0, s->cur, a);

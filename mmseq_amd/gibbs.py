@@ -46,9 +46,10 @@ class Problem:
         return cls(h)
 
     @classmethod
-    def synthetic(cls, rows, n, avg_hits, seed=1234, row0=0, uniform=False, mapped_reads=0, device=0):
+    def synthetic(cls, rows, n, avg_hits, seed=1234, row0=0, uniform=False, mapped_reads=0, device=0,
+                  sort=True):
         lib = _lib.load()
-        d = SynthDesc(seed, rows, row0, n, float(avg_hits), int(uniform), mapped_reads)
+        d = SynthDesc(seed, rows, row0, n, float(avg_hits), int(uniform), int(sort), mapped_reads)
         h = C.c_void_p()
         check(lib.mmg_problem_create_synthetic(C.byref(d), device, C.byref(h)))
         return cls(h)

@@ -226,7 +226,7 @@ def sokal_ref(x):
 
 
 # ----------------------------------------------------------------------------- synthetic input
-def synth_problem(R, T, avg_hits, seed=1234, uniform=False, row0=0, mapped_reads=None):
+def synth_problem(R, T, avg_hits, seed=1234, uniform=False, row0=0, mapped_reads=None, sort=True):
     """Synthetic problem of SURVEY.md App. D: rows [row0,row0+R), k=1. Returns (Problem, efflen)."""
     L = lib()
     efflen = np.empty(T, np.float64)
@@ -239,6 +239,17 @@ def synth_problem(R, T, avg_hits, seed=1234, uniform=False, row0=0, mapped_reads
     L.orc_synth_csr(seed, row0, R, T, cdf, len_cdf, int(uniform), row_ptr, None)
     col = np.empty(int(row_ptr[-1]), np.uint32)
     L.orc_synth_csr(seed, row0, R, T, cdf, len_cdf, int(uniform), row_ptr, col.ctypes.data_as(C.c_void_p))
+    if sort and R > 0:
+        # rows stably ordered by leading (smallest) transcript -- the layout the sample kernel wants
+        lens = np.diff(row_ptr.astype(np.int64))
+        first = col[row_ptr[:-1].astype(np.int64)]
+        perm = np.argsort(first, kind="stable")
+        new_rp = np.zeros(R + 1, np.uint64)
+        new_rp[1:] = np.cumsum(lens[perm])
+        starts = row_ptr[:-1].astype(np.int64)[perm]
+        idx = np.repeat(starts - new_rp[:-1].astype(np.int64), lens[perm]) + np.arange(col.size, dtype=np.int64)
+        col = np.ascontiguousarray(col[idx])
+        row_ptr = new_rp
     nreads = R if mapped_reads is None else mapped_reads
     l = efflen * float(nreads) / 1e9  # src/mmseq.cpp:603
     return Problem(row_ptr, col, l), dict(efflen=efflen, theta=theta, cdf=cdf, len_cdf=len_cdf)

@@ -7,6 +7,18 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+def test_unsorted_rows_still_bit_exact(gpu, orc):
+    """Row order only affects speed (LDS window hit rate), never the result."""
+    p, aux = orc.synth_problem(R=40000, T=6000, avg_hits=6, seed=3, sort=False)
+    mu0, _ = orc.start_values(p)
+    prob = gpu.Problem.from_csr(p.row_ptr, p.col_idx, p.l)
+    s = gpu.Sampler(prob, mu0, seed=8, gibbs_iter=16, trace_len=16)
+    s.run(16)
+    ref = orc.gibbs_keyed(p, mu0, seed=8, n_iter=16, trace_len=16)
+    assert np.array_equal(s.counts(0), ref["cnt"])
+    assert np.array_equal(s.trace(0), ref["trace"])
+
+
 def _mk(orc, R, T, avg, seed=1234, **kw):
     p, aux = orc.synth_problem(R=R, T=T, avg_hits=avg, seed=seed, **kw)
     mu0, uh = orc.start_values(p)
@@ -142,11 +154,12 @@ def test_chains_and_shards_reproduce_single_chain(gpu, orc):
 
 
 def test_device_generator_matches_oracle_generator(gpu, orc):
-    for (R, T, avg, uni, row0) in [(30000, 2000, 8, False, 0), (5000, 300, 20, False, 12345), (4000, 5000, 3, True, 7),
-                                   (1000, 50, 20, False, 0)]:
-        prob = gpu.Problem.synthetic(R, T, avg, seed=1234, row0=row0, uniform=uni, mapped_reads=R)
+    for (R, T, avg, uni, row0, srt) in [(30000, 2000, 8, False, 0, True), (5000, 300, 20, False, 12345, True),
+                                        (4000, 5000, 3, True, 7, True), (1000, 50, 20, False, 0, False),
+                                        (20000, 1000, 8, False, 99, False)]:
+        prob = gpu.Problem.synthetic(R, T, avg, seed=1234, row0=row0, uniform=uni, mapped_reads=R, sort=srt)
         rp, ci = prob.download()
-        p, aux = orc.synth_problem(R=R, T=T, avg_hits=avg, seed=1234, uniform=uni, row0=row0)
+        p, aux = orc.synth_problem(R=R, T=T, avg_hits=avg, seed=1234, uniform=uni, row0=row0, sort=srt)
         assert np.array_equal(rp, p.row_ptr)
         assert np.array_equal(ci, p.col_idx)
         assert np.array_equal(prob.l(), p.l)

@@ -4,9 +4,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from mmseq_amd import Problem, Sampler
 
-def probe(R, T, avg, iters=20, chains=1, uniform=False):
+def probe(R, T, avg, iters=20, chains=1, uniform=False, sort=True):
     t0 = time.time()
-    prob = Problem.synthetic(R, T, avg, seed=1234, uniform=uniform)
+    prob = Problem.synthetic(R, T, avg, seed=1234, uniform=uniform, sort=sort)
     inf = prob.info
     t1 = time.time()
     mu0, uh = prob.start_values()
@@ -21,7 +21,7 @@ def probe(R, T, avg, iters=20, chains=1, uniform=False):
     k1 = tm["sample_ms"] / tm["sample_launches"]
     k2 = tm["update_ms"] / tm["update_launches"]
     wall = (t4 - t3) / iters * 1e3
-    print(f"R={R} T={T} avg={avg} C={chains} uni={uniform} nnz={inf.nnz} tiles={inf.n_tiles} gen={t1-t0:.1f}s start={t2-t1:.2f}s "
+    print(f"R={R} T={T} avg={avg} C={chains} uni={uniform} sort={sort} nnz={inf.nnz} tiles={inf.n_tiles} gen={t1-t0:.1f}s start={t2-t1:.2f}s "
           f"K1={k1:.3f}ms K2={k2:.3f}ms wall/iter={wall:.3f}ms  B={B/1e6:.1f}MB  K1 GB/s={(4*(inf.m+1)+4*inf.nnz)/k1/1e6:.0f} "
           f"iter/s={1e3/wall:.1f} chain-it/s={chains*1e3/wall:.1f} frac8TB={B/(wall*1e-3)/8e12:.3f}", flush=True)
     cnt = s.counts(0)
@@ -30,6 +30,6 @@ def probe(R, T, avg, iters=20, chains=1, uniform=False):
 
 if __name__ == "__main__":
     probe(5_000_000, 50_000, 8)
-    probe(5_000_000, 50_000, 8, uniform=True)
+    probe(5_000_000, 50_000, 8, sort=False)
     probe(50_000_000, 200_000, 20, iters=10)
-    probe(50_000_000, 200_000, 20, iters=5, chains=2)
+    probe(50_000_000, 200_000, 20, iters=5, sort=False)
