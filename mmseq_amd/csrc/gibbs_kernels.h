@@ -17,22 +17,32 @@
 namespace mmg {
 
 constexpr int K1_BLOCK = 256;
-constexpr int K1_LDS_ELEMS = 4096;            // LDS column-id staging buffer (16 KiB)
-constexpr int K1_TILE_NNZ = K1_LDS_ELEMS - 8; // hits per tile: leaves the alignment slack of the 16-byte stream
-                                              // (16 + 16 + 8 KiB = 40 KiB LDS per workgroup -> 4 workgroups per CU)
-constexpr int K1_WIN = 2048;                  // transcripts covered by the LDS window (mu 16 KiB + counts 8 KiB)
 constexpr uint32_t K1_WIN_MARGIN = 160;       // hits are expected within this many ids above a row's first hit
 constexpr uint32_t K_SMALL = 8u;              // == MMG_K_SMALL
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
+// K1 variants (compile-time): LDS staging elements (tile = ELEMS-8 hits), window width, unroll
+enum : int { K1M_NO_PHASE2 = 1 };
+
+// One tile of consecutive rows, built once per problem (k_tile_desc)
+struct TileDesc {
+    uint64_t nz0;   // first hit of the tile in col_idx
+    uint64_t r0;    // first row
+    uint32_t nrows;
+    uint32_t nnz;   // > tile capacity <=> a single long row handled by the slow path
+    uint32_t cmin;  // leading transcript of the first non-empty row
+    uint32_t clast; // leading transcript of the last non-empty row
+    uint32_t cmax;  // largest transcript id in the tile
+    uint32_t call;  // smallest transcript id in the tile (== cmin when rows are sorted)
+};
+
 struct SampleArgs {
     const void *row_ptr;        // IdxT[m+1]
-    const uint32_t *col_idx;    // nnz (+ 32 B padding)
+    const uint32_t *col_idx;    // nnz (+ 64 B padding)
     const uint32_t *k;          // m or nullptr
-    const uint64_t *tile_row;   // n_tiles+1
-    const uint64_t *chunk_tile; // n_chunks+1 : contiguous tile ranges, one per workgroup visit
-    uint64_t n_chunks;
+    const TileDesc *tiles;      // n_tiles
+    const uint64_t *chunk_tile; // grid+1 : one contiguous tile range per workgroup
     const double *mu;           // n
     int32_t *cnt;               // n
     uint64_t seed;
@@ -42,16 +52,111 @@ struct SampleArgs {
     uint32_t iter;
 };
 
-// One row.  col_at(j) / w_at(j) read the j-th hit and its weight, add(col, v) adds v to the count
-// of transcript col (LDS window or global).  Restates src/mmseq.cpp:871-889 for the row.
-template <bool HAS_K, typename ColAt, typename WAt, typename Add>
-__device__ __forceinline__ void allocate_row(ColAt col_at, WAt w_at, Add add, uint32_t L, uint32_t kk, const SampleArgs &a,
-                                             uint64_t row_id)
+__device__ __forceinline__ void global_count_add(int32_t *cnt, uint32_t col, int32_t v)
 {
+    __hip_atomic_fetch_add(&cnt[col], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- row views: how phase 2 reads one row's hits and weights -------------------------------
+// total() / pick() implement the k == 1 fast path; every variant performs the SAME sequence of
+// fp64 additions in row order (adding an exact 0.0 for masked slots), so all are bit-identical.
+template <int WIN, int UNR, bool INWIN>
+struct RowViewWin {
+    const uint32_t *cl; // row's column ids in LDS
+    uint32_t L;
+    uint32_t wbase;
+    const double *s_mu;
+    const double *gmu;
+    __device__ __forceinline__ uint32_t col(uint32_t j) const { return cl[j]; }
+    __device__ __forceinline__ double wc(uint32_t c) const
+    {
+        const uint32_t d = c - wbase;
+        if (INWIN) return s_mu[d];
+        return d < (uint32_t)WIN ? s_mu[d] : gmu[c];
+    }
+    __device__ __forceinline__ double w(uint32_t j) const { return wc(cl[j]); }
+    __device__ __forceinline__ double total() const
+    {
+        double t = 0.0;
+        if (UNR <= 1) {
+            for (uint32_t j = 0; j < L; ++j) t += w(j);
+            return t;
+        }
+        const uint32_t last = L - 1;
+        for (uint32_t j = 0; j < L; j += UNR) {
+            uint32_t c[UNR];
+            double wv[UNR];
+#pragma unroll
+            for (int i = 0; i < UNR; ++i) c[i] = cl[min(j + (uint32_t)i, last)];
+#pragma unroll
+            for (int i = 0; i < UNR; ++i) wv[i] = wc(c[i]);
+#pragma unroll
+            for (int i = 0; i < UNR; ++i) t += (j + (uint32_t)i < L) ? wv[i] : 0.0;
+        }
+        return t;
+    }
+    __device__ __forceinline__ uint32_t pick(double target) const
+    {
+        double acc = 0.0;
+        if (UNR <= 1) {
+            for (uint32_t j = 0; j < L; ++j) {
+                acc += w(j);
+                if (target < acc) return j;
+            }
+            return L - 1;
+        }
+        const uint32_t last = L - 1;
+        for (uint32_t j = 0; j < L; j += UNR) {
+            uint32_t c[UNR];
+            double wv[UNR];
+#pragma unroll
+            for (int i = 0; i < UNR; ++i) c[i] = cl[min(j + (uint32_t)i, last)];
+#pragma unroll
+            for (int i = 0; i < UNR; ++i) wv[i] = wc(c[i]);
+            uint32_t found = 0xffffffffu;
+#pragma unroll
+            for (int i = 0; i < UNR; ++i) {
+                acc += (j + (uint32_t)i < L) ? wv[i] : 0.0;
+                if (found == 0xffffffffu && target < acc) found = min(j + (uint32_t)i, last);
+            }
+            if (found != 0xffffffffu) return found;
+        }
+        return last;
+    }
+};
+
+// long rows: everything from global memory
+struct RowViewGlobal {
+    const uint32_t *cl;
+    const double *gmu;
+    uint32_t L;
+    __device__ __forceinline__ uint32_t col(uint32_t j) const { return cl[j]; }
+    __device__ __forceinline__ double w(uint32_t j) const { return gmu[cl[j]]; }
+    __device__ __forceinline__ double total() const
+    {
+        double t = 0.0;
+        for (uint32_t j = 0; j < L; ++j) t += w(j);
+        return t;
+    }
+    __device__ __forceinline__ uint32_t pick(double target) const
+    {
+        double acc = 0.0;
+        for (uint32_t j = 0; j < L; ++j) {
+            acc += w(j);
+            if (target < acc) return j;
+        }
+        return L - 1;
+    }
+};
+
+// One row: restates src/mmseq.cpp:871-889.  add(col, v) adds v to the count of transcript col.
+template <bool HAS_K, typename View, typename Add>
+__device__ __forceinline__ void allocate_row(const View &v, Add add, uint32_t kk, const SampleArgs &a, uint64_t row_id)
+{
+    const uint32_t L = v.L;
     if (L == 0 || kk == 0) return;
-    if (L == 1) { add(col_at(0), (int32_t)kk); return; }
-    double total = 0.0;
-    for (uint32_t j = 0; j < L; ++j) total += w_at(j);
+    if (L == 1) { add(v.col(0), (int32_t)kk); return; }
+    const double total = v.total();
     const bool degenerate = !(total > 0.0) || !(total < __builtin_huge_val());
     if (!HAS_K || kk <= K_SMALL) {
         Stream s(a.seed, a.chain, TAG_ROW, row_id, a.iter);
@@ -64,15 +169,9 @@ __device__ __forceinline__ void allocate_row(ColAt col_at, WAt w_at, Add add, ui
                 sel = (uint32_t)(u * (double)L);
                 if (sel >= L) sel = L - 1;
             } else {
-                const double target = u * total;
-                double acc = 0.0;
-                sel = L - 1;
-                for (uint32_t j = 0; j < L; ++j) {
-                    acc += w_at(j);
-                    if (target < acc) { sel = j; break; }
-                }
+                sel = v.pick(u * total);
             }
-            add(col_at(sel), 1);
+            add(v.col(sel), 1);
         }
         return;
     }
@@ -81,114 +180,184 @@ __device__ __forceinline__ void allocate_row(ColAt col_at, WAt w_at, Add add, ui
     uint32_t remaining = kk;
     double rem_w = total;
     for (uint32_t j = 0; j + 1 < L && remaining > 0; ++j) {
-        const double w = w_at(j);
+        const double w = v.w(j);
         double p = degenerate ? 1.0 / (double)(L - j) : (rem_w > 0.0 ? w / rem_w : 1.0);
         if (p > 1.0) p = 1.0;
         const uint32_t x = binomial(q, remaining, p);
-        if (x) add(col_at(j), (int32_t)x);
+        if (x) add(v.col(j), (int32_t)x);
         remaining -= x;
         rem_w -= w;
     }
-    if (remaining > 0) add(col_at(L - 1), (int32_t)remaining);
+    if (remaining > 0) add(v.col(L - 1), (int32_t)remaining);
 }
 
-__device__ __forceinline__ void global_count_add(int32_t *cnt, uint32_t col, int32_t v)
+// Per-tile descriptor builder: one 64-lane workgroup per tile.
+template <typename IdxT>
+__global__ __launch_bounds__(64) void k_tile_desc(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
+                                                  const uint64_t *__restrict__ tile_row, uint64_t n_tiles, TileDesc *out)
 {
-    __hip_atomic_fetch_add(&cnt[col], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    const uint64_t r0 = tile_row[tile], r1 = tile_row[tile + 1];
+    const uint64_t nz0 = row_ptr[r0], nz1 = row_ptr[r1];
+    uint32_t mx = 0, mn = 0xffffffffu;
+    for (uint64_t j = nz0 + threadIdx.x; j < nz1; j += 64) { const uint32_t c = col_idx[j]; mx = max(mx, c); mn = min(mn, c); }
+    for (int off = 32; off > 0; off >>= 1) {
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
+        mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
+    }
+    if (threadIdx.x == 0) {
+        TileDesc d;
+        d.nz0 = nz0; d.r0 = r0; d.nrows = (uint32_t)(r1 - r0);
+        d.nnz = (uint32_t)min((uint64_t)0xffffffffu, nz1 - nz0);
+        d.cmin = 0; d.clast = 0; d.cmax = mx; d.call = mn;
+        if (nz1 > nz0) {
+            d.cmin = col_idx[nz0];
+            uint64_t rl = r1 - 1;
+            while (rl > r0 && (uint64_t)row_ptr[rl] == nz1) --rl; // skip trailing empty rows
+            d.clast = col_idx[row_ptr[rl]];
+        }
+        out[tile] = d;
+    }
 }
 
-// K1.  A workgroup walks a contiguous chunk of tiles.  Rows arrive sorted by leading transcript
+// K1.  A workgroup walks ONE contiguous range of tiles.  Rows arrive sorted by leading transcript
 // (the order hit-set collapse produces), so consecutive tiles touch a slowly advancing band of
-// transcripts: that band's mu and counts live in an LDS window [base, base+K1_WIN); hits outside
+// transcripts: that band's mu and counts live in an LDS window [base, base+WIN); hits outside
 // the window fall back to the L2 gather / global atomic, so any row order is CORRECT, sorted
 // order is FAST (global int32 atomics cap at ~26 G/s on MI355X, LDS atomics at >100 G/s).
-template <typename IdxT, bool HAS_K>
+// The next tile's column ids and row offsets are prefetched into registers while the current
+// tile's rows are walked, so the only dependent global access per tile is the descriptor.
+template <typename IdxT, bool HAS_K, int ELEMS, int WIN, int UNR, int MODE>
 __global__ __launch_bounds__(K1_BLOCK) void k_sample(SampleArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t s_col[K1_LDS_ELEMS];
-    __shared__ __attribute__((aligned(16))) double s_mu[K1_WIN];
-    __shared__ int32_t s_cnt[K1_WIN];
+    constexpr int TILE_NNZ = ELEMS - 8;
+    constexpr int ROWS_CAP = ELEMS / 4;             // rows per tile (host enforces)
+    constexpr int NC = ELEMS / 4 / K1_BLOCK;        // 16-byte chunks per thread
+    constexpr int NR = ROWS_CAP / K1_BLOCK + 1;     // row offsets per thread (nrows+1 entries)
+    __shared__ __attribute__((aligned(16))) uint32_t s_col[ELEMS];
+    __shared__ __attribute__((aligned(16))) double s_mu[WIN];
+    __shared__ uint32_t s_rp[ROWS_CAP + K1_BLOCK];
+    __shared__ uint32_t s_k[HAS_K ? ROWS_CAP : 1];
+    __shared__ int32_t s_cnt[WIN];
     const IdxT *__restrict__ row_ptr = (const IdxT *)a.row_ptr;
     const int tid = threadIdx.x;
 
-    for (int i = tid; i < K1_WIN; i += K1_BLOCK) s_cnt[i] = 0;
-    uint32_t base = 0xffffffffu; // no window yet (every lookup misses)
+    const uint64_t t_begin = a.chunk_tile[blockIdx.x], t_end = a.chunk_tile[blockIdx.x + 1];
+    if (t_begin >= t_end) return;
+
+    for (int i = tid; i < WIN; i += K1_BLOCK) s_cnt[i] = 0;
+    uint32_t base = 0xffffffffu;
     bool win_valid = false;
 
     auto flush_window = [&]() {
         if (!win_valid) return;
-        for (int i = tid; i < K1_WIN; i += K1_BLOCK) {
+        for (int i = tid; i < WIN; i += K1_BLOCK) {
             const int32_t v = s_cnt[i];
             if (v) { global_count_add(a.cnt, base + (uint32_t)i, v); s_cnt[i] = 0; }
         }
     };
 
-    for (uint64_t chunk = blockIdx.x; chunk < a.n_chunks; chunk += gridDim.x) {
-        const uint64_t tile_end = a.chunk_tile[chunk + 1];
-        for (uint64_t tile = a.chunk_tile[chunk]; tile < tile_end; ++tile) {
-            const uint64_t r0 = a.tile_row[tile], r1 = a.tile_row[tile + 1];
-            const uint64_t nz0 = (uint64_t)row_ptr[r0], nz1 = (uint64_t)row_ptr[r1];
-            const uint64_t nt = nz1 - nz0;
-            if (nt > (uint64_t)K1_TILE_NNZ) {
-                // a single row longer than a tile: one lane walks it straight from global memory
-                if (tid == 0) {
-                    const uint32_t *cols = a.col_idx + nz0;
-                    const double *mu = a.mu;
-                    int32_t *cnt = a.cnt;
-                    allocate_row<HAS_K>([&](uint32_t j) { return cols[j]; }, [&](uint32_t j) { return mu[cols[j]]; },
-                                        [&](uint32_t c, int32_t v) { global_count_add(cnt, c, v); }, (uint32_t)nt,
-                                        HAS_K ? a.k[r0] : 1u, a, a.row_id_base + r0);
-                }
-                continue;
+    u32x4 pc[NC];
+    uint32_t prp[NR];
+    uint32_t pk[HAS_K ? NR : 1];
+    auto issue = [&](const TileDesc &d) {
+        if (d.nnz == 0 || d.nnz > (uint32_t)TILE_NNZ) return;
+        const uint64_t abase = d.nz0 & ~(uint64_t)3;
+        const uint32_t shift = (uint32_t)(d.nz0 - abase);
+        const uint32_t nchunks = (d.nnz + shift + 3) >> 2;
+        const u32x4 *__restrict__ src = (const u32x4 *)(a.col_idx + abase);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const uint32_t ch = (uint32_t)tid + (uint32_t)i * K1_BLOCK;
+            if (ch < nchunks) pc[i] = __builtin_nontemporal_load(src + ch);
+        }
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const uint32_t idx = (uint32_t)tid + (uint32_t)i * K1_BLOCK;
+            if (idx <= d.nrows) prp[i] = (uint32_t)((uint64_t)row_ptr[d.r0 + idx] - d.nz0) + shift;
+            if (HAS_K && idx < d.nrows) pk[i] = a.k[d.r0 + idx];
+        }
+    };
+    auto commit = [&](const TileDesc &d) {
+        const uint32_t shift = (uint32_t)(d.nz0 & 3);
+        const uint32_t nchunks = (d.nnz + shift + 3) >> 2;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const uint32_t ch = (uint32_t)tid + (uint32_t)i * K1_BLOCK;
+            if (ch < nchunks) *(u32x4 *)(s_col + 4 * ch) = pc[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const uint32_t idx = (uint32_t)tid + (uint32_t)i * K1_BLOCK;
+            if (idx <= d.nrows) s_rp[idx] = prp[i];
+            if (HAS_K && idx < d.nrows) s_k[idx] = pk[i];
+        }
+    };
+
+    TileDesc d = a.tiles[t_begin];
+    issue(d);
+    for (uint64_t tile = t_begin; tile < t_end; ++tile) {
+        TileDesc nd;
+        nd.nnz = 0; nd.nrows = 0; nd.nz0 = 0; nd.r0 = 0; nd.cmin = nd.clast = nd.cmax = nd.call = 0;
+        if (tile + 1 < t_end) nd = a.tiles[tile + 1];
+        if (d.nnz > (uint32_t)TILE_NNZ) {
+            // a single row longer than a tile: one lane walks it straight from global memory
+            if (tid == 0) {
+                const uint64_t r0 = d.r0, r1 = r0 + d.nrows;
+                const uint64_t nz0 = (uint64_t)row_ptr[r0], nz1 = (uint64_t)row_ptr[r1];
+                int32_t *cnt = a.cnt;
+                RowViewGlobal v{a.col_idx + nz0, a.mu, (uint32_t)(nz1 - nz0)};
+                allocate_row<HAS_K>(v, [&](uint32_t c, int32_t x) { global_count_add(cnt, c, x); }, HAS_K ? a.k[r0] : 1u, a,
+                                    a.row_id_base + r0);
             }
-            if (nt == 0) continue; // only empty rows
-            // ---- phase 1: stream the tile's column ids into LDS (16-byte aligned, non-temporal)
-            const uint64_t abase = nz0 & ~(uint64_t)3;
-            const uint32_t shift = (uint32_t)(nz0 - abase);
-            const uint32_t nchunks = (uint32_t)((nz1 - abase + 3) >> 2);
-            const u32x4 *__restrict__ src = (const u32x4 *)(a.col_idx + abase);
-            for (uint32_t ch = tid; ch < nchunks; ch += K1_BLOCK)
-                *(u32x4 *)(s_col + 4 * ch) = __builtin_nontemporal_load(src + ch);
-            __syncthreads();
-            // ---- window decision (uniform): first hit of the first / last non-empty row
-            const uint32_t cmin = s_col[shift];
-            uint64_t rl = r1 - 1;
-            while (rl > r0 && (uint64_t)row_ptr[rl] == nz1) --rl; // skip trailing empty rows
-            const uint32_t clast = s_col[(uint32_t)((uint64_t)row_ptr[rl] - nz0) + shift];
-            const bool keep = win_valid && cmin >= base && (uint64_t)clast + K1_WIN_MARGIN <= (uint64_t)base + K1_WIN;
-            if (!keep) {
-                flush_window();
-                base = cmin & ~15u;
-                win_valid = true;
-                for (int i = tid; i < K1_WIN; i += K1_BLOCK) {
-                    const uint32_t c = base + (uint32_t)i;
-                    s_mu[i] = c < a.n ? a.mu[c] : 0.0;
-                }
-                __syncthreads();
+            issue(nd);
+            d = nd;
+            continue;
+        }
+        if (d.nnz == 0) { issue(nd); d = nd; continue; } // only empty rows
+        commit(d);
+        // ---- window decision (uniform, from the descriptor)
+        const bool keep = win_valid && d.cmin >= base && (uint64_t)d.clast + K1_WIN_MARGIN <= (uint64_t)base + WIN;
+        if (!keep) {
+            flush_window();
+            base = d.cmin & ~15u;
+            win_valid = true;
+            for (int i = tid; i < WIN; i += K1_BLOCK) {
+                const uint32_t c = base + (uint32_t)i;
+                s_mu[i] = c < a.n ? a.mu[c] : 0.0;
             }
-            // ---- phase 2: one lane per row walks its LDS segment
+        }
+        issue(nd); // prefetch the next tile; the loads stay in flight across phase 2
+        __syncthreads();
+        // ---- phase 2: one lane per row walks its LDS segment
+        if (!(MODE & K1M_NO_PHASE2)) {
             const uint32_t wbase = base;
             const double *__restrict__ gmu = a.mu;
             int32_t *gcnt = a.cnt;
-            for (uint64_t r = r0 + tid; r < r1; r += K1_BLOCK) {
-                const uint32_t b = (uint32_t)((uint64_t)row_ptr[r] - nz0) + shift;
-                const uint32_t L = (uint32_t)((uint64_t)row_ptr[r + 1] - (uint64_t)row_ptr[r]);
-                const uint32_t *cl = s_col + b;
-                allocate_row<HAS_K>(
-                    [&](uint32_t j) { return cl[j]; },
-                    [&](uint32_t j) {
-                        const uint32_t c = cl[j], d = c - wbase;
-                        return d < (uint32_t)K1_WIN ? s_mu[d] : gmu[c];
-                    },
-                    [&](uint32_t c, int32_t v) {
-                        const uint32_t d = c - wbase;
-                        if (d < (uint32_t)K1_WIN) atomicAdd(&s_cnt[d], v);
-                        else global_count_add(gcnt, c, v);
-                    },
-                    L, HAS_K ? a.k[r] : 1u, a, a.row_id_base + r);
+            const bool inwin = d.call >= wbase && (uint64_t)d.cmax < (uint64_t)wbase + WIN;
+            if (inwin) {
+                auto add = [&](uint32_t c, int32_t x) { atomicAdd(&s_cnt[c - wbase], x); };
+                for (uint32_t r = tid; r < d.nrows; r += K1_BLOCK) {
+                    const uint32_t b = s_rp[r], L = s_rp[r + 1] - b;
+                    RowViewWin<WIN, UNR, true> v{s_col + b, L, wbase, s_mu, gmu};
+                    allocate_row<HAS_K>(v, add, HAS_K ? s_k[r] : 1u, a, a.row_id_base + d.r0 + r);
+                }
+            } else {
+                auto add = [&](uint32_t c, int32_t x) {
+                    const uint32_t dd = c - wbase;
+                    if (dd < (uint32_t)WIN) atomicAdd(&s_cnt[dd], x);
+                    else global_count_add(gcnt, c, x);
+                };
+                for (uint32_t r = tid; r < d.nrows; r += K1_BLOCK) {
+                    const uint32_t b = s_rp[r], L = s_rp[r + 1] - b;
+                    RowViewWin<WIN, 1, false> v{s_col + b, L, wbase, s_mu, gmu};
+                    allocate_row<HAS_K>(v, add, HAS_K ? s_k[r] : 1u, a, a.row_id_base + d.r0 + r);
+                }
             }
-            __syncthreads();
         }
+        __syncthreads();
+        d = nd;
     }
     flush_window();
 }

@@ -5,11 +5,47 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 using namespace mmg;
+
+// ------------------------------------------------------------------------------ K1 variants
+struct K1Variant { int elems, win, unr, mode; };
+#define K1_VARIANT_LIST(X) \
+    X(0, 4096, 2048, 4, 0)             \
+    X(1, 4096, 1024, 4, 0)             \
+    X(2, 8192, 2048, 4, 0)             \
+    X(3, 2048, 1024, 4, 0)             \
+    X(4, 4096, 2048, 8, 0)             \
+    X(5, 4096, 2048, 1, 0)             \
+    X(6, 4096, 2048, 4, K1M_NO_PHASE2) \
+    X(7, 8192, 2048, 8, 0)
+static const K1Variant k1_variants[] = {
+#define X(id, e, w, u, m) {e, w, u, m},
+    K1_VARIANT_LIST(X)
+#undef X
+};
+static const int k1_n_variants = (int)(sizeof(k1_variants) / sizeof(k1_variants[0]));
+static const int K1_DEFAULT_VARIANT = 0;
+
+template <typename IdxT, bool HAS_K>
+static const void *k1_kernel_for(int variant)
+{
+    switch (variant) {
+#define X(id, e, w, u, m) case id: return (const void *)&k_sample<IdxT, HAS_K, e, w, u, m>;
+        K1_VARIANT_LIST(X)
+#undef X
+    }
+    return nullptr;
+}
+static const void *k1_kernel(int variant, bool idx64, bool has_k)
+{
+    if (idx64) return has_k ? k1_kernel_for<uint64_t, true>(variant) : k1_kernel_for<uint64_t, false>(variant);
+    return has_k ? k1_kernel_for<uint32_t, true>(variant) : k1_kernel_for<uint32_t, false>(variant);
+}
 
 // ------------------------------------------------------------------------------ errors
 static thread_local std::string g_err;
@@ -62,11 +98,13 @@ struct mmg_problem {
     uint32_t *d_col = nullptr;
     uint32_t *d_k = nullptr;
     double *d_l = nullptr;
-    uint64_t *d_tile_row = nullptr;
+    TileDesc *d_tiles = nullptr;
     uint64_t *d_chunk_tile = nullptr;
     uint64_t n_chunks = 0;
     int grid_sample = 1;
+    int variant = K1_DEFAULT_VARIANT;
     std::vector<double> h_l;
+    std::vector<uint64_t> h_tile_row; // consumed by problem_build_desc
 };
 
 static void problem_free(mmg_problem *p)
@@ -77,13 +115,14 @@ static void problem_free(mmg_problem *p)
     if (p->d_col) (void)hipFree(p->d_col);
     if (p->d_k) (void)hipFree(p->d_k);
     if (p->d_l) (void)hipFree(p->d_l);
-    if (p->d_tile_row) (void)hipFree(p->d_tile_row);
+    if (p->d_tiles) (void)hipFree(p->d_tiles);
     if (p->d_chunk_tile) (void)hipFree(p->d_chunk_tile);
     delete p;
 }
 
-// Tiles of consecutive rows: <= K1_TILE_NNZ hits and <= K1_TILE_NNZ rows; a longer row is alone.
-static void build_tiles(const uint64_t *row_ptr, uint64_t m, std::vector<uint64_t> &tile_row, uint32_t &max_len)
+// Tiles of consecutive rows: <= tile_nnz hits and <= tile_rows rows; a longer row is alone.
+static void build_tiles(const uint64_t *row_ptr, uint64_t m, uint64_t tile_nnz, uint64_t tile_rows, std::vector<uint64_t> &tile_row,
+                        uint32_t &max_len)
 {
     tile_row.clear();
     tile_row.push_back(0);
@@ -92,7 +131,7 @@ static void build_tiles(const uint64_t *row_ptr, uint64_t m, std::vector<uint64_
     for (uint64_t r = 0; r < m; ++r) {
         const uint64_t L = row_ptr[r + 1] - row_ptr[r];
         if (L > max_len) max_len = (uint32_t)std::min<uint64_t>(L, 0xffffffffu);
-        if (cur_rows > 0 && (cur_nnz + L > (uint64_t)K1_TILE_NNZ || cur_rows >= (uint64_t)K1_TILE_NNZ)) {
+        if (cur_rows > 0 && (cur_nnz + L > tile_nnz || cur_rows >= tile_rows)) {
             tile_row.push_back(r);
             cur_nnz = 0;
             cur_rows = 0;
@@ -107,7 +146,13 @@ static void build_tiles(const uint64_t *row_ptr, uint64_t m, std::vector<uint64_
 static int problem_finish(mmg_problem *p, const uint64_t *h_row_ptr)
 {
     std::vector<uint64_t> tiles;
-    build_tiles(h_row_ptr, p->m, tiles, p->max_row_len);
+    if (const char *ev = getenv("MMG_K1_VARIANT")) {
+        const int v = atoi(ev);
+        if (v < 0 || v >= k1_n_variants) return fail(MMG_ERR_ARG, "MMG_K1_VARIANT out of range");
+        p->variant = v;
+    }
+    build_tiles(h_row_ptr, p->m, (uint64_t)k1_variants[p->variant].elems - 8, (uint64_t)k1_variants[p->variant].elems / 4, tiles,
+                p->max_row_len);
     p->n_tiles = tiles.empty() ? 0 : tiles.size() - 1;
     p->idx64 = p->nnz >= 0xffffffffull;
     if (p->idx64) {
@@ -121,30 +166,51 @@ static int problem_finish(mmg_problem *p, const uint64_t *h_row_ptr)
         HIP_TRY(hipMemcpy(p->d_row_ptr, rp32.data(), (p->m + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
         p->device_bytes += (p->m + 1) * 4;
     }
-    const size_t tb = std::max<size_t>(tiles.size(), 1) * sizeof(uint64_t);
-    HIP_TRY(hipMalloc((void **)&p->d_tile_row, tb));
-    if (!tiles.empty()) HIP_TRY(hipMemcpy(p->d_tile_row, tiles.data(), tiles.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-    p->device_bytes += tb;
+    p->h_tile_row.swap(tiles);
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, p->device));
     p->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     // Persistent grid: every resident workgroup (4 per CU at 40 KiB LDS) walks q contiguous
     // chunks of tiles, so its LDS window slides monotonically over the sorted rows.
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sample<uint32_t, false>, K1_BLOCK, 0) != hipSuccess || per_cu < 1) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k1_kernel(p->variant, p->idx64, false), K1_BLOCK, 0) != hipSuccess || per_cu < 1) {
         (void)hipGetLastError();
         per_cu = 4;
     }
-    const uint64_t resident = (uint64_t)p->cu_count * (uint64_t)std::min(per_cu, 4);
+    if (per_cu > 8) per_cu = 8;
+    if (const char *ev = getenv("MMG_K1_BLOCKS_PER_CU")) { const int v = atoi(ev); if (v >= 1 && v <= 8) per_cu = v; }
+    const uint64_t resident = (uint64_t)p->cu_count * (uint64_t)per_cu;
     const uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>(p->n_tiles, resident));
-    const uint64_t q = std::max<uint64_t>(1, std::min<uint64_t>(8, p->n_tiles / (grid * 32)));
-    p->n_chunks = p->n_tiles ? grid * q : 0;
+    p->n_chunks = p->n_tiles ? grid : 0; // one contiguous tile range per workgroup
     p->grid_sample = (int)grid;
     std::vector<uint64_t> chunk(p->n_chunks + 1, 0);
     for (uint64_t c = 0; c <= p->n_chunks; ++c)
         chunk[c] = p->n_chunks ? (uint64_t)(((unsigned __int128)p->n_tiles * c) / p->n_chunks) : 0;
     HIP_TRY(hipMalloc((void **)&p->d_chunk_tile, chunk.size() * sizeof(uint64_t)));
     HIP_TRY(hipMemcpy(p->d_chunk_tile, chunk.data(), chunk.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    return MMG_OK;
+}
+
+// per-tile descriptors, built on the device from the RESIDENT CSR (col_idx must be final)
+static int problem_build_desc(mmg_problem *p)
+{
+    std::vector<uint64_t> &tiles = p->h_tile_row;
+        uint64_t *d_tile_row = nullptr;
+        const size_t tb = std::max<size_t>(tiles.size(), 1) * sizeof(uint64_t);
+        HIP_TRY(hipMalloc((void **)&d_tile_row, tb));
+        hipError_t e = hipSuccess;
+        if (!tiles.empty()) e = hipMemcpy(d_tile_row, tiles.data(), tiles.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void **)&p->d_tiles, std::max<uint64_t>(p->n_tiles, 1) * sizeof(TileDesc));
+        if (e == hipSuccess && p->n_tiles) {
+            if (p->idx64) hipLaunchKernelGGL(k_tile_desc<uint64_t>, dim3((unsigned)p->n_tiles), dim3(64), 0, 0, (const uint64_t *)p->d_row_ptr, p->d_col, d_tile_row, p->n_tiles, p->d_tiles);
+            else hipLaunchKernelGGL(k_tile_desc<uint32_t>, dim3((unsigned)p->n_tiles), dim3(64), 0, 0, (const uint32_t *)p->d_row_ptr, p->d_col, d_tile_row, p->n_tiles, p->d_tiles);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+        }
+        (void)hipFree(d_tile_row);
+        if (e != hipSuccess) return fail(MMG_ERR_HIP, std::string("tile descriptors: ") + hipGetErrorString(e));
+        p->device_bytes += p->n_tiles * sizeof(TileDesc);
+        std::vector<uint64_t>().swap(tiles);
     return MMG_OK;
 }
 
@@ -169,7 +235,7 @@ extern "C" int mmg_problem_create(const mmg_problem_desc *d, int device, mmg_pro
     p->h_l.assign(d->l, d->l + d->n);
     if (d->k) { for (uint64_t r = 0; r < d->m; ++r) p->total_k += d->k[r]; } else p->total_k = d->m;
     auto bail = [&](int code) { problem_free(p); return code; };
-    const size_t col_bytes = (nnz + 8) * sizeof(uint32_t); // padded: the 16-byte stream may over-read
+    const size_t col_bytes = (nnz + 16) * sizeof(uint32_t); // padded: the 16-byte stream may over-read
     if (hipMalloc((void **)&p->d_col, col_bytes) != hipSuccess) return bail(fail(MMG_ERR_HIP, "hipMalloc col_idx"));
     if (hipMemset(p->d_col, 0, col_bytes) != hipSuccess) return bail(fail(MMG_ERR_HIP, "hipMemset col_idx"));
     if (nnz && hipMemcpy(p->d_col, d->col_idx, nnz * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
@@ -186,6 +252,8 @@ extern "C" int mmg_problem_create(const mmg_problem_desc *d, int device, mmg_pro
         return bail(fail(MMG_ERR_HIP, "hipMemcpy l"));
     p->device_bytes += d->n * 8;
     rc = problem_finish(p, d->row_ptr);
+    if (rc) return bail(rc);
+    rc = problem_build_desc(p);
     if (rc) return bail(rc);
     *out = p;
     return MMG_OK;
@@ -285,6 +353,8 @@ extern "C" int mmg_problem_create_synthetic(const mmg_synth_desc *d, int device,
     SYN_TRY(hipGetLastError());
     SYN_TRY(hipDeviceSynchronize());
 #undef SYN_TRY
+    rc = problem_build_desc(p);
+    if (rc) return bail(rc);
     cleanup();
     *out = p;
     return MMG_OK;
@@ -503,21 +573,15 @@ extern "C" int mmg_sampler_sample(mmg_sampler *s)
     if (p->n_tiles > 0) {
         for (int c = 0; c < s->cfg.n_chains; ++c) {
             SampleArgs a;
-            a.row_ptr = p->d_row_ptr; a.col_idx = p->d_col; a.k = p->d_k; a.tile_row = p->d_tile_row;
-            a.chunk_tile = p->d_chunk_tile; a.n_chunks = p->n_chunks; a.n = p->n;
+            a.row_ptr = p->d_row_ptr; a.col_idx = p->d_col; a.k = p->d_k; a.tiles = p->d_tiles;
+            a.chunk_tile = p->d_chunk_tile; a.n = p->n;
             a.mu = s->d_mu + (size_t)c * p->n;
             a.cnt = s->d_cnt + (size_t)c * p->n;
             a.seed = s->cfg.seed; a.row_id_base = p->row_id_base;
             a.chain = (uint32_t)(s->cfg.chain_base + c);
             a.iter = (uint32_t)s->iter;
-            const dim3 g(p->grid_sample), b(K1_BLOCK);
-            if (p->idx64) {
-                if (p->d_k) hipLaunchKernelGGL((k_sample<uint64_t, true>), g, b, 0, s->cur, a);
-                else hipLaunchKernelGGL((k_sample<uint64_t, false>), g, b, 0, s->cur, a);
-            } else {
-                if (p->d_k) hipLaunchKernelGGL((k_sample<uint32_t, true>), g, b, 0, s->cur, a);
-                else hipLaunchKernelGGL((k_sample<uint32_t, false>), g, b, 0, s->cur, a);
-            }
+            void *kargs[] = {(void *)&a};
+            HIP_TRY(hipLaunchKernel(k1_kernel(p->variant, p->idx64, p->d_k != nullptr), dim3(p->grid_sample), dim3(K1_BLOCK), kargs, 0, s->cur));
         }
         HIP_TRY(hipGetLastError());
     }
