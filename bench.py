@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py -- Gibbs iterations/sec of the mmseq hot path on MI355X (contract: see the task prompt).
+
+A "step" is one Gibbs sweep: K1 (per-row multinomial allocation + count scatter, the CSR stream)
++ K2 (Gamma redraw + trace capture) over the whole synthetic hit matrix, for every chain on the GPU.
+Default workload = BASELINE.json's 50M-read / 200k-transcript shape (configs[2]/[3]): 1 chain per GPU.
+
+  python bench.py --gpus 1 --steps 64 --warmup 8
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W            (one rank per GPU, RCCL)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def cpu_baseline(args, total_reads):
+    """Oracle ("port" of src/mmseq.cpp:851-918, reference-structured: per-thread MT19937, count slabs,
+    conditional-binomial multinomial) timed on this host's cores on a bounded sample of the same workload."""
+    import numpy as np
+    from oracle import binding as B
+    Rs = min(args.cpu_sample_rows, args.rows)
+    p, _ = B.synth_problem(R=Rs, T=args.transcripts, avg_hits=args.avg_hits, seed=args.seed, mapped_reads=total_reads)
+    mu0, _ = B.start_values(p)
+    threads = os.cpu_count() or 1
+    iters = args.cpu_iters
+    B.gibbs_ref(p, mu0, seed=args.seed, n_iter=1, trace_len=1, threads=threads, want_trace=False)  # warm
+    r = B.gibbs_ref(p, mu0, seed=args.seed, n_iter=iters, trace_len=iters, threads=threads, want_trace=False)
+    reads_it_s = Rs * iters / r["seconds"]
+    r1 = B.gibbs_ref(p, mu0, seed=args.seed, n_iter=max(1, iters // 4), trace_len=max(1, iters // 4), threads=1,
+                     want_trace=False)
+    reads_it_s_1 = Rs * max(1, iters // 4) / r1["seconds"]
+    return {"value": reads_it_s / args.rows, "unit": "iterations/s", "cores": threads, "kind": "port",
+            "sample": "first %d generator rows of the same workload (T=%d, avg %.0f hits), %d iterations, all %d host "
+                      "threads; reads*iter/s scaled to the %d-read problem" % (Rs, args.transcripts, args.avg_hits,
+                                                                              iters, threads, args.rows),
+            "reads_iters_per_sec": reads_it_s, "single_thread_iterations_per_sec": reads_it_s_1 / args.rows}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--rows", type=int, default=50_000_000, help="reads per GPU")
+    ap.add_argument("--transcripts", type=int, default=200_000)
+    ap.add_argument("--avg-hits", type=float, default=20.0)
+    ap.add_argument("--chains", type=int, default=1, help="chains per GPU")
+    ap.add_argument("--mode", choices=["chains", "shard"], default="chains")
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
+    ap.add_argument("--cpu-iters", type=int, default=24)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from mmseq_amd import Problem, Sampler
+    from mmseq_amd import dist as mdist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # ---- workload (synthetic, generated straight into device CSR; not timed)
+    if args.mode == "shard":
+        total_reads = args.rows * world
+        row0 = args.rows * rank
+    else:
+        total_reads = args.rows
+        row0 = 0
+    prob = Problem.synthetic(args.rows, args.transcripts, args.avg_hits, seed=args.seed, row0=row0,
+                             mapped_reads=total_reads, device=local_rank)
+    inf = prob.info
+    mu0, _ = prob.start_values()
+    if args.mode == "shard" and world > 1:
+        t = torch.from_numpy(mu0 * prob.l()).cuda()       # shares k/|row| summed over ranks, then / l
+        dist.all_reduce(t)
+        mu0 = t.cpu().numpy() / prob.l()
+    trace_len = 1024
+    gibbs_iter = 1024                                      # every iteration is a kept sample (BASELINE.md B formula)
+    chain_base = 0 if args.mode == "shard" else rank * args.chains
+    smp = Sampler(prob, mu0, seed=args.seed, n_chains=args.chains, chain_base=chain_base, gibbs_iter=gibbs_iter,
+                  trace_len=trace_len, keep_trace=True, timing=True)
+    mdist.use_current_stream(smp)
+    counts = mdist.counts_tensor(smp) if args.mode == "shard" else None
+    moments = mdist.moments_tensor(smp)
+
+    def step():
+        if args.mode == "shard":
+            mdist.shard_step(smp, counts)
+        else:
+            smp.run(1)
+
+    if args.warmup + args.steps > gibbs_iter:
+        raise SystemExit("warmup + steps must be <= %d" % gibbs_iter)
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    smp.reset_timing()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if args.mode == "chains":
+        mdist.pool_moments(moments)                        # the one collective of chains mode
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    tm = smp.timing()
+
+    # sanity inside the bench: every read was allocated exactly once in the last sweep
+    if args.mode == "chains":
+        assert int(smp.counts(0).astype(np.int64).sum()) == inf.total_k
+
+    if rank == 0:
+        C = args.chains
+        chains_total = C * (world if args.mode == "chains" else 1)
+        iters_per_s = chains_total * args.steps / elapsed
+        reads_per_chain = total_reads
+        k1_ms = tm["sample_ms"] / max(tm["sample_launches"], 1)
+        k2_ms = tm["update_ms"] / max(tm["update_launches"], 1)
+        # algorithmic bytes of one K1 launch (one GPU): u32 row_ptr + u32 col_idx streamed once,
+        # per chain fp64 mu read + int32 count write
+        b_k1 = 4 * (inf.m + 1) + 4 * inf.nnz + 12 * C * inf.n
+        b_sweep = 4 * (inf.m + 1) + 4 * inf.nnz + 28 * C * inf.n
+        ach = b_k1 / (k1_ms * 1e-3) / 1e9
+        out = {
+            "metric": "gibbs_iterations_per_sec", "value": iters_per_s, "unit": "iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "50M-read x 200k-transcript synthetic CSR hits (BASELINE.json configs[2]/[3] shape)"
+                       if (args.rows, args.transcripts) == (50_000_000, 200_000) else "custom synthetic CSR hits",
+                       "reads_per_gpu": inf.m, "transcripts": inf.n, "hits_per_gpu": inf.nnz,
+                       "avg_hits_per_read": args.avg_hits, "chains_per_gpu": C, "mode": args.mode,
+                       "parallelism": ("%d independent chains (1 all-reduce of posterior moments)" % chains_total)
+                       if args.mode == "chains" else ("read-sharded single chain over %d GPUs "
+                                                      "(int32 count all-reduce per iteration)" % world),
+                       "trace": "every iteration kept (fp64 mu trace resident in HBM)", "generator_seed": args.seed},
+            "reads_iters_per_sec": iters_per_s * reads_per_chain,
+            "roofline": {"bound": "hbm", "kernel": "k_sample (K1)", "achieved": ach, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": b_k1, "avg_launch_ms": k1_ms,
+                         "k_update_avg_launch_ms": k2_ms, "sweep_bytes": b_sweep,
+                         "sweep_frac_of_peak": b_sweep / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, total_reads)
+            out["speedup_vs_cpu_baseline"] = iters_per_s / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    smp.close()
+    prob.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

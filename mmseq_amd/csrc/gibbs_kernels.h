@@ -38,13 +38,6 @@ struct TileDesc {
 };
 
 struct SampleArgs {
-    const void *row_ptr;        // IdxT[m+1]
-    const uint32_t *col_idx;    // nnz (+ 64 B padding)
-    const uint32_t *k;          // m or nullptr
-    const TileDesc *tiles;      // n_tiles
-    const uint64_t *chunk_tile; // grid+1 : one contiguous tile range per workgroup
-    const double *mu;           // n
-    int32_t *cnt;               // n
     uint64_t seed;
     uint64_t row_id_base;
     uint32_t n;
@@ -122,6 +115,62 @@ struct RowViewWin {
             if (found != 0xffffffffu) return found;
         }
         return last;
+    }
+};
+
+// fast path: the tile lies inside the LDS window and s_col holds BYTE OFFSETS into s_mu
+// ((col - wbase) * 8, written by commit), so a hit costs ds_read_b32 + ds_read_b64 + v_add_f64.
+// Full groups of UNR hits run unmasked; the <UNR tail runs one hit at a time.
+template <int UNR>
+struct RowViewOff {
+    const uint32_t *cl; // row's byte offsets in LDS
+    uint32_t L;
+    const double *s_mu;
+    __device__ __forceinline__ double wo(uint32_t off) const { return *(const double *)((const char *)s_mu + off); }
+    __device__ __forceinline__ uint32_t col(uint32_t j) const { return cl[j]; } // a byte offset: add() understands it
+    __device__ __forceinline__ double w(uint32_t j) const { return wo(cl[j]); }
+    __device__ __forceinline__ double total() const
+    {
+        double t = 0.0;
+        uint32_t j = 0;
+        for (; j + UNR <= L; j += UNR) {
+            uint32_t o[UNR];
+            double wv[UNR];
+#pragma unroll
+            for (int i = 0; i < UNR; ++i) o[i] = cl[j + i];
+#pragma unroll
+            for (int i = 0; i < UNR; ++i) wv[i] = wo(o[i]);
+#pragma unroll
+            for (int i = 0; i < UNR; ++i) t += wv[i];
+        }
+        for (; j < L; ++j) t += wo(cl[j]);
+        return t;
+    }
+    __device__ __forceinline__ uint32_t pick(double target) const
+    {
+        double acc = 0.0;
+        uint32_t j = 0;
+        for (; j + UNR <= L; j += UNR) {
+            uint32_t o[UNR];
+            double wv[UNR], pa[UNR];
+#pragma unroll
+            for (int i = 0; i < UNR; ++i) o[i] = cl[j + i];
+#pragma unroll
+            for (int i = 0; i < UNR; ++i) wv[i] = wo(o[i]);
+#pragma unroll
+            for (int i = 0; i < UNR; ++i) { acc += wv[i]; pa[i] = acc; }
+            if (target < acc) { // prefix sums never decrease: the first i with target < pa[i] is in this group
+                uint32_t sel = UNR - 1;
+#pragma unroll
+                for (int i = UNR - 2; i >= 0; --i) sel = (target < pa[i]) ? (uint32_t)i : sel;
+                return j + sel;
+            }
+        }
+        for (; j < L; ++j) {
+            acc += wo(cl[j]);
+            if (target < acc) return j;
+        }
+        return L - 1;
     }
 };
 
@@ -229,7 +278,10 @@ __global__ __launch_bounds__(64) void k_tile_desc(const IdxT *__restrict__ row_p
 // The next tile's column ids and row offsets are prefetched into registers while the current
 // tile's rows are walked, so the only dependent global access per tile is the descriptor.
 template <typename IdxT, bool HAS_K, int ELEMS, int WIN, int UNR, int MODE>
-__global__ __launch_bounds__(K1_BLOCK) void k_sample(SampleArgs a)
+__global__ __launch_bounds__(K1_BLOCK) void k_sample(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
+                                                     const uint32_t *__restrict__ kmult, const TileDesc *__restrict__ tiles,
+                                                     const uint64_t *__restrict__ chunk_tile, const double *__restrict__ gmu,
+                                                     int32_t *gcnt, SampleArgs a)
 {
     constexpr int TILE_NNZ = ELEMS - 8;
     constexpr int ROWS_CAP = ELEMS / 4;             // rows per tile (host enforces)
@@ -238,12 +290,11 @@ __global__ __launch_bounds__(K1_BLOCK) void k_sample(SampleArgs a)
     __shared__ __attribute__((aligned(16))) uint32_t s_col[ELEMS];
     __shared__ __attribute__((aligned(16))) double s_mu[WIN];
     __shared__ uint32_t s_rp[ROWS_CAP + K1_BLOCK];
-    __shared__ uint32_t s_k[HAS_K ? ROWS_CAP : 1];
+    __shared__ uint32_t s_k[HAS_K ? ROWS_CAP + K1_BLOCK : 1];
     __shared__ int32_t s_cnt[WIN];
-    const IdxT *__restrict__ row_ptr = (const IdxT *)a.row_ptr;
     const int tid = threadIdx.x;
 
-    const uint64_t t_begin = a.chunk_tile[blockIdx.x], t_end = a.chunk_tile[blockIdx.x + 1];
+    const uint64_t t_begin = chunk_tile[blockIdx.x], t_end = chunk_tile[blockIdx.x + 1];
     if (t_begin >= t_end) return;
 
     for (int i = tid; i < WIN; i += K1_BLOCK) s_cnt[i] = 0;
@@ -254,61 +305,65 @@ __global__ __launch_bounds__(K1_BLOCK) void k_sample(SampleArgs a)
         if (!win_valid) return;
         for (int i = tid; i < WIN; i += K1_BLOCK) {
             const int32_t v = s_cnt[i];
-            if (v) { global_count_add(a.cnt, base + (uint32_t)i, v); s_cnt[i] = 0; }
+            if (v) { global_count_add(gcnt, base + (uint32_t)i, v); s_cnt[i] = 0; }
         }
     };
 
+    // Prefetch registers: raw loaded values only (any arithmetic on them would force the
+    // compiler to wait for the loads right here); all loads are unconditional with clamped
+    // indices so that no branch separates them (keeps the vmcnt bookkeeping exact).
     u32x4 pc[NC];
-    uint32_t prp[NR];
+    IdxT prp[NR];
     uint32_t pk[HAS_K ? NR : 1];
     auto issue = [&](const TileDesc &d) {
-        if (d.nnz == 0 || d.nnz > (uint32_t)TILE_NNZ) return;
+        if (d.nnz == 0 || d.nnz > (uint32_t)TILE_NNZ) return; // uniform
         const uint64_t abase = d.nz0 & ~(uint64_t)3;
         const uint32_t shift = (uint32_t)(d.nz0 - abase);
         const uint32_t nchunks = (d.nnz + shift + 3) >> 2;
-        const u32x4 *__restrict__ src = (const u32x4 *)(a.col_idx + abase);
+        const u32x4 *__restrict__ src = (const u32x4 *)(col_idx + abase);
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
-            const uint32_t ch = (uint32_t)tid + (uint32_t)i * K1_BLOCK;
-            if (ch < nchunks) pc[i] = __builtin_nontemporal_load(src + ch);
+            const uint32_t ch = min((uint32_t)tid + (uint32_t)i * K1_BLOCK, nchunks - 1);
+            pc[i] = __builtin_nontemporal_load(src + ch);
         }
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            const uint32_t idx = (uint32_t)tid + (uint32_t)i * K1_BLOCK;
-            if (idx <= d.nrows) prp[i] = (uint32_t)((uint64_t)row_ptr[d.r0 + idx] - d.nz0) + shift;
-            if (HAS_K && idx < d.nrows) pk[i] = a.k[d.r0 + idx];
+            const uint32_t idx = min((uint32_t)tid + (uint32_t)i * K1_BLOCK, d.nrows);
+            prp[i] = row_ptr[d.r0 + idx];
+            if (HAS_K) pk[i] = kmult[d.r0 + min(idx, d.nrows - 1)];
         }
     };
-    auto commit = [&](const TileDesc &d) {
+    auto commit = [&](const TileDesc &d, bool inwin, uint32_t wbase) {
         const uint32_t shift = (uint32_t)(d.nz0 & 3);
         const uint32_t nchunks = (d.nnz + shift + 3) >> 2;
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             const uint32_t ch = (uint32_t)tid + (uint32_t)i * K1_BLOCK;
-            if (ch < nchunks) *(u32x4 *)(s_col + 4 * ch) = pc[i];
+            // in-window tiles store byte offsets into s_mu instead of column ids (edge junk is never read)
+            const u32x4 v = inwin ? (pc[i] - wbase) * 8u : pc[i];
+            if (ch < nchunks) *(u32x4 *)(s_col + 4 * ch) = v;
         }
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             const uint32_t idx = (uint32_t)tid + (uint32_t)i * K1_BLOCK;
-            if (idx <= d.nrows) s_rp[idx] = prp[i];
+            if (idx <= d.nrows) s_rp[idx] = (uint32_t)((uint64_t)prp[i] - d.nz0) + shift;
             if (HAS_K && idx < d.nrows) s_k[idx] = pk[i];
         }
     };
 
-    TileDesc d = a.tiles[t_begin];
+    TileDesc d = tiles[t_begin];
     issue(d);
     for (uint64_t tile = t_begin; tile < t_end; ++tile) {
         TileDesc nd;
         nd.nnz = 0; nd.nrows = 0; nd.nz0 = 0; nd.r0 = 0; nd.cmin = nd.clast = nd.cmax = nd.call = 0;
-        if (tile + 1 < t_end) nd = a.tiles[tile + 1];
+        if (tile + 1 < t_end) nd = tiles[tile + 1];
         if (d.nnz > (uint32_t)TILE_NNZ) {
             // a single row longer than a tile: one lane walks it straight from global memory
             if (tid == 0) {
                 const uint64_t r0 = d.r0, r1 = r0 + d.nrows;
                 const uint64_t nz0 = (uint64_t)row_ptr[r0], nz1 = (uint64_t)row_ptr[r1];
-                int32_t *cnt = a.cnt;
-                RowViewGlobal v{a.col_idx + nz0, a.mu, (uint32_t)(nz1 - nz0)};
-                allocate_row<HAS_K>(v, [&](uint32_t c, int32_t x) { global_count_add(cnt, c, x); }, HAS_K ? a.k[r0] : 1u, a,
+                RowViewGlobal v{col_idx + nz0, gmu, (uint32_t)(nz1 - nz0)};
+                allocate_row<HAS_K>(v, [&](uint32_t c, int32_t x) { global_count_add(gcnt, c, x); }, HAS_K ? kmult[r0] : 1u, a,
                                     a.row_id_base + r0);
             }
             issue(nd);
@@ -316,7 +371,6 @@ __global__ __launch_bounds__(K1_BLOCK) void k_sample(SampleArgs a)
             continue;
         }
         if (d.nnz == 0) { issue(nd); d = nd; continue; } // only empty rows
-        commit(d);
         // ---- window decision (uniform, from the descriptor)
         const bool keep = win_valid && d.cmin >= base && (uint64_t)d.clast + K1_WIN_MARGIN <= (uint64_t)base + WIN;
         if (!keep) {
@@ -325,22 +379,21 @@ __global__ __launch_bounds__(K1_BLOCK) void k_sample(SampleArgs a)
             win_valid = true;
             for (int i = tid; i < WIN; i += K1_BLOCK) {
                 const uint32_t c = base + (uint32_t)i;
-                s_mu[i] = c < a.n ? a.mu[c] : 0.0;
+                s_mu[i] = c < a.n ? gmu[c] : 0.0;
             }
         }
+        const uint32_t wbase = base;
+        const bool inwin = d.call >= wbase && (uint64_t)d.cmax < (uint64_t)wbase + WIN;
+        commit(d, inwin, wbase);
         issue(nd); // prefetch the next tile; the loads stay in flight across phase 2
         __syncthreads();
         // ---- phase 2: one lane per row walks its LDS segment
         if (!(MODE & K1M_NO_PHASE2)) {
-            const uint32_t wbase = base;
-            const double *__restrict__ gmu = a.mu;
-            int32_t *gcnt = a.cnt;
-            const bool inwin = d.call >= wbase && (uint64_t)d.cmax < (uint64_t)wbase + WIN;
             if (inwin) {
-                auto add = [&](uint32_t c, int32_t x) { atomicAdd(&s_cnt[c - wbase], x); };
+                auto add = [&](uint32_t off, int32_t x) { atomicAdd((int32_t *)((char *)s_cnt + (off >> 1)), x); };
                 for (uint32_t r = tid; r < d.nrows; r += K1_BLOCK) {
                     const uint32_t b = s_rp[r], L = s_rp[r + 1] - b;
-                    RowViewWin<WIN, UNR, true> v{s_col + b, L, wbase, s_mu, gmu};
+                    RowViewOff<UNR> v{s_col + b, L, s_mu};
                     allocate_row<HAS_K>(v, add, HAS_K ? s_k[r] : 1u, a, a.row_id_base + d.r0 + r);
                 }
             } else {

@@ -29,7 +29,7 @@ static const K1Variant k1_variants[] = {
 #undef X
 };
 static const int k1_n_variants = (int)(sizeof(k1_variants) / sizeof(k1_variants[0]));
-static const int K1_DEFAULT_VARIANT = 0;
+static const int K1_DEFAULT_VARIANT = 1;
 
 template <typename IdxT, bool HAS_K>
 static const void *k1_kernel_for(int variant)
@@ -324,13 +324,24 @@ extern "C" int mmg_problem_create_synthetic(const mmg_synth_desc *d, int device,
     std::vector<uint64_t> rp(d->rows + 1);
     rp[0] = 0;
     if (d->sorted) {
-        // stable counting sort of the rows by leading transcript (keys < n): deterministic order
-        std::vector<uint32_t> keys(d->rows), perm(d->rows);
+        // stable two-pass (LSD) counting sort by (leading transcript, row length): deterministic.
+        // Equal-length neighbours keep a wave's 64 rows in step; the leading transcript keeps the
+        // LDS window of the sample kernel sliding monotonically.
+        std::vector<uint32_t> keys(d->rows), perm(d->rows), tmp(d->rows);
         SYN_TRY(hipMemcpy(keys.data(), d_keys, d->rows * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        std::vector<uint64_t> pos((size_t)d->n + 1, 0);
-        for (uint64_t r = 0; r < d->rows; ++r) pos[(size_t)keys[r] + 1]++;
-        for (uint32_t t = 0; t < d->n; ++t) pos[t + 1] += pos[t];
-        for (uint64_t r = 0; r < d->rows; ++r) perm[pos[keys[r]]++] = (uint32_t)r;
+        {
+            std::vector<uint64_t> pos(102, 0);
+            for (uint64_t r = 0; r < d->rows; ++r) pos[(size_t)lens[r] + 1]++;
+            for (int i = 0; i < 101; ++i) pos[i + 1] += pos[i];
+            for (uint64_t r = 0; r < d->rows; ++r) tmp[pos[lens[r]]++] = (uint32_t)r;
+        }
+        {
+            std::vector<uint64_t> pos((size_t)d->n + 1, 0);
+            for (uint64_t r = 0; r < d->rows; ++r) pos[(size_t)keys[r] + 1]++;
+            for (uint32_t t = 0; t < d->n; ++t) pos[t + 1] += pos[t];
+            for (uint64_t i = 0; i < d->rows; ++i) { const uint32_t r = tmp[i]; perm[pos[keys[r]]++] = r; }
+        }
+        std::vector<uint32_t>().swap(tmp);
         for (uint64_t r = 0; r < d->rows; ++r) rp[r + 1] = rp[r] + lens[perm[r]];
         SYN_TRY(hipMalloc((void **)&d_perm, d->rows * sizeof(uint32_t)));
         SYN_TRY(hipMemcpy(d_perm, perm.data(), d->rows * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -573,14 +584,16 @@ extern "C" int mmg_sampler_sample(mmg_sampler *s)
     if (p->n_tiles > 0) {
         for (int c = 0; c < s->cfg.n_chains; ++c) {
             SampleArgs a;
-            a.row_ptr = p->d_row_ptr; a.col_idx = p->d_col; a.k = p->d_k; a.tiles = p->d_tiles;
-            a.chunk_tile = p->d_chunk_tile; a.n = p->n;
-            a.mu = s->d_mu + (size_t)c * p->n;
-            a.cnt = s->d_cnt + (size_t)c * p->n;
-            a.seed = s->cfg.seed; a.row_id_base = p->row_id_base;
+            a.seed = s->cfg.seed; a.row_id_base = p->row_id_base; a.n = p->n;
             a.chain = (uint32_t)(s->cfg.chain_base + c);
             a.iter = (uint32_t)s->iter;
-            void *kargs[] = {(void *)&a};
+            const void *rp = p->d_row_ptr;
+            const uint32_t *ci = p->d_col, *kk = p->d_k;
+            const TileDesc *td = p->d_tiles;
+            const uint64_t *ct = p->d_chunk_tile;
+            const double *mu = s->d_mu + (size_t)c * p->n;
+            int32_t *cnt = s->d_cnt + (size_t)c * p->n;
+            void *kargs[] = {(void *)&rp, (void *)&ci, (void *)&kk, (void *)&td, (void *)&ct, (void *)&mu, (void *)&cnt, (void *)&a};
             HIP_TRY(hipLaunchKernel(k1_kernel(p->variant, p->idx64, p->d_k != nullptr), dim3(p->grid_sample), dim3(K1_BLOCK), kargs, 0, s->cur));
         }
         HIP_TRY(hipGetLastError());

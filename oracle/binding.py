@@ -240,10 +240,10 @@ def synth_problem(R, T, avg_hits, seed=1234, uniform=False, row0=0, mapped_reads
     col = np.empty(int(row_ptr[-1]), np.uint32)
     L.orc_synth_csr(seed, row0, R, T, cdf, len_cdf, int(uniform), row_ptr, col.ctypes.data_as(C.c_void_p))
     if sort and R > 0:
-        # rows stably ordered by leading (smallest) transcript -- the layout the sample kernel wants
+        # rows stably ordered by (leading transcript, row length) -- the layout the sample kernel wants
         lens = np.diff(row_ptr.astype(np.int64))
         first = col[row_ptr[:-1].astype(np.int64)]
-        perm = np.argsort(first, kind="stable")
+        perm = np.lexsort((lens, first))
         new_rp = np.zeros(R + 1, np.uint64)
         new_rp[1:] = np.cumsum(lens[perm])
         starts = row_ptr[:-1].astype(np.int64)[perm]

@@ -41,9 +41,15 @@ def probe(R, T, avg, iters=20, chains=1, uniform=False, sort=True, tag="", check
     s.close(); prob.close()
 
 if __name__ == "__main__":
-    variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0,1,2,3,4,5,6,7".split(","))]
-    for v in variants:
+    specs = (sys.argv[1] if len(sys.argv) > 1 else "0,1,2,3,4,5,6,7").split(",")
+    for spec in specs:
+        v, _, bpc = spec.partition(":")
+        v = int(v)
         os.environ["MMG_K1_VARIANT"] = str(v)
+        if bpc:
+            os.environ["MMG_K1_BLOCKS_PER_CU"] = bpc
+        else:
+            os.environ.pop("MMG_K1_BLOCKS_PER_CU", None)
         ok = parity(v) if v != 6 else None
-        probe(5_000_000, 50_000, 8, tag=f"[v{v} parity={ok}]", check=(v != 6))
-        probe(50_000_000, 200_000, 20, iters=10, tag=f"[v{v} parity={ok}]", check=(v != 6))
+        probe(5_000_000, 50_000, 8, tag=f"[v{spec} parity={ok}]", check=(v != 6))
+        probe(50_000_000, 200_000, 20, iters=10, tag=f"[v{spec} parity={ok}]", check=(v != 6))
