@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same
 seeded inputs.  Integer outputs and -- because both sides implement the same keyed-stream spec
 with once-rounded fp64 arithmetic -- fp64 traces are required to be BIT-IDENTICAL."""
+import os
+
 import numpy as np
 import pytest
 
@@ -200,3 +202,54 @@ def test_errors_are_loud(gpu):
         s.trace(0)
     with pytest.raises(Exception):
         s.update()
+
+
+def test_golden_tiny_chain_on_device(gpu):
+    """The committed golden fixture (tests/golden/keyed_chain_tiny.json): k up to 1000, all three row paths."""
+    import json, os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "keyed_chain_tiny.json")))
+    f = lambda hs: np.array([float.fromhex(h) for h in hs])
+    prob = gpu.Problem.from_csr(np.array(g["row_ptr"], np.uint64), np.array(g["col_idx"], np.uint32), f(g["l"]),
+                                k=np.array(g["k"], np.uint32))
+    mu0, uh = prob.start_values()
+    assert uh.tolist() == g["unique_hits"]
+    np.testing.assert_allclose(mu0, f(g["mu0"]), rtol=1e-14)
+    s = gpu.Sampler(prob, f(g["mu0"]), seed=1234, gibbs_iter=32, trace_len=16)
+    s.run(32)
+    assert np.array_equal(s.trace(0).ravel(), f(g["trace"]))
+    assert s.counts(0).tolist() == g["cnt_last"]
+    assert np.array_equal(s.mu(0), f(g["mu_last"]))
+
+
+def test_torch_view_of_device_buffers_and_single_rank_collectives(gpu, orc):
+    """dist glue on one GPU: zero-copy torch views of the library's buffers, kernels on torch's stream,
+    a 1-rank RCCL process group around the shard-mode step."""
+    import torch
+    import torch.distributed as dist
+    from mmseq_amd import dist as mdist
+    p, aux = orc.synth_problem(R=20000, T=900, avg_hits=6, seed=5)
+    mu0, _ = orc.start_values(p)
+    prob = gpu.Problem.from_csr(p.row_ptr, p.col_idx, p.l)
+    s = gpu.Sampler(prob, mu0, seed=3, gibbs_iter=8, trace_len=8)
+    mdist.use_current_stream(s)
+    counts = mdist.counts_tensor(s)
+    assert counts.dtype == torch.int32 and counts.numel() == 900 and counts.is_cuda
+    own = not dist.is_initialized()
+    if own:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        for _ in range(8):
+            s.sample()
+            dist.all_reduce(counts)            # world size 1: identity, but exercises RCCL on the same stream
+            s.update()
+        torch.cuda.synchronize()
+        mom = mdist.moments_tensor(s)
+        mdist.pool_moments(mom)
+    finally:
+        if own:
+            dist.destroy_process_group()
+    ref = orc.gibbs_keyed(p, mu0, seed=3, n_iter=8, trace_len=8)
+    assert np.array_equal(s.trace(0), ref["trace"])
+    assert np.array_equal(mom.cpu().numpy()[:900], ref["sum_log"])
