@@ -1,0 +1,496 @@
+// hitsio.cpp -- see hitsio.hpp.  Written from the format description;
+// behaviour notes cite the reference lines they reproduce.
+#include "hitsio.hpp"
+
+#include <zlib.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <limits>
+#include <sstream>
+
+namespace hitsio_detail {
+
+// ---------------------------------------------------------------- buffered input (plain or zlib)
+class ByteSource {
+public:
+    ByteSource(const std::string &fileName, bool &ok)
+    {
+        fp = std::fopen(fileName.c_str(), "rb");
+        ok = fp != nullptr;
+        if (!ok) return;
+        int c = std::fgetc(fp);
+        if (c != EOF) std::ungetc(c, fp);
+        compressed = (c == 0x78); // "lazy but sufficient" zlib sniff, src/hitsio.cpp:258
+        if (compressed) {
+            std::memset(&zs, 0, sizeof zs);
+            if (inflateInit(&zs) != Z_OK) { ok = false; return; }
+            zinit = true;
+        }
+    }
+    ~ByteSource()
+    {
+        if (zinit) inflateEnd(&zs);
+        if (fp) std::fclose(fp);
+    }
+    // next byte or -1 at end of data
+    int peek()
+    {
+        if (pos == len && !fill()) return -1;
+        return (unsigned char)buf[pos];
+    }
+    int get()
+    {
+        int c = peek();
+        if (c >= 0) ++pos;
+        return c;
+    }
+    bool atEnd() { return peek() < 0; }
+    // std::getline semantics: reads up to '\n' (consumed, not stored). Returns false if nothing at all could be read.
+    bool getline(std::string &out)
+    {
+        out.clear();
+        if (atEnd()) return false;
+        for (;;) {
+            if (pos == len && !fill()) return true; // last line without newline
+            const char *p = (const char *)std::memchr(buf + pos, '\n', len - pos);
+            if (p) {
+                out.append(buf + pos, p - (buf + pos));
+                pos = (size_t)(p - buf) + 1;
+                return true;
+            }
+            out.append(buf + pos, len - pos);
+            pos = len;
+        }
+    }
+    bool read(void *dst, size_t n)
+    {
+        char *d = (char *)dst;
+        while (n) {
+            if (pos == len && !fill()) return false;
+            size_t take = std::min(n, len - pos);
+            std::memcpy(d, buf + pos, take);
+            pos += take; d += take; n -= take;
+        }
+        return true;
+    }
+    bool readU32(uint32_t &v)
+    {
+        unsigned char b[4];
+        if (!read(b, 4)) return false;
+        v = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24); // little-endian raw
+        return true;
+    }
+
+private:
+    bool fill()
+    {
+        pos = len = 0;
+        if (!compressed) {
+            len = std::fread(buf, 1, sizeof buf, fp);
+            return len > 0;
+        }
+        if (zdone) return false;
+        zs.next_out = (Bytef *)buf;
+        zs.avail_out = sizeof buf;
+        while (zs.avail_out == sizeof buf) {
+            if (zs.avail_in == 0) {
+                zs.avail_in = (uInt)std::fread(inbuf, 1, sizeof inbuf, fp);
+                zs.next_in = (Bytef *)inbuf;
+                if (zs.avail_in == 0) { zdone = true; break; } // truncated stream: stop like a short read
+            }
+            int rc = inflate(&zs, Z_NO_FLUSH);
+            if (rc == Z_STREAM_END) { zdone = true; break; }
+            if (rc != Z_OK && rc != Z_BUF_ERROR) {
+                std::cerr << "Error decompressing hits file (zlib error " << rc << ").\n";
+                std::exit(1);
+            }
+        }
+        len = sizeof buf - zs.avail_out;
+        return len > 0;
+    }
+    FILE *fp = nullptr;
+    bool compressed = false, zinit = false, zdone = false;
+    z_stream zs;
+    char buf[1 << 16];
+    char inbuf[1 << 16];
+    size_t pos = 0, len = 0;
+};
+
+// ---------------------------------------------------------------- output (plain or zlib level 1)
+class ByteSink {
+public:
+    ByteSink(FILE *f, bool compress) : fp(f), compressed(compress)
+    {
+        if (compressed) {
+            std::memset(&zs, 0, sizeof zs);
+            if (deflateInit(&zs, Z_BEST_SPEED) != Z_OK) { // zlib::best_speed, src/hitsio.cpp:127
+                std::cerr << "Error initialising zlib.\n";
+                std::exit(1);
+            }
+        }
+    }
+    ~ByteSink() { finish(); }
+    void write(const void *p, size_t n)
+    {
+        if (!compressed) { std::fwrite(p, 1, n, fp); return; }
+        zs.next_in = (Bytef *)p;
+        zs.avail_in = (uInt)n;
+        while (zs.avail_in) pump(Z_NO_FLUSH);
+    }
+    void writeStr(const std::string &s) { write(s.data(), s.size()); write("\n", 1); }
+    void writeU32(uint64_t v)
+    {
+        if (v > std::numeric_limits<uint32_t>::max()) {
+            std::cerr << "Numeric value overflow when writing the hits file" << std::endl; // src/hitsio.cpp:24-27
+            std::exit(1);
+        }
+        unsigned char b[4] = {(unsigned char)v, (unsigned char)(v >> 8), (unsigned char)(v >> 16), (unsigned char)(v >> 24)};
+        write(b, 4);
+    }
+    void writeSmall(uint64_t v) // 1 byte if < 255 else 0xFF + u32, src/hitsio.cpp:36-45
+    {
+        if (v < 255) { unsigned char b = (unsigned char)v; write(&b, 1); }
+        else { unsigned char b = 255; write(&b, 1); writeU32(v); }
+    }
+    void finish()
+    {
+        if (done) return;
+        done = true;
+        if (compressed) {
+            zs.avail_in = 0;
+            int rc;
+            do { rc = pump(Z_FINISH); } while (rc != Z_STREAM_END);
+            deflateEnd(&zs);
+        }
+        std::fflush(fp);
+    }
+
+private:
+    int pump(int flush)
+    {
+        zs.next_out = (Bytef *)outbuf;
+        zs.avail_out = sizeof outbuf;
+        int rc = deflate(&zs, flush);
+        std::fwrite(outbuf, 1, sizeof outbuf - zs.avail_out, fp);
+        return rc;
+    }
+    FILE *fp;
+    bool compressed, done = false;
+    z_stream zs;
+    char outbuf[1 << 16];
+};
+
+static std::string fmt_double(double v) // default ostream formatting (6 significant digits), src/hitsio.cpp:7-12
+{
+    std::ostringstream s;
+    s << v;
+    return s.str();
+}
+static double parse_double(const std::string &s) // src/hitsio.cpp:14-20
+{
+    std::istringstream i(s);
+    double x;
+    if (!(i >> x)) return 0;
+    return x;
+}
+
+} // namespace hitsio_detail
+
+using namespace hitsio_detail;
+
+// ================================================================= writer
+HitsfileWriter::HitsfileWriter(std::string fmt, FILE *out)
+{
+    hitsfileSchema = (!fmt.empty() && fmt[0] == 't') ? 0 : 1; // default binary, src/hitsio.cpp:118-126
+    sink.reset(new ByteSink(out, hitsfileSchema == 1));
+}
+HitsfileWriter::~HitsfileWriter() { close(); }
+void HitsfileWriter::close() { if (sink) sink->finish(); }
+
+void HitsfileWriter::addTranscriptMetaData(std::string name, double efflen, int truelen)
+{
+    transcriptName.push_back(name);
+    transcriptEffectiveLength.insert(std::make_pair(name, efflen));
+    transcriptTrueLength.insert(std::make_pair(name, truelen));
+    const uint32_t idx = (uint32_t)transcriptToIndex.size(); // evaluated BEFORE the insertion, src/hitsio.cpp:135-140
+    transcriptToIndex[name] = idx;
+}
+void HitsfileWriter::addGeneIsoformRecord(std::string geneName)
+{
+    geneIsoforms.insert(std::make_pair(geneName, std::vector<std::string>()));
+    currentGeneName = geneName;
+}
+void HitsfileWriter::addTranscriptToGeneIsoformRecord(std::string name) { geneIsoforms[currentGeneName].push_back(name); }
+void HitsfileWriter::addIdenticalTranscriptsRecord() { identicalTranscripts.push_back(std::vector<std::string>()); }
+void HitsfileWriter::addTranscriptToIdenticalTranscriptsRecord(std::string name) { identicalTranscripts.back().push_back(name); }
+
+void HitsfileWriter::writeHeaderSchema0()
+{
+    std::ostringstream o;
+    for (size_t i = 0; i < transcriptName.size(); i++)
+        o << "@TranscriptMetaData\t" << transcriptName[i] << "\t" << transcriptEffectiveLength[transcriptName[i]] << "\t"
+          << transcriptTrueLength[transcriptName[i]] << "\n";
+    for (auto &g : geneIsoforms) { // std::map order of gene ids
+        o << "@GeneIsoforms\t" << g.first;
+        for (auto &t : g.second) o << "\t" << t;
+        o << "\n";
+    }
+    for (auto &set : identicalTranscripts) {
+        o << "@IdenticalTranscripts";
+        for (auto &t : set) o << "\t" << t;
+        o << "\n";
+    }
+    const std::string s = o.str();
+    sink->write(s.data(), s.size());
+}
+void HitsfileWriter::writeHeaderSchema1()
+{
+    sink->writeStr(MMSEQ_HEADER);
+    sink->writeU32((uint64_t)hitsfileSchema);
+    sink->writeU32(transcriptName.size());
+    for (size_t i = 0; i < transcriptName.size(); i++) {
+        sink->writeStr(transcriptName[i]);
+        sink->writeStr(fmt_double(transcriptEffectiveLength[transcriptName[i]]));
+        sink->writeU32((uint64_t)(uint32_t)transcriptTrueLength[transcriptName[i]]);
+    }
+    sink->writeU32(geneIsoforms.size());
+    for (auto &g : geneIsoforms) {
+        sink->writeStr(g.first);
+        sink->writeU32(g.second.size());
+        for (auto &t : g.second) sink->writeStr(t);
+    }
+    sink->writeU32(identicalTranscripts.size());
+    for (auto &set : identicalTranscripts) {
+        sink->writeU32(set.size());
+        for (auto &t : set) sink->writeStr(t);
+    }
+}
+void HitsfileWriter::writeHeader() { if (hitsfileSchema == 0) writeHeaderSchema0(); else writeHeaderSchema1(); }
+
+void HitsfileWriter::addReadMapRecord(std::string readName) { currentReadName = readName; currentReadTranscripts.clear(); }
+void HitsfileWriter::addTranscriptToReadMapRecord(std::string name) { currentReadTranscripts.push_back(name); }
+
+void HitsfileWriter::writeReadMapRecordSchema0()
+{
+    std::string s = ">" + currentReadName + "\n";
+    for (auto &t : currentReadTranscripts) { s += t; s += "\n"; }
+    sink->write(s.data(), s.size());
+}
+void HitsfileWriter::writeReadMapRecordSchema1()
+{
+    // delta coding of the read name against the previous one, src/hitsio.cpp:77-100
+    const std::string &cur = currentReadName;
+    size_t nBeg = 0, nEnd = 0;
+    const size_t lim = std::min(deltaBuffer.size(), cur.size());
+    while (nBeg < lim && deltaBuffer[nBeg] == cur[nBeg]) nBeg++;
+    while (nBeg + nEnd < lim && deltaBuffer[deltaBuffer.size() - 1 - nEnd] == cur[cur.size() - 1 - nEnd]) nEnd++;
+    if (nBeg == 0 && nEnd == 0) {
+        sink->writeStr(cur);
+    } else {
+        sink->writeStr("");
+        sink->writeSmall(nBeg);
+        sink->writeStr(cur.substr(nBeg, cur.size() - nBeg - nEnd));
+        sink->writeSmall(nEnd);
+    }
+    deltaBuffer = cur;
+    sink->writeU32(currentReadTranscripts.size());
+    for (auto &t : currentReadTranscripts) sink->writeU32(transcriptToIndex[t]);
+}
+void HitsfileWriter::writeReadMapRecord() { if (hitsfileSchema == 0) writeReadMapRecordSchema0(); else writeReadMapRecordSchema1(); }
+
+// ================================================================= reader
+HitsfileReader::HitsfileReader(std::string fileName) : hitsfileSchema(-1), countReadMapRecord(0)
+{
+    bool ok = false;
+    {
+        ByteSource probe(fileName, ok);
+        if (!ok) {
+            std::cerr << "Error reading hits file \"" << fileName << "\".\n"; // src/hitsio.cpp:252-255
+            std::exit(1);
+        }
+        // schema detection from the first line, src/hitsio.cpp:263-276
+        std::string line;
+        probe.getline(line);
+        std::istringstream tokens(line);
+        std::string token1;
+        tokens >> token1;
+        if (token1 == "@TranscriptMetaData") {
+            hitsfileSchema = 0;
+        } else {
+            uint32_t v = 0xffffffffu;
+            probe.readU32(v);
+            hitsfileSchema = (v <= 4 && line == MMSEQ_HEADER) ? (int)v : -1;
+        }
+        if (hitsfileSchema < 0 || hitsfileSchema > 4) {
+            std::cerr << "Input file \"" << fileName << "\" does not seem to be a hits file.\n";
+            std::exit(1);
+        }
+    }
+    src.reset(new ByteSource(fileName, ok)); // reopen from the start, src/hitsio.cpp:277-284
+    if (!ok) {
+        std::cerr << "Error reading hits file \"" << fileName << "\".\n";
+        std::exit(1);
+    }
+}
+HitsfileReader::~HitsfileReader() {}
+
+void HitsfileReader::readHeaderSchema0(std::vector<std::string> *transcriptName, std::map<std::string, double> *efflen,
+                                       std::map<std::string, int> *truelen, std::map<std::string, std::vector<std::string>> *geneIsoforms,
+                                       std::vector<std::vector<std::string>> *identicalTranscripts)
+{
+    std::string line;
+    while (!src->atEnd() && src->peek() != '>') {
+        src->getline(line);
+        std::istringstream tokens(line);
+        std::string token1;
+        tokens >> token1;
+        if (token1 == "@TranscriptMetaData") {
+            std::string name;
+            double e = 0;
+            int t = 0;
+            tokens >> name >> e >> t;
+            transcriptName->push_back(name);
+            headerIndex.insert(std::make_pair(name, (uint32_t)headerTranscriptName.size()));
+            headerTranscriptName.push_back(name);
+            efflen->insert(std::make_pair(name, e));
+            truelen->insert(std::make_pair(name, t));
+        } else if (token1 == "@GeneIsoforms") {
+            std::string gid, tid;
+            std::vector<std::string> tids;
+            tokens >> gid;
+            while (tokens >> tid) tids.push_back(tid);
+            geneIsoforms->insert(std::make_pair(gid, tids));
+        } else if (token1 == "@IdenticalTranscripts") {
+            std::string tid;
+            std::vector<std::string> tids;
+            while (tokens >> tid) tids.push_back(tid);
+            identicalTranscripts->push_back(tids);
+        } else {
+            std::cerr << "Hits file looks malformed.\n"; // src/hitsio.cpp:324-327
+            std::exit(1);
+        }
+    }
+}
+
+void HitsfileReader::readHeaderSchema1(std::vector<std::string> *transcriptName, std::map<std::string, double> *efflen,
+                                       std::map<std::string, int> *truelen, std::map<std::string, std::vector<std::string>> *geneIsoforms,
+                                       std::vector<std::vector<std::string>> *identicalTranscripts)
+{
+    std::string s, s2;
+    uint32_t v = 0, n = 0;
+    auto need = [&](bool ok) {
+        if (!ok) { std::cerr << "Hits file looks malformed.\n"; std::exit(1); }
+    };
+    need(src->getline(s)); // "MMSEQ_HITSFILE"
+    need(src->readU32(v)); // schema
+    hitsfileSchema = (int)v;
+    need(src->readU32(n));
+    for (uint32_t i = 0; i < n; i++) {
+        need(src->getline(s));
+        transcriptName->push_back(s);
+        headerTranscriptName.push_back(s);
+        need(src->getline(s2));
+        efflen->insert(std::make_pair(s, parse_double(s2)));
+        need(src->readU32(v));
+        truelen->insert(std::make_pair(s, (int)v));
+    }
+    need(src->readU32(n));
+    for (uint32_t i = 0; i < n; i++) {
+        std::string gid;
+        need(src->getline(gid));
+        uint32_t cnt = 0;
+        need(src->readU32(cnt));
+        std::vector<std::string> tids;
+        for (uint32_t j = 0; j < cnt; j++) { need(src->getline(s)); tids.push_back(s); }
+        geneIsoforms->insert(std::make_pair(gid, tids));
+    }
+    need(src->readU32(n));
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t cnt = 0;
+        need(src->readU32(cnt));
+        std::vector<std::string> tids;
+        for (uint32_t j = 0; j < cnt; j++) { need(src->getline(s)); tids.push_back(s); }
+        identicalTranscripts->push_back(tids);
+    }
+}
+
+void HitsfileReader::readHeader(std::vector<std::string> *a, std::map<std::string, double> *b, std::map<std::string, int> *c,
+                                std::map<std::string, std::vector<std::string>> *d, std::vector<std::vector<std::string>> *e)
+{
+    if (hitsfileSchema == 0) readHeaderSchema0(a, b, c, d, e);
+    else if (hitsfileSchema == 1) readHeaderSchema1(a, b, c, d, e);
+    else { std::cerr << "We should never get to this state!\n"; std::exit(1); }
+}
+
+bool HitsfileReader::readReadMapRecordReadID(std::string &readID)
+{
+    if (hitsfileSchema == 0) {
+        if (src->atEnd()) return false;
+        src->getline(readID);
+        if (readID.empty() || readID[0] != '>') { std::cerr << "Hits file looks malformed.\n"; std::exit(1); }
+        readID = readID.substr(1);
+        if (src->atEnd()) { // src/hitsio.cpp:336-340
+            std::cerr << "Warning: read record without any mapping transcripts found"
+                      << " at the end of the hits file. The hits file may be corrupted.\n";
+            return false;
+        }
+        return true;
+    }
+    // schema 1: delta-decoded name, src/hitsio.cpp:102-115, :413-420
+    std::string s;
+    if (!src->getline(s)) return false;
+    if (s.empty()) {
+        auto small = [&](uint32_t &v) {
+            int b = src->get();
+            if (b < 0) return false;
+            if (b == 255) return src->readU32(v);
+            v = (uint32_t)b;
+            return true;
+        };
+        uint32_t nBeg = 0, nEnd = 0;
+        if (!small(nBeg)) return false;
+        if (!src->getline(s)) return false;
+        if (!small(nEnd)) return false;
+        if (nBeg > deltaBuffer.size() || nEnd > deltaBuffer.size()) { std::cerr << "Hits file looks malformed.\n"; std::exit(1); }
+        s = deltaBuffer.substr(0, nBeg) + s + deltaBuffer.substr(deltaBuffer.size() - nEnd, nEnd);
+    }
+    deltaBuffer = s;
+    uint32_t cnt = 0;
+    if (!src->readU32(cnt)) return false;
+    readID = s;
+    countReadMapRecord = cnt;
+    return true;
+}
+
+bool HitsfileReader::readReadMapRecordTranscriptIndex(uint32_t &index)
+{
+    if (hitsfileSchema == 0) {
+        std::string name;
+        if (!readReadMapRecordTranscriptID(name)) return false;
+        auto it = headerIndex.find(name);
+        if (it == headerIndex.end()) { index = 0xffffffffu; return true; } // not in the header: caller reports it
+        index = it->second;
+        return true;
+    }
+    if (countReadMapRecord == 0 || src->atEnd()) return false;
+    uint32_t v = 0;
+    if (!src->readU32(v)) return false;
+    countReadMapRecord--;
+    index = v;
+    return true;
+}
+
+bool HitsfileReader::readReadMapRecordTranscriptID(std::string &transcriptID)
+{
+    if (hitsfileSchema == 0) {
+        if (src->atEnd() || src->peek() == '>') return false;
+        return src->getline(transcriptID);
+    }
+    uint32_t v = 0;
+    if (!readReadMapRecordTranscriptIndex(v)) return false;
+    if (v >= headerTranscriptName.size()) { std::cerr << "Hits file looks malformed.\n"; std::exit(1); }
+    transcriptID = headerTranscriptName[v];
+    return true;
+}

@@ -1,0 +1,87 @@
+// hitsio.hpp -- reading and writing mmseq hits files (text schema 0, zlib-binary schema 1).
+//
+// Same class interface as the reference's src/hitsio.hpp:33-95 (HitsfileWriter / HitsfileReader,
+// same method names and argument meaning, errors print to stderr and exit(1) like the reference),
+// implemented from the file-format description on plain zlib instead of Boost.Iostreams:
+//   text   : src/hitsio.cpp:162-187 (writer), :286-347 (reader)
+//   binary : one zlib stream; "MMSEQ_HITSFILE\n", u32 schema, header tables, then records of
+//            delta-encoded read name + u32 count + u32 transcript indices
+//            (src/hitsio.cpp:189-213, :232-240, :349-398, :413-439; delta coding :77-115)
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#define MMSEQ_HEADER "MMSEQ_HITSFILE"
+
+namespace hitsio_detail {
+class ByteSource;
+class ByteSink;
+}
+
+class HitsfileWriter {
+public:
+    // 't...' = text (schema 0), anything else = binary (schema 1), like src/hitsio.cpp:117-129.
+    // The reference always writes to stdout; `out` (default stdout) is an additive extension.
+    explicit HitsfileWriter(std::string argHitsfileFormat, FILE *out = stdout);
+    ~HitsfileWriter();
+    void addTranscriptMetaData(std::string transcriptName, double effectiveLength, int trueLength);
+    void addGeneIsoformRecord(std::string geneName);
+    void addTranscriptToGeneIsoformRecord(std::string transcriptName);
+    void addIdenticalTranscriptsRecord();
+    void addTranscriptToIdenticalTranscriptsRecord(std::string transcriptName);
+    void writeHeader();
+    void addReadMapRecord(std::string readName);
+    void addTranscriptToReadMapRecord(std::string transcriptName);
+    void writeReadMapRecord();
+    void close(); // flushes the compressor (the reference relies on destructor order)
+
+private:
+    void writeHeaderSchema0();
+    void writeHeaderSchema1();
+    void writeReadMapRecordSchema0();
+    void writeReadMapRecordSchema1();
+    std::unique_ptr<hitsio_detail::ByteSink> sink;
+    int hitsfileSchema;
+    std::vector<std::string> transcriptName;
+    std::map<std::string, double> transcriptEffectiveLength;
+    std::map<std::string, int> transcriptTrueLength;
+    std::map<std::string, uint32_t> transcriptToIndex;
+    std::map<std::string, std::vector<std::string>> geneIsoforms;
+    std::string currentGeneName;
+    std::vector<std::vector<std::string>> identicalTranscripts;
+    std::string currentReadName;
+    std::vector<std::string> currentReadTranscripts;
+    std::string deltaBuffer;
+};
+
+class HitsfileReader {
+public:
+    explicit HitsfileReader(std::string fileName);
+    ~HitsfileReader();
+    void readHeader(std::vector<std::string> *transcriptName, std::map<std::string, double> *transcriptEffectiveLength,
+                    std::map<std::string, int> *transcriptTrueLength,
+                    std::map<std::string, std::vector<std::string>> *geneIsoforms,
+                    std::vector<std::vector<std::string>> *identicalTranscripts);
+    bool readReadMapRecordReadID(std::string &readID);
+    bool readReadMapRecordTranscriptID(std::string &transcriptID);
+    // Additive fast path: the transcript's index in header order instead of its name
+    // (the binary schema stores exactly this, src/hitsio.cpp:435-436).  -1 when the record is done.
+    bool readReadMapRecordTranscriptIndex(uint32_t &index);
+    int schema() const { return hitsfileSchema; }
+
+private:
+    void readHeaderSchema0(std::vector<std::string> *, std::map<std::string, double> *, std::map<std::string, int> *,
+                           std::map<std::string, std::vector<std::string>> *, std::vector<std::vector<std::string>> *);
+    void readHeaderSchema1(std::vector<std::string> *, std::map<std::string, double> *, std::map<std::string, int> *,
+                           std::map<std::string, std::vector<std::string>> *, std::vector<std::vector<std::string>> *);
+    std::unique_ptr<hitsio_detail::ByteSource> src;
+    std::vector<std::string> headerTranscriptName;
+    std::map<std::string, uint32_t> headerIndex; // text schema: name -> header index
+    int hitsfileSchema;
+    uint32_t countReadMapRecord;
+    std::string deltaBuffer;
+};

@@ -1,0 +1,51 @@
+// hitstools -- inspect / convert hits files (equivalent of the reference's src/hitstools.cpp:42-159,
+// built purely on hitsio).  Usage: hitstools inspect|header|t|b hits_file      (output on stdout)
+#include <cstdlib>
+#include <iostream>
+
+#include "hitsio.hpp"
+
+static void usage()
+{
+    std::cerr << "Usage: hitstools COMMAND hits_file\n\n"
+              << "Commands:\n"
+              << "  inspect   print the hits file in text format\n"
+              << "  header    print only the header in text format\n"
+              << "  t         convert to text format\n"
+              << "  b         convert to binary format\n";
+}
+
+int main(int argc, char **argv)
+{
+    if (argc != 3) { usage(); return 1; }
+    const std::string cmd = argv[1];
+    if (cmd != "inspect" && cmd != "header" && cmd != "t" && cmd != "b") { usage(); return 1; }
+    HitsfileReader reader(argv[2]);
+    HitsfileWriter writer(cmd == "b" ? "b" : "t");
+    std::vector<std::string> names;
+    std::map<std::string, double> efflen;
+    std::map<std::string, int> truelen;
+    std::map<std::string, std::vector<std::string>> genes;
+    std::vector<std::vector<std::string>> identical;
+    reader.readHeader(&names, &efflen, &truelen, &genes, &identical);
+    for (auto &n : names) writer.addTranscriptMetaData(n, efflen[n], truelen[n]);
+    for (auto &g : genes) {
+        writer.addGeneIsoformRecord(g.first);
+        for (auto &t : g.second) writer.addTranscriptToGeneIsoformRecord(t);
+    }
+    for (auto &set : identical) {
+        writer.addIdenticalTranscriptsRecord();
+        for (auto &t : set) writer.addTranscriptToIdenticalTranscriptsRecord(t);
+    }
+    writer.writeHeader();
+    if (cmd != "header") {
+        std::string id, tid;
+        while (reader.readReadMapRecordReadID(id)) {
+            writer.addReadMapRecord(id);
+            while (reader.readReadMapRecordTranscriptID(tid)) writer.addTranscriptToReadMapRecord(tid);
+            writer.writeReadMapRecord();
+        }
+    }
+    writer.close();
+    return 0;
+}
