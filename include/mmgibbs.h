@@ -152,6 +152,11 @@ int mmg_sampler_get_timing(mmg_sampler *s, mmg_timing *t);
 int mmg_sampler_reset_timing(mmg_sampler *s);
 void mmg_sampler_destroy(mmg_sampler *s);
 
+/* ---- host-side keyed draws ------------------------------------------------------------ */
+/* out[i] = Gamma(shape, scale) from the keyed stream (seed, tag SIMU, id, i): the simulated traces
+ * of isoforms without hits, src/mmseq.cpp:971-978 (which uses rg[0] there).  Pure host code. */
+int mmg_host_gamma_trace(uint64_t seed, uint64_t id, double shape, double scale, int n, double *out);
+
 /* ---- self-test hooks (used by tests only) ------------------------------------------- */
 /* Evaluates the library's own log / exp / sqrt / 1/x on x[0..n) (device >= 0: in a kernel
  * on that device; device == -1: the host instantiation of the same inline code). */

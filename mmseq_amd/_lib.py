@@ -76,6 +76,7 @@ SYMBOLS = {
     "mmg_sampler_get_timing": (C.c_int, [C.c_void_p, C.POINTER(Timing)]),
     "mmg_sampler_reset_timing": (C.c_int, [C.c_void_p]),
     "mmg_sampler_destroy": (None, [C.c_void_p]),
+    "mmg_host_gamma_trace": (C.c_int, [C.c_uint64, C.c_uint64, C.c_double, C.c_double, C.c_int, C.c_void_p]),
     "mmg_selftest_math": (C.c_int, [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mmg_selftest_philox": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mmg_selftest_gamma": (C.c_int, [C.c_int, C.c_uint64, C.c_double, C.c_double, C.c_int64, C.c_void_p]),

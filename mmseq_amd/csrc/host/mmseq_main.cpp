@@ -1,0 +1,850 @@
+// mmseq -- drop-in for the reference's `mmseq` CLI (src/mmseq.cpp:179-1728) with the Gibbs loop
+// (and the EM that seeds it) running on MI355X through libmmgibbs' C ABI (include/mmgibbs.h).
+//
+//   Usage: mmseq [OPTIONS...] hits_file output_base          (same flags as src/mmseq.cpp:156-177)
+//
+// What is the same as the reference: flags, validation and exit codes (:183-299), hits-file input
+// (hitsio), transcript / hit-set index order (:395-441), every output file, its column names, row
+// order and default 6-significant-digit formatting (:682-695, :823-831, :1033-1108, :1469-1669).
+// What differs on purpose: random numbers come from keyed Philox streams (results do not depend on
+// a thread count, cf. :834-838), the per-iteration "\r" progress line is throttled (:852), traces
+// are written after the loop from the device-resident trace, VLAs are heap vectors (:1308-1348).
+// There is no CPU sampler here: without a HIP device the program stops with an error.
+#include <omp.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <functional>
+#include <iostream>
+#include <limits>
+#include <map>
+#include <sstream>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../../include/mmgibbs.h"
+#include "hitsio.hpp"
+#include "numerics.hpp"
+
+#ifndef MMSEQ_VERSION
+#define MMSEQ_VERSION "1.0.11-mi355x"
+#endif
+
+using namespace std;
+
+static void printUsage(ostream &out)
+{
+    out << "Usage: mmseq [OPTIONS...] hits_file output_base" << endl
+        << endl
+        << "Mandatory arguments:" << endl
+        << "  hits_file          hits file generated with `bam2hits`\n"
+        << "  output_base        base name for output files" << endl
+        << endl
+        << "Optional arguments:\n"
+        << "  -alpha FLOAT       value of alpha in Gamma prior for mu (default: 0.1)" << endl
+        << "  -beta FLOAT        value of beta in Gamma prior for mu (default: 0.1)" << endl
+        << "  -max_em_iter INT   maximum number of EM iterations (default: 1000)" << endl
+        << "  -epsilon FLOAT     minimum loglik ratio between successive EM iterations (default: 0.1)" << endl
+        << "  -gibbs_iter INT    number of Gibbs iterations (default: 16384)" << endl
+        << "  -gibbs_ss INT      subsampling interval for Gibbs output (default: gibbs_iter/1024)" << endl
+        << "  -seed INT          seed for the PRNG in thread 0 (default: 1234)" << endl
+        << "  -percentiles STR   comma-separated list of real-scale marginal posterior percentiles to output (default: "
+           "\"5,25,50,75,95\")"
+        << endl
+        << "  -debug             output additional diagnostic files" << endl
+        << "  -help              print this help message" << endl
+        << "  -version           print the version" << endl
+        << "  -device INT        HIP device to run on (default: 0)              [MI355X build]" << endl
+        << endl;
+}
+
+static void tokenise(const string &str, vector<string> &tokens, const string &delimiters)
+{
+    string::size_type lastPos = str.find_first_not_of(delimiters, 0);
+    string::size_type pos = str.find_first_of(delimiters, lastPos);
+    while (string::npos != pos || string::npos != lastPos) {
+        tokens.push_back(str.substr(lastPos, pos - lastPos));
+        lastPos = str.find_first_not_of(delimiters, pos);
+        pos = str.find_first_of(delimiters, lastPos);
+    }
+}
+
+static int powerof2(unsigned int x)
+{
+    while (((x & 1) == 0) && x > 1) x >>= 1;
+    return (x == 1);
+}
+
+#define MMG_TRY(expr)                                                                     \
+    do {                                                                                  \
+        if ((expr) != 0) {                                                                \
+            cerr << "Error: " << mmg_last_error() << " (" << #expr << ")" << endl;         \
+            exit(1);                                                                      \
+        }                                                                                 \
+    } while (0)
+
+// gzip text sink with ostream-compatible number formatting ("%g" == default ostream, 6 digits)
+struct GzText {
+    gzFile f = nullptr;
+    string buf;
+    explicit GzText(const string &path)
+    {
+        f = gzopen(path.c_str(), "wb");
+        if (!f) { cerr << "Error: cannot open " << path << " for writing.\n"; exit(1); }
+        buf.reserve(1 << 20);
+    }
+    void str(const string &s) { buf += s; maybe_flush(); }
+    void num(double v)
+    {
+        char tmp[40];
+        int n = snprintf(tmp, sizeof tmp, "%g", v);
+        buf.append(tmp, n);
+    }
+    void maybe_flush() { if (buf.size() > (1 << 20) - 64) flush(); }
+    void flush() { if (!buf.empty()) { gzwrite(f, buf.data(), (unsigned)buf.size()); buf.clear(); } }
+    void close() { flush(); gzclose(f); f = nullptr; }
+};
+
+// rows of n numbers, each followed by a space, one line per sample (src/mmseq.cpp:912-916):
+// lines are formatted in parallel, compressed serially
+static void write_trace_lines(GzText &gz, int n_lines, size_t n_cols, const function<double(int, size_t)> &at,
+                              const function<bool(size_t)> &keep)
+{
+    const int B = 16;
+    vector<string> lines(B);
+    for (int i0 = 0; i0 < n_lines; i0 += B) {
+        const int nb = min(B, n_lines - i0);
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int b = 0; b < nb; ++b) {
+            string &s = lines[b];
+            s.clear();
+            char tmp[40];
+            for (size_t c = 0; c < n_cols; ++c) {
+                if (!keep(c)) continue;
+                int len = snprintf(tmp, sizeof tmp, "%g ", at(i0 + b, c));
+                s.append(tmp, len);
+            }
+            s += "\n";
+        }
+        for (int b = 0; b < nb; ++b) { gz.flush(); gzwrite(gz.f, lines[b].data(), (unsigned)lines[b].size()); }
+    }
+}
+
+int main(int argc, char **argv)
+{
+    const int max_threads = omp_get_max_threads();
+
+    // DEFAULT PARAMETER VALUES (src/mmseq.cpp:183-205)
+    double alpha = 0.1, beta = 0.1;
+    int max_em_iter = 1000;
+    double epsilon = 0.1;
+    int gibbs_iter = 16384;
+    const int trace_length = 1024;
+    int gibbs_ss = gibbs_iter / trace_length;
+    vector<double> percentiles = {5.0, 25.0, 50.0, 75.0, 95.0};
+    vector<string> tokens;
+    int seed = 1234;
+    bool debug = false;
+    int device = 0;
+
+    vector<string> arguments;
+    for (int i = 1; i < argc; i++) arguments.push_back(string(argv[i]));
+    auto need_value = [&]() {
+        if (arguments.size() < 2) { cerr << "Error: mandatory arguments missing.\n"; printUsage(cerr); exit(1); }
+    };
+    while (true) {
+        if (arguments.size() > 0 && arguments[0] == "-alpha") {
+            need_value(); arguments.erase(arguments.begin());
+            alpha = strtod(arguments[0].c_str(), NULL); arguments.erase(arguments.begin());
+        } else if (arguments.size() > 0 && arguments[0] == "-beta") {
+            need_value(); arguments.erase(arguments.begin());
+            beta = strtod(arguments[0].c_str(), NULL); arguments.erase(arguments.begin());
+        } else if (arguments.size() > 0 && arguments[0] == "-max_em_iter") {
+            need_value(); arguments.erase(arguments.begin());
+            max_em_iter = atoi(arguments[0].c_str()); arguments.erase(arguments.begin());
+        } else if (arguments.size() > 0 && arguments[0] == "-epsilon") {
+            need_value(); arguments.erase(arguments.begin());
+            epsilon = strtod(arguments[0].c_str(), NULL); arguments.erase(arguments.begin());
+        } else if (arguments.size() > 0 && arguments[0] == "-gibbs_iter") {
+            need_value(); arguments.erase(arguments.begin());
+            gibbs_iter = atoi(arguments[0].c_str()); arguments.erase(arguments.begin());
+        } else if (arguments.size() > 0 && arguments[0] == "-gibbs_ss") {
+            need_value(); arguments.erase(arguments.begin());
+            gibbs_ss = atoi(arguments[0].c_str()); arguments.erase(arguments.begin());
+        } else if (arguments.size() > 0 && arguments[0] == "-seed") {
+            need_value(); arguments.erase(arguments.begin());
+            seed = atoi(arguments[0].c_str()); arguments.erase(arguments.begin());
+        } else if (arguments.size() > 0 && arguments[0] == "-device") {
+            need_value(); arguments.erase(arguments.begin());
+            device = atoi(arguments[0].c_str()); arguments.erase(arguments.begin());
+        } else if (arguments.size() > 0 && arguments[0] == "-percentiles") {
+            need_value(); arguments.erase(arguments.begin());
+            tokens.clear();
+            tokenise(arguments[0], tokens, ",");
+            percentiles.resize(tokens.size());
+            for (size_t i = 0; i < tokens.size(); i++) {
+                const double v = strtod(tokens[i].c_str(), NULL);
+                if (v >= 0 && v <= 100) percentiles[i] = v;
+                else { cerr << "Percentiles must be in (0,100)\n"; exit(1); }
+            }
+            arguments.erase(arguments.begin());
+        } else if (arguments.size() > 0 && arguments[0] == "-debug") {
+            debug = true; arguments.erase(arguments.begin());
+        } else if (arguments.size() > 0 && (arguments[0] == "-h" || arguments[0] == "--help" || arguments[0] == "-help")) {
+            cerr << "Calculate mmseq expression estimates.\n";
+            printUsage(cerr);
+            exit(1); // the reference exits 1 here too (src/mmseq.cpp:256-259)
+        } else if (arguments.size() > 0 && (arguments[0] == "-v" || arguments[0] == "--version" || arguments[0] == "-version")) {
+            cerr << "mmseq-" << MMSEQ_VERSION << endl;
+            exit(1);
+        } else {
+            if (arguments.size() == 2) break;
+            if (arguments.size() > 0 && arguments[0][0] == '-') cerr << "Error: unrecognised option " << arguments[0] << ".\n";
+            else cerr << "Error: mandatory arguments missing.\n";
+            printUsage(cerr);
+            exit(1);
+        }
+    }
+    if (gibbs_ss == 0 || gibbs_iter % gibbs_ss != 0) { // :278 (gibbs_ss == 0 is a division by zero there)
+        cerr << "Error: gibbs_iter must be divisible by gibbs_ss.\n";
+        printUsage(cerr);
+        exit(1);
+    }
+    gibbs_ss = gibbs_iter / trace_length; // :284 -- the user's -gibbs_ss is overwritten, as in the reference
+    if (gibbs_iter <= 0 || trace_length <= 0) {
+        cerr << "Error: no. of iteratons or trace length <= 0. Possible integer overflow - is gibbs_iter too high?\n";
+        printUsage(cerr);
+        exit(1);
+    }
+    if (gibbs_ss < 1 || gibbs_iter % trace_length != 0) { // the reference overruns its trace / divides by zero here (App. A)
+        cerr << "Error: gibbs_iter must be a positive multiple of " << trace_length << ".\n";
+        printUsage(cerr);
+        exit(1);
+    }
+    if (!powerof2(trace_length)) {
+        cerr << "Error: gibbs_iter/gibbs_ss must be a power of 2.\n";
+        printUsage(cerr);
+        exit(1);
+    }
+    const string hits_file = arguments[0];
+    const string output_base(arguments[1]);
+
+    HitsfileReader hitsfileReader(hits_file);
+
+    cout << "Running mmseq with parameters:\n"
+         << "  alpha:         " << alpha << endl
+         << "  beta:          " << beta << endl
+         << "  max_em_iter:   " << max_em_iter << endl
+         << "  epsilon:       " << epsilon << endl
+         << "  gibbs_iter:    " << gibbs_iter << endl
+         << "  gibbs_ss:      " << gibbs_ss << endl
+         << "  seed[0]:       " << seed << endl
+         << "  debug:         " << debug << endl
+         << "  threads:       " << max_threads << endl
+         << "  device:        " << device << " (HIP, libmmgibbs ABI " << mmg_abi_version() << ")" << endl;
+
+    // ---- header (src/mmseq.cpp:332-379)
+    map<string, double> sidLen;
+    map<string, int> sidSeqLen;
+    vector<string> transcriptList;
+    map<string, vector<string>> gene2transcripts;
+    vector<vector<string>> identical_transcripts;
+    hitsfileReader.readHeader(&transcriptList, &sidLen, &sidSeqLen, &gene2transcripts, &identical_transcripts);
+
+    map<string, string> transcript2gene;
+    {
+        vector<string> transcriptListGI;
+        for (auto &g : gene2transcripts)
+            for (auto &t : g.second) {
+                if (transcript2gene.count(t) > 0) {
+                    cerr << "Error: transcripts must be nested within genes in GeneIsoforms metadata.\n";
+                    exit(1);
+                }
+                transcriptListGI.push_back(t);
+                transcript2gene[t] = g.first;
+            }
+        vector<string> a = transcriptList, b = transcriptListGI;
+        sort(a.begin(), a.end());
+        sort(b.begin(), b.end());
+        if ((size_t)(unique(a.begin(), a.end()) - a.begin()) != transcriptList.size()) {
+            cerr << "Error: duplicate transcripts in @TranscriptMetaData entries.\n";
+            exit(1);
+        }
+        if ((size_t)(unique(b.begin(), b.end()) - b.begin()) != transcriptListGI.size()) {
+            cerr << "Error: duplicate transcripts in @GeneIsoforms entries.\n";
+            exit(1);
+        }
+        for (auto &t : transcriptList)
+            if (transcript2gene.count(t) == 0) {
+                cerr << "Error: " << t << " does not belong to a gene in the @GeneIsoforms header entries.\n";
+                exit(1);
+            }
+    }
+    const size_t nHeader = transcriptList.size();
+
+    // ---- READ LOOP (src/mmseq.cpp:395-441): transcript index = first-seen order, row = first-seen hit set
+    vector<int32_t> hdr2obs(nHeader, -1); // header index -> observed index
+    vector<uint32_t> obs2hdr;             // indexSid
+    vector<int> doublehits;
+    vector<uint32_t> k;                   // multiplicity per hit set
+    vector<uint64_t> row_ptr(1, 0);       // hit sets in first-seen order
+    vector<uint32_t> col_idx;
+    unordered_map<string, uint32_t> indexComb;
+    long long numbermappedreads = 0;
+    {
+        string rid, key;
+        vector<uint32_t> comb;
+        uint32_t hidx = 0;
+        while (hitsfileReader.readReadMapRecordReadID(rid)) {
+            numbermappedreads++;
+            comb.clear();
+            while (hitsfileReader.readReadMapRecordTranscriptIndex(hidx)) {
+                if (hidx >= nHeader) {
+                    cerr << "Error: a read maps to a transcript that has no @TranscriptMetaData entry (no length).\n";
+                    exit(1);
+                }
+                if (hdr2obs[hidx] < 0) { hdr2obs[hidx] = (int32_t)obs2hdr.size(); obs2hdr.push_back(hidx); doublehits.push_back(0); }
+                const uint32_t o = (uint32_t)hdr2obs[hidx];
+                if (find(comb.begin(), comb.end(), o) == comb.end()) comb.push_back(o);
+                else doublehits[o]++;
+            }
+            sort(comb.begin(), comb.end());
+            key.assign((const char *)comb.data(), comb.size() * sizeof(uint32_t));
+            auto it = indexComb.find(key);
+            if (it == indexComb.end()) {
+                const uint32_t row = (uint32_t)k.size();
+                if ((row & 0xfff) == 0)
+                    cout << "Found " << obs2hdr.size() << " transcripts in " << row << " transcript combinations.\r" << flush;
+                indexComb.emplace(key, row);
+                k.push_back(0);
+                col_idx.insert(col_idx.end(), comb.begin(), comb.end());
+                row_ptr.push_back(col_idx.size());
+                it = indexComb.find(key);
+            }
+            k[it->second]++;
+        }
+        cout << "Found " << obs2hdr.size() << " transcripts in " << k.size() << " transcript combinations." << endl;
+    }
+    const uint32_t n = (uint32_t)obs2hdr.size();
+    const uint64_t m = k.size();
+    if (n == 0 || m == 0) { cerr << "Error: no reads with transcript hits found in the hits file.\n"; exit(1); }
+    auto sid = [&](uint32_t t) -> const string & { return transcriptList[obs2hdr[t]]; };
+    auto obs_of = [&](const string &name) -> int32_t { // sidIndex lookup by name
+        static map<string, int32_t> cache;
+        if (cache.empty()) for (uint32_t t = 0; t < n; ++t) cache[sid(t)] = (int32_t)t;
+        auto it = cache.find(name);
+        return it == cache.end() ? -1 : it->second;
+    };
+
+    // ---- l[t] (src/mmseq.cpp:593-608)
+    vector<double> l(n);
+    for (uint32_t t = 0; t < n; t++) {
+        if (sidLen.count(sid(t)) == 0) { cerr << "Error: transcript '" << sid(t) << "' has no length.\n"; exit(1); }
+        l[t] = (double)sidLen[sid(t)] * (double)numbermappedreads / 1000000000.0;
+        if (l[t] <= 0) { cerr << "Error: transcript '" << sid(t) << "' has a length of zero.\n"; exit(1); }
+    }
+
+    // ---- start values and the shared-count histogram (src/mmseq.cpp:610-638); host, deterministic
+    vector<vector<int>> counts_shared(n, vector<int>(100, 0));
+    vector<double> mu(n, 0.0);
+    for (uint64_t i = 0; i < m; ++i) {
+        const uint64_t b = row_ptr[i], e = row_ptr[i + 1];
+        const int L = (int)(e - b);
+        for (uint64_t j = b; j < e; ++j) {
+            mu[col_idx[j]] += (double)k[i] / L;
+            counts_shared[col_idx[j]][min(L, 100) - 1] += (int)k[i];
+        }
+    }
+    for (uint32_t t = 0; t < n; ++t) mu[t] /= l[t];
+
+    // ---- unique hits to identical sets and genes: O(nnz) form of src/uh.cpp:3-26
+    vector<int> identical_unique_hits(identical_transcripts.size(), 0), gene_unique_hits(gene2transcripts.size(), 0);
+    {
+        cerr << "Counting unique hits to sets of identical transcripts...";
+        vector<vector<uint32_t>> t2sets(n);
+        for (size_t v = 0; v < identical_transcripts.size(); ++v)
+            for (auto &name : identical_transcripts[v]) {
+                const int32_t t = obs_of(name);
+                if (t >= 0) t2sets[t].push_back((uint32_t)v);
+            }
+        vector<uint32_t> cand, tmp;
+        for (uint64_t i = 0; i < m; ++i) {
+            const uint64_t b = row_ptr[i], e = row_ptr[i + 1];
+            if (b == e) { for (auto &x : identical_unique_hits) x += (int)k[i]; continue; } // empty row counts for every group
+            cand = t2sets[col_idx[b]];
+            for (uint64_t j = b + 1; j < e && !cand.empty(); ++j) {
+                tmp.clear();
+                for (uint32_t s : cand)
+                    if (find(t2sets[col_idx[j]].begin(), t2sets[col_idx[j]].end(), s) != t2sets[col_idx[j]].end()) tmp.push_back(s);
+                cand.swap(tmp);
+            }
+            sort(cand.begin(), cand.end());
+            cand.erase(unique(cand.begin(), cand.end()), cand.end());
+            for (uint32_t s : cand) identical_unique_hits[s] += (int)k[i];
+        }
+        cerr << "done." << endl;
+        cerr << "Counting unique hits to genes...";
+        map<string, int> gene2index;
+        { int g = 0; for (auto &gt : gene2transcripts) gene2index[gt.first] = g++; }
+        vector<int> t2g(n);
+        for (uint32_t t = 0; t < n; ++t) t2g[t] = gene2index[transcript2gene[sid(t)]];
+        for (uint64_t i = 0; i < m; ++i) {
+            const uint64_t b = row_ptr[i], e = row_ptr[i + 1];
+            if (b == e) { for (auto &x : gene_unique_hits) x += (int)k[i]; continue; }
+            const int g = t2g[col_idx[b]];
+            bool uniq = true;
+            for (uint64_t j = b + 1; j < e; ++j) if (t2g[col_idx[j]] != g) { uniq = false; break; }
+            if (uniq) gene_unique_hits[g] += (int)k[i];
+        }
+        cerr << "done." << endl;
+    }
+
+    // ---- .k and .M (src/mmseq.cpp:682-695)
+    ofstream ofs;
+    ofs.open((output_base + ".k").c_str());
+    for (uint64_t i = 0; i < m; i++) ofs << k[i] << "\n";
+    ofs.close(); ofs.clear();
+    ofs.open((output_base + ".M").c_str());
+    ofs << "#";
+    for (uint32_t t = 0; t < n; t++) ofs << "\t" << sid(t);
+    ofs << "\n";
+    for (uint64_t i = 0; i < m; ++i)
+        for (uint64_t j = row_ptr[i]; j < row_ptr[i + 1]; ++j) ofs << i << "\t" << col_idx[j] << "\n";
+    ofs.close(); ofs.clear();
+
+    if (debug) { // src/mmseq.cpp:697-731
+        ofs.open((output_base + ".sharedcounts").c_str());
+        for (auto &name : transcriptList) {
+            ofs << name << "\t";
+            const int32_t t = obs_of(name);
+            for (int i = 0; i < 100; i++) ofs << (t >= 0 ? counts_shared[t][i] : 0) << "\t";
+            ofs << endl;
+        }
+        ofs.close(); ofs.clear();
+        ofs.open((output_base + ".doublehits").c_str());
+        for (uint32_t i = 0; i < n; i++) ofs << doublehits[i] << endl;
+        ofs.close(); ofs.clear();
+        // transposed matrix without consecutive duplicate rows, and the ids of the duplicates
+        vector<vector<uint32_t>> Mt(n);
+        for (uint64_t i = 0; i < m; ++i)
+            for (uint64_t j = row_ptr[i]; j < row_ptr[i + 1]; ++j) Mt[col_idx[j]].push_back((uint32_t)i);
+        ofs.open((output_base + ".Mt-nodups").c_str());
+        ofstream ofs2((output_base + ".dupIDs").c_str());
+        for (uint32_t t = 0; t < n; ++t) {
+            if (t > 0 && Mt[t] == Mt[t - 1]) ofs2 << sid(t) << endl;
+            else for (uint32_t r : Mt[t]) ofs << t << "\t" << r << endl;
+        }
+        ofs.close(); ofs.clear();
+    }
+
+    // ---- device problem: rows stably sorted by (leading transcript, length) -- the layout the sample
+    //      kernel's LDS window wants; the row order is irrelevant to the model (rows are exchangeable)
+    mmg_problem *prob = nullptr;
+    {
+        vector<uint32_t> order(m);
+        for (uint64_t i = 0; i < m; ++i) order[i] = (uint32_t)i;
+        stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+            const uint64_t la = row_ptr[a + 1] - row_ptr[a], lb = row_ptr[b + 1] - row_ptr[b];
+            const int64_t fa = la ? (int64_t)col_idx[row_ptr[a]] : -1, fb = lb ? (int64_t)col_idx[row_ptr[b]] : -1;
+            if (fa != fb) return fa < fb;
+            return la < lb;
+        });
+        vector<uint64_t> d_rp(m + 1, 0);
+        vector<uint32_t> d_ci(col_idx.size()), d_k(m);
+        for (uint64_t i = 0; i < m; ++i) {
+            const uint32_t r = order[i];
+            const uint64_t L = row_ptr[r + 1] - row_ptr[r];
+            copy(col_idx.begin() + row_ptr[r], col_idx.begin() + row_ptr[r + 1], d_ci.begin() + d_rp[i]);
+            d_rp[i + 1] = d_rp[i] + L;
+            d_k[i] = k[r];
+        }
+        mmg_problem_desc pd;
+        pd.m = m; pd.n = n; pd.row_ptr = d_rp.data(); pd.col_idx = d_ci.data(); pd.k = d_k.data(); pd.l = l.data();
+        pd.row_id_base = 0;
+        MMG_TRY(mmg_problem_create(&pd, device, &prob));
+    }
+
+    // ---- EM on the device (src/mmseq.cpp:741-811), one sweep per call so the per-iteration output matches
+    GzText *gz_em = debug ? new GzText(output_base + ".trace_em.gz") : nullptr;
+    if (gz_em) { for (uint32_t t = 0; t < n; t++) { gz_em->str(sid(t)); gz_em->str(" "); } gz_em->str("\n"); }
+    {
+        double loglik = 0.0;
+        int its = 0;
+        MMG_TRY(mmg_problem_em(prob, mu.data(), 0, epsilon, &its, &loglik));
+        double llr = epsilon + 1;
+        int iter = 0;
+        cout.precision(5);
+        cout.setf(ios::fixed, ios::floatfield);
+        while (iter < max_em_iter && llr > epsilon) {
+            cout << "EM iteration " << iter << flush;
+            if (gz_em) { for (uint32_t t = 0; t < n; t++) { gz_em->num(mu[t]); gz_em->str(" "); } gz_em->str("\n"); }
+            double ll = 0.0;
+            MMG_TRY(mmg_problem_em(prob, mu.data(), 1, -numeric_limits<double>::max(), &its, &ll));
+            llr = ll - loglik;
+            loglik = ll;
+            cout << ", log likelihood ratio: " << llr << "            \r";
+            iter++;
+        }
+        cout << endl;
+        cout.unsetf(ios::floatfield);
+        cout.precision(6);
+    }
+    if (gz_em) { gz_em->close(); delete gz_em; }
+    const vector<double> mu_em = mu;
+
+    // ---- Gibbs on the device (src/mmseq.cpp:833-918)
+    vector<double> mu_trace((size_t)n * trace_length);
+    {
+        mmg_config cfg;
+        memset(&cfg, 0, sizeof cfg);
+        cfg.alpha = alpha; cfg.beta = beta; cfg.seed = (uint64_t)(int64_t)seed;
+        cfg.n_chains = 1; cfg.chain_base = 0; cfg.gibbs_iter = gibbs_iter; cfg.trace_len = trace_length;
+        cfg.keep_trace = 1; cfg.timing = 0;
+        mmg_sampler *smp = nullptr;
+        MMG_TRY(mmg_sampler_create(prob, &cfg, mu_em.data(), &smp));
+        const int chunk = max(1, gibbs_iter / 16);
+        for (int done = 0; done < gibbs_iter; done += chunk) {
+            cout << "Gibbs iteration " << done << "       \r" << flush;
+            MMG_TRY(mmg_sampler_run(smp, min(chunk, gibbs_iter - done)));
+            MMG_TRY(mmg_sampler_sync(smp));
+        }
+        cout << "Gibbs iteration " << gibbs_iter - 1 << "       \r" << endl;
+        MMG_TRY(mmg_sampler_get_trace(smp, 0, mu_trace.data()));
+        mmg_sampler_destroy(smp);
+    }
+    mmg_problem_destroy(prob);
+
+    // ---- .trace_gibbs.gz (src/mmseq.cpp:823-831, :911-917), written after the loop
+    {
+        GzText gz(output_base + ".trace_gibbs.gz");
+        for (uint32_t t = 0; t < n; t++) { gz.str(sid(t)); gz.str(" "); }
+        gz.str("\n");
+        write_trace_lines(gz, trace_length, n, [&](int i, size_t t) { return mu_trace[t * trace_length + i]; },
+                          [](size_t) { return true; });
+        gz.close();
+    }
+
+    cout << "Amalgamating transcripts and calculating summary statistics..." << flush;
+
+    // ---- trace aggregation (src/mmseq.cpp:927-1008)
+    const size_t nI = identical_transcripts.size(), nG = gene2transcripts.size();
+    vector<double> mu_trace_identical(nI * trace_length, 0.0), mu_trace_gene(nG * trace_length, 0.0);
+    for (size_t v = 0; v < nI; ++v)
+        for (auto &name : identical_transcripts[v]) {
+            const int32_t t = obs_of(name);
+            if (t >= 0) for (int i = 0; i < trace_length; i++) mu_trace_identical[v * trace_length + i] += mu_trace[(size_t)t * trace_length + i];
+        }
+    map<string, uint32_t> headerIndexOf;
+    for (size_t i = 0; i < nHeader; ++i) headerIndexOf[transcriptList[i]] = (uint32_t)i;
+    map<string, vector<double>> mu_trace_simu, prop_trace_simu;
+    {
+        size_t g = 0;
+        for (auto &gt : gene2transcripts) {
+            for (auto &name : gt.second) {
+                const int32_t t = obs_of(name);
+                if (t >= 0) {
+                    for (int i = 0; i < trace_length; i++) mu_trace_gene[g * trace_length + i] += mu_trace[(size_t)t * trace_length + i];
+                } else { // no hits: simulate from the prior-only conditional (keyed by the header index, :971-978)
+                    vector<double> temp(trace_length);
+                    const uint64_t id = headerIndexOf.count(name) ? headerIndexOf[name] : (uint64_t)nHeader + g;
+                    MMG_TRY(mmg_host_gamma_trace((uint64_t)(int64_t)seed, id, alpha,
+                                                 1.0 / (beta + sidLen[name] * (double)numbermappedreads / 1000000000.0), trace_length,
+                                                 temp.data()));
+                    for (int i = 0; i < trace_length; i++) mu_trace_gene[g * trace_length + i] += temp[i];
+                    mu_trace_simu[name] = temp;
+                }
+            }
+            g++;
+        }
+    }
+    vector<double> prop_trace((size_t)n * trace_length, NAN);
+    {
+        size_t g = 0;
+        for (auto &gt : gene2transcripts) {
+            for (auto &name : gt.second) {
+                const int32_t t = obs_of(name);
+                if (t >= 0) {
+                    for (int i = 0; i < trace_length; i++)
+                        prop_trace[(size_t)t * trace_length + i] = mu_trace[(size_t)t * trace_length + i] / mu_trace_gene[g * trace_length + i];
+                } else {
+                    vector<double> temp(trace_length);
+                    for (int i = 0; i < trace_length; i++) temp[i] = mu_trace_simu[name][i] / mu_trace_gene[g * trace_length + i];
+                    prop_trace_simu[name] = temp;
+                }
+            }
+            g++;
+        }
+    }
+
+    // ---- identical / gene / proportion traces (src/mmseq.cpp:1033-1108)
+    {
+        vector<char> keepI(nI), keepG(nG);
+        for (size_t v = 0; v < nI; ++v) keepI[v] = isfinite(log(mu_trace_identical[v * trace_length])) != 0;
+        for (size_t g = 0; g < nG; ++g) keepG[g] = isfinite(log(mu_trace_gene[g * trace_length])) != 0;
+        GzText gi(output_base + ".identical.trace_gibbs.gz");
+        for (size_t v = 0; v < nI; ++v)
+            if (keepI[v]) {
+                for (size_t j = 0; j < identical_transcripts[v].size(); ++j) {
+                    gi.str(identical_transcripts[v][j]);
+                    if (identical_transcripts[v][j].compare(identical_transcripts[v].back()) != 0) gi.str("+");
+                }
+                gi.str(" ");
+            }
+        gi.str("\n");
+        write_trace_lines(gi, trace_length, nI, [&](int i, size_t v) { return mu_trace_identical[v * trace_length + i]; },
+                          [&](size_t v) { return keepI[v] != 0; });
+        gi.close();
+        GzText gg(output_base + ".gene.trace_gibbs.gz");
+        { size_t g = 0; for (auto &gt : gene2transcripts) { if (keepG[g]) { gg.str(gt.first); gg.str(" "); } g++; } }
+        gg.str("\n");
+        write_trace_lines(gg, trace_length, nG, [&](int i, size_t g) { return mu_trace_gene[g * trace_length + i]; },
+                          [&](size_t g) { return keepG[g] != 0; });
+        gg.close();
+        GzText gp(output_base + ".prop.trace_gibbs.gz");
+        for (uint32_t t = 0; t < n; t++) { gp.str(sid(t)); gp.str(" "); }
+        gp.str("\n");
+        write_trace_lines(gp, trace_length, n, [&](int i, size_t t) { return prop_trace[t * trace_length + i]; },
+                          [](size_t) { return true; });
+        gp.close();
+    }
+
+    // ---- percentiles (src/mmseq.cpp:1110-1192)
+    const size_t nP = percentiles.size();
+    vector<int> pind(nP);
+    for (size_t i = 0; i < nP; i++) pind[i] = static_cast<int>(round(percentiles[i] / 100.0 * (trace_length - 1)));
+    auto pct_of = [&](const double *tr, vector<double> &out) {
+        vector<double> v(tr, tr + trace_length);
+        std::sort(v.begin(), v.end());
+        out.resize(nP);
+        for (size_t j = 0; j < nP; j++) out[j] = v[pind[j]];
+    };
+    vector<vector<double>> percentiles_prop(n), percentiles_transcript(n), percentiles_identical(nI), percentiles_gene(nG);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)n; i++) {
+        pct_of(&prop_trace[(size_t)i * trace_length], percentiles_prop[i]);
+        pct_of(&mu_trace[(size_t)i * trace_length], percentiles_transcript[i]);
+    }
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)nI; i++) pct_of(&mu_trace_identical[(size_t)i * trace_length], percentiles_identical[i]);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)nG; i++) pct_of(&mu_trace_gene[(size_t)i * trace_length], percentiles_gene[i]);
+    map<string, vector<double>> percentiles_simu, percentiles_prop_simu;
+    for (auto &s : mu_trace_simu) pct_of(s.second.data(), percentiles_simu[s.first]);
+    for (auto &s : prop_trace_simu) pct_of(s.second.data(), percentiles_prop_simu[s.first]);
+
+    // ---- log traces and their means (src/mmseq.cpp:1195-1227)
+    vector<double> meanmu(n, 0), meanmu_identical(nI, 0), meanmu_gene(nG, 0);
+    auto log_and_mean = [&](vector<double> &tr, vector<double> &mean, size_t count) {
+#pragma omp parallel for schedule(static)
+        for (int64_t t = 0; t < (int64_t)count; t++) {
+            double sacc = 0;
+            for (int i = 0; i < trace_length; i++) { double &x = tr[(size_t)t * trace_length + i]; x = log(x); sacc += x; }
+            mean[t] = sacc / trace_length;
+        }
+    };
+    log_and_mean(mu_trace, meanmu, n);
+    log_and_mean(mu_trace_identical, meanmu_identical, nI);
+    log_and_mean(mu_trace_gene, meanmu_gene, nG);
+
+    // ---- proportion summaries (src/mmseq.cpp:1235-1305)
+    auto prop_summary = [&](const double *pt, bool multi, double &meanprop, double &meanprobit, double &sdprobit) {
+        double sp = 0, s1 = 0, s2 = 0;
+        for (int i = 0; i < trace_length; i++) {
+            sp += pt[i];
+            const double temp = multi ? mmnum::probit(min(max(pt[i], 0.000000001), 0.999999999)) : numeric_limits<double>::infinity();
+            s1 += temp;
+            s2 += temp * temp;
+        }
+        meanprop = sp / trace_length;
+        sdprobit = sqrt((s2 - s1 * s1 / trace_length) / (trace_length - 1.0));
+        meanprobit = s1 / trace_length;
+    };
+    vector<double> meanprop(n), meanprobitprop(n), sdprobitprop(n);
+#pragma omp parallel for schedule(static)
+    for (int64_t t = 0; t < (int64_t)n; t++) {
+        const bool multi = gene2transcripts.find(transcript2gene.find(sid((uint32_t)t))->second)->second.size() > 1;
+        prop_summary(&prop_trace[(size_t)t * trace_length], multi, meanprop[t], meanprobitprop[t], sdprobitprop[t]);
+    }
+    map<string, double> meanprop_simu, meanprobitprop_simu, sdprobitprop_simu;
+    for (auto &s : prop_trace_simu) {
+        const bool multi = gene2transcripts[transcript2gene[s.first]].size() > 1;
+        prop_summary(s.second.data(), multi, meanprop_simu[s.first], meanprobitprop_simu[s.first], sdprobitprop_simu[s.first]);
+    }
+
+    // ---- sd, mcse, iact via Sokal (src/mmseq.cpp:1307-1363)
+    auto sokal_summary = [&](const vector<double> &tr, size_t count, vector<double> &sd, vector<double> &mcse, vector<double> &iact) {
+        sd.resize(count); mcse.resize(count); iact.resize(count);
+#pragma omp parallel for schedule(static)
+        for (int64_t t = 0; t < (int64_t)count; t++) {
+            double var = 0, tau = 0;
+            int mm = 0;
+            if (mmnum::sokal_iact(&tr[(size_t)t * trace_length], trace_length, &var, &tau, &mm) != 0) {
+                mcse[t] = trace_length;
+                iact[t] = NAN;
+            } else {
+                mcse[t] = sqrt(tau * var / trace_length);
+                iact[t] = tau;
+            }
+            sd[t] = sqrt(var);
+        }
+    };
+    vector<double> sd, mumcse, iact, sd_identical, mumcse_identical, iact_identical, sd_gene, mumcse_gene, iact_gene;
+    sokal_summary(mu_trace, n, sd, mumcse, iact);
+    sokal_summary(mu_trace_identical, nI, sd_identical, mumcse_identical, iact_identical);
+    sokal_summary(mu_trace_gene, nG, sd_gene, mumcse_gene, iact_gene);
+
+    const double digalpha = mmnum::digamma(alpha);                 // gsl_sf_psi(alpha)        :1372
+    const double sqrtpolygalpha = sqrt(mmnum::trigamma(alpha));    // sqrt(gsl_sf_psi_n(1,.))  :1373
+    auto prior_logmu = [&](const string &name) { return digalpha - log(beta + sidLen[name] * (double)numbermappedreads / 1000000000.0); };
+
+    // ---- gene-level expression-weighted effective length (src/mmseq.cpp:1375-1395)
+    vector<double> gene_lengths(nG, 0.0);
+    {
+        size_t g = 0;
+        for (auto &gt : gene2transcripts) {
+            if (isfinite(meanmu_gene[g]) != 0) {
+                double sum = 0;
+                for (auto &name : gt.second) {
+                    const int32_t t = obs_of(name);
+                    const double e = t >= 0 ? exp(meanmu[t]) : exp(prior_logmu(name));
+                    gene_lengths[g] += sidLen[name] * e;
+                    sum += e;
+                }
+                gene_lengths[g] /= sum;
+            }
+            g++;
+        }
+    }
+
+    auto join_pct = [&](ostream &o, const vector<double> &v, const char *term) {
+        for (size_t i = 0; i < nP; i++) { o << v[i]; o << (i == nP - 1 ? term : ","); }
+    };
+    auto pct_header = [&](ostream &o, const char *label, const char *term) {
+        o << label;
+        for (size_t i = 0; i < nP; i++) { o << percentiles[i]; o << (i == nP - 1 ? term : ","); }
+    };
+
+    // ---- .mmseq (src/mmseq.cpp:1469-1554)
+    ofs.open((output_base + ".mmseq").c_str());
+    ofs << "# Mapped fragments: " << numbermappedreads << endl;
+    ofs << "feature_id\tlog_mu\tsd\tmcse\tiact\teffective_length\ttrue_length\tunique_hits\tmean_proportion\tmean_probit_proportion\tsd_"
+           "probit_proportion\tlog_mu_em\tobserved\tntranscripts\t";
+    pct_header(ofs, "percentiles", "\t");
+    pct_header(ofs, "percentiles_proportion", "\n");
+    for (auto &name : transcriptList) {
+        const int32_t t = obs_of(name);
+        if (t >= 0) {
+            ofs << name << "\t" << meanmu[t] << "\t" << sd[t] << "\t" << mumcse[t] << "\t" << iact[t] << "\t" << sidLen[name] << "\t"
+                << sidSeqLen[name] << "\t" << counts_shared[t][0] << "\t" << meanprop[t] << "\t" << meanprobitprop[t] << "\t"
+                << sdprobitprop[t] << "\t" << log(mu_em[t]) << "\t"
+                << "1"
+                << "\t" << gene2transcripts[transcript2gene[name]].size() << "\t";
+            join_pct(ofs, percentiles_transcript[t], "\t");
+            join_pct(ofs, percentiles_prop[t], "\n");
+        } else {
+            ofs << name << "\t" << prior_logmu(name) << "\t" << sqrtpolygalpha << "\t"
+                << "0"
+                << "\t"
+                << "1"
+                << "\t" << sidLen[name] << "\t" << sidSeqLen[name] << "\t" << 0 << "\t" << meanprop_simu[name] << "\t"
+                << meanprobitprop_simu[name] << "\t" << sdprobitprop_simu[name] << "\t"
+                << "NA"
+                << "\t"
+                << "0"
+                << "\t" << gene2transcripts[transcript2gene[name]].size() << "\t";
+            join_pct(ofs, percentiles_simu[name], "\t");
+            join_pct(ofs, percentiles_prop_simu[name], "\n");
+        }
+    }
+    ofs.close(); ofs.clear();
+
+    // ---- .identical.mmseq (src/mmseq.cpp:1556-1613)
+    ofs.open((output_base + ".identical.mmseq").c_str());
+    ofs << "# Mapped fragments: " << numbermappedreads << endl;
+    ofs << "feature_id\tlog_mu\tsd\tmcse\tiact\teffective_length\ttrue_length\tunique_hits\tobserved\tntranscripts\t";
+    pct_header(ofs, "percentiles", "\n");
+    for (size_t v = 0; v < nI; ++v) {
+        const vector<string> &set = identical_transcripts[v];
+        const bool fin = isfinite(meanmu_identical[v]);
+        for (auto &name : set) {
+            ofs << name;
+            if (name.compare(set.back()) != 0) ofs << "+";
+            else if (fin)
+                ofs << "\t" << meanmu_identical[v] << "\t" << sd_identical[v] << "\t" << mumcse_identical[v] << "\t" << iact_identical[v] << "\t"
+                    << sidLen[set.front()] << "\t" << sidSeqLen[set.front()] << "\t" << identical_unique_hits[v] << "\t"
+                    << "1"
+                    << "\t" << set.size() << "\t";
+            else
+                ofs << "\t" << log((double)set.size()) + prior_logmu(name) << "\t" << sqrtpolygalpha << "\t"
+                    << "0"
+                    << "\t"
+                    << "NA"
+                    << "\t" << sidLen[set.front()] << "\t" << sidSeqLen[set.front()] << "\t" << 0 << "\t"
+                    << "0"
+                    << "\t" << set.size() << "\t";
+        }
+        if (fin) join_pct(ofs, percentiles_identical[v], "\n");
+        else for (size_t i = 0; i < nP; i++) ofs << "NA" << (i == nP - 1 ? "\n" : ",");
+    }
+    ofs.close(); ofs.clear();
+
+    // ---- .gene.mmseq (src/mmseq.cpp:1615-1669)
+    ofs.open((output_base + ".gene.mmseq").c_str());
+    ofs << "# Mapped fragments: " << numbermappedreads << endl;
+    ofs << "feature_id\tlog_mu\tsd\tmcse\tiact\teffective_length\ttrue_length\tunique_hits\tntranscripts\tobserved\t";
+    pct_header(ofs, "percentiles", "\n");
+    {
+        size_t g = 0;
+        for (auto &gt : gene2transcripts) {
+            bool obs = false;
+            for (auto &name : gt.second) if (obs_of(name) >= 0) { obs = true; break; }
+            if (obs) {
+                ofs << gt.first << "\t" << meanmu_gene[g] << "\t" << sd_gene[g] << "\t" << mumcse_gene[g] << "\t" << iact_gene[g] << "\t"
+                    << gene_lengths[g] << "\t"
+                    << "NA"
+                    << "\t" << gene_unique_hits[g] << "\t" << gt.second.size() << "\t"
+                    << "1"
+                    << "\t";
+            } else {
+                ofs << gt.first << "\t" << meanmu_gene[g] << "\t" << sd_gene[g] << "\t" << sd_gene[g] / sqrt(trace_length) << "\t" << 1 << "\t"
+                    << gene_lengths[g] << "\t"
+                    << "NA"
+                    << "\t"
+                    << "0"
+                    << "\t" << gt.second.size() << "\t"
+                    << "0"
+                    << "\t";
+            }
+            join_pct(ofs, percentiles_gene[g], "\n");
+            g++;
+        }
+    }
+    ofs.close(); ofs.clear();
+
+    cout << "done." << endl;
+    cout << "Output files: " << endl
+         << "  " << output_base << ".mmseq" << endl
+         << "  " << output_base << ".identical.mmseq" << endl
+         << "  " << output_base << ".gene.mmseq" << endl;
+    cout << "  " << output_base << ".M" << endl << "  " << output_base << ".k" << endl << endl;
+    cout << "  " << output_base << ".trace_gibbs.gz" << endl
+         << "  " << output_base << ".identical.trace_gibbs.gz" << endl
+         << "  " << output_base << ".gene.trace_gibbs.gz" << endl
+         << "  " << output_base << ".prop.trace_gibbs.gz" << endl
+         << endl;
+    if (debug) {
+        cout << endl
+             << "  " << output_base << ".trace_em.gz" << endl
+             << "  " << output_base << ".sharedcounts" << endl
+             << "  " << output_base << ".Mt-nodups" << endl
+             << "  " << output_base << ".doublehits" << endl
+             << "  " << output_base << ".dupIDs" << endl;
+    }
+    return 0;
+}

@@ -99,6 +99,8 @@ struct mmg_problem {
     uint32_t *d_k = nullptr;
     double *d_l = nullptr;
     TileDesc *d_tiles = nullptr;
+    uint64_t *d_col_ptr = nullptr; // CSC transpose for the deterministic EM (lazy)
+    uint32_t *d_row_of = nullptr;
     uint64_t *d_chunk_tile = nullptr;
     uint64_t n_chunks = 0;
     int grid_sample = 1;
@@ -116,6 +118,8 @@ static void problem_free(mmg_problem *p)
     if (p->d_k) (void)hipFree(p->d_k);
     if (p->d_l) (void)hipFree(p->d_l);
     if (p->d_tiles) (void)hipFree(p->d_tiles);
+    if (p->d_col_ptr) (void)hipFree(p->d_col_ptr);
+    if (p->d_row_of) (void)hipFree(p->d_row_of);
     if (p->d_chunk_tile) (void)hipFree(p->d_chunk_tile);
     delete p;
 }
@@ -430,51 +434,82 @@ extern "C" int mmg_problem_start_values(const mmg_problem *p, double *mu0, int32
     return rc;
 }
 
-extern "C" int mmg_problem_em(const mmg_problem *p, double *mu, int max_iter, double epsilon, int *iters, double *loglik)
+// CSC transpose (rows ascending within a column), built on the host from the resident CSR on first use
+static int problem_build_csc(mmg_problem *p)
 {
-    if (!p || !mu) return fail(MMG_ERR_ARG, "NULL argument");
-    HIP_TRY(hipSetDevice(p->device));
-    double *d_mu = nullptr, *d_acc = nullptr, *d_ll = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_mu, p->n * sizeof(double)));
-    if (hipMalloc((void **)&d_acc, p->n * sizeof(double)) != hipSuccess || hipMalloc((void **)&d_ll, sizeof(double)) != hipSuccess) {
-        (void)hipFree(d_mu); if (d_acc) (void)hipFree(d_acc);
-        return fail(MMG_ERR_HIP, "hipMalloc");
+    if (p->d_col_ptr) return MMG_OK;
+    if (p->m >= 0xffffffffull) return fail(MMG_ERR_ARG, "EM needs fewer than 2^32 rows per device");
+    std::vector<uint64_t> rp(p->m + 1);
+    std::vector<uint32_t> ci(p->nnz);
+    int rc = mmg_problem_download(p, rp.data(), ci.data());
+    if (rc) return rc;
+    std::vector<uint64_t> cp((size_t)p->n + 1, 0);
+    for (uint64_t j = 0; j < p->nnz; ++j) cp[(size_t)ci[j] + 1]++;
+    for (uint32_t t = 0; t < p->n; ++t) cp[t + 1] += cp[t];
+    std::vector<uint32_t> rows(p->nnz);
+    {
+        std::vector<uint64_t> cur(cp.begin(), cp.end() - 1);
+        for (uint64_t r = 0; r < p->m; ++r)
+            for (uint64_t j = rp[r]; j < rp[r + 1]; ++j) rows[cur[ci[j]]++] = (uint32_t)r;
     }
-    int rc = MMG_OK, it = 0;
-    double ll_prev = 0.0;
+    HIP_TRY(hipMalloc((void **)&p->d_col_ptr, cp.size() * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc((void **)&p->d_row_of, std::max<uint64_t>(p->nnz, 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(p->d_col_ptr, cp.data(), cp.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    if (p->nnz) HIP_TRY(hipMemcpy(p->d_row_of, rows.data(), p->nnz * sizeof(uint32_t), hipMemcpyHostToDevice));
+    p->device_bytes += cp.size() * 8 + p->nnz * 4;
+    return MMG_OK;
+}
+
+extern "C" int mmg_problem_em(const mmg_problem *cp, double *mu, int max_iter, double epsilon, int *iters, double *loglik)
+{
+    if (!cp || !mu) return fail(MMG_ERR_ARG, "NULL argument");
+    mmg_problem *p = const_cast<mmg_problem *>(cp); // the lazily built transpose is a cache
+    HIP_TRY(hipSetDevice(p->device));
+    int rc = problem_build_csc(p);
+    if (rc) return rc;
     const unsigned gr = (unsigned)std::max<uint64_t>((p->m + 255) / 256, 1), gc = (p->n + 255) / 256;
+    double *d_mu = nullptr, *d_q = nullptr, *d_pr = nullptr, *d_pc = nullptr, *d_ll = nullptr;
+    auto cleanup = [&]() { for (double *x : {d_mu, d_q, d_pr, d_pc, d_ll}) if (x) (void)hipFree(x); };
+#define EM_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail(MMG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
+    EM_TRY(hipMalloc((void **)&d_mu, p->n * sizeof(double)));
+    EM_TRY(hipMalloc((void **)&d_q, std::max<uint64_t>(p->m, 1) * sizeof(double)));
+    EM_TRY(hipMalloc((void **)&d_pr, gr * sizeof(double)));
+    EM_TRY(hipMalloc((void **)&d_pc, gc * sizeof(double)));
+    EM_TRY(hipMalloc((void **)&d_ll, sizeof(double)));
+    EM_TRY(hipMemcpy(d_mu, mu, p->n * sizeof(double), hipMemcpyHostToDevice));
     auto rows_pass = [&]() {
-        if (p->idx64) hipLaunchKernelGGL(k_em_rows<uint64_t>, dim3(gr), dim3(256), 0, 0, (const uint64_t *)p->d_row_ptr, p->d_col, p->d_k, p->m, d_mu, d_acc, d_ll);
-        else hipLaunchKernelGGL(k_em_rows<uint32_t>, dim3(gr), dim3(256), 0, 0, (const uint32_t *)p->d_row_ptr, p->d_col, p->d_k, p->m, d_mu, d_acc, d_ll);
+        if (p->idx64) hipLaunchKernelGGL(k_em_rows<uint64_t>, dim3(gr), dim3(256), 0, 0, (const uint64_t *)p->d_row_ptr, p->d_col, p->d_k, p->m, d_mu, d_q, d_pr);
+        else hipLaunchKernelGGL(k_em_rows<uint32_t>, dim3(gr), dim3(256), 0, 0, (const uint32_t *)p->d_row_ptr, p->d_col, p->d_k, p->m, d_mu, d_q, d_pr);
     };
-    do {
-#define EM_TRY(expr) if ((expr) != hipSuccess) { rc = fail(MMG_ERR_HIP, #expr); break; }
-        EM_TRY(hipMemcpy(d_mu, mu, p->n * sizeof(double), hipMemcpyHostToDevice));
-        EM_TRY(hipMemset(d_acc, 0, p->n * sizeof(double)));
-        EM_TRY(hipMemset(d_ll, 0, sizeof(double)));
-        rows_pass();
-        hipLaunchKernelGGL(k_em_cols, dim3(gc), dim3(256), 0, 0, d_mu, d_acc, p->d_l, p->n, d_ll, 0);
-        EM_TRY(hipMemcpy(&ll_prev, d_ll, sizeof(double), hipMemcpyDeviceToHost));
-        double llr = epsilon + 1.0;
-        bool err = false;
-        while (it < max_iter && llr > epsilon) {
-            if (hipMemset(d_ll, 0, sizeof(double)) != hipSuccess) { err = true; break; }
-            hipLaunchKernelGGL(k_em_cols, dim3(gc), dim3(256), 0, 0, d_mu, d_acc, p->d_l, p->n, d_ll, 1);
-            rows_pass();
-            double ll = 0.0;
-            if (hipMemcpy(&ll, d_ll, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { err = true; break; }
-            llr = ll - ll_prev;
-            ll_prev = ll;
-            ++it;
-        }
-        if (err) { rc = fail(MMG_ERR_HIP, "EM sweep failed"); break; }
-        EM_TRY(hipMemcpy(mu, d_mu, p->n * sizeof(double), hipMemcpyDeviceToHost));
+    auto cols_pass = [&](int apply) {
+        hipLaunchKernelGGL(k_em_cols, dim3(gc), dim3(256), 0, 0, p->d_col_ptr, p->d_row_of, d_q, d_mu, p->d_l, p->n, d_pc, apply);
+    };
+    auto read_ll = [&](double &ll) -> hipError_t {
+        hipLaunchKernelGGL(k_em_finish, dim3(1), dim3(1), 0, 0, d_pr, gr, d_pc, gc, d_ll);
+        return hipMemcpy(&ll, d_ll, sizeof(double), hipMemcpyDeviceToHost);
+    };
+    // log-likelihood of the start value (src/mmseq.cpp:745-754)
+    double ll_prev = 0.0;
+    rows_pass();
+    cols_pass(0);
+    EM_TRY(read_ll(ll_prev));
+    double llr = __builtin_huge_val(); // the reference starts from epsilon+1 (src/mmseq.cpp:756): first sweep always runs
+    int it = 0;
+    while (it < max_iter && llr > epsilon) {
+        cols_pass(1); // uses q of the current mu, leaves the new mu and its penalty
+        rows_pass();  // q and log-likelihood part of the new mu
+        double ll = 0.0;
+        EM_TRY(read_ll(ll));
+        llr = ll - ll_prev;
+        ll_prev = ll;
+        ++it;
+    }
+    EM_TRY(hipMemcpy(mu, d_mu, p->n * sizeof(double), hipMemcpyDeviceToHost));
 #undef EM_TRY
-    } while (0);
-    (void)hipFree(d_mu); (void)hipFree(d_acc); (void)hipFree(d_ll);
+    cleanup();
     if (iters) *iters = it;
     if (loglik) *loglik = ll_prev;
-    return rc;
+    return MMG_OK;
 }
 
 extern "C" void mmg_problem_destroy(mmg_problem *p) { problem_free(p); }
@@ -798,6 +833,16 @@ extern "C" int mmg_sampler_reset_timing(mmg_sampler *s)
 }
 
 extern "C" void mmg_sampler_destroy(mmg_sampler *s) { sampler_free(s); }
+
+extern "C" int mmg_host_gamma_trace(uint64_t seed, uint64_t id, double shape, double scale, int n, double *out)
+{
+    if (n < 0 || !out || !(shape > 0.0)) return fail(MMG_ERR_ARG, "bad argument");
+    for (int i = 0; i < n; ++i) {
+        Stream s(seed, 0, TAG_SIMU, id, (uint32_t)i);
+        out[i] = gamma_unit(s, shape) * scale;
+    }
+    return MMG_OK;
+}
 
 // ------------------------------------------------------------------------------ self tests
 extern "C" int mmg_selftest_math(int device, int64_t n, const double *x, double *ol, double *oe, double *os, double *orc)

@@ -39,6 +39,7 @@ def lib():
     L.orc_gamma_draw.restype = C.c_double
     L.orc_binomial_keyed.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_double]
     L.orc_binomial_keyed.restype = C.c_uint32
+    L.orc_simu_gamma_trace.argtypes = [C.c_uint64, C.c_uint64, C.c_double, C.c_double, C.c_int, f64p]
     L.orc_sample_counts.argtypes = [C.c_uint64, C.c_uint32, u64p, u32p, C.c_void_p, f64p, C.c_uint64,
                                     C.c_uint32, C.c_uint32, C.c_uint64, i32p]
     L.orc_gamma_update.argtypes = [C.c_uint32, i32p, f64p, C.c_double, C.c_double, C.c_uint64, C.c_uint32,
@@ -106,6 +107,12 @@ def exp_v(x):
 def mt19937(seed, n):
     out = np.empty(n, np.uint32)
     lib().orc_mt19937(seed, n, out)
+    return out
+
+
+def simu_gamma_trace(seed, sid, shape, scale, n):
+    out = np.empty(n, np.float64)
+    lib().orc_simu_gamma_trace(seed, sid, shape, scale, n, out)
     return out
 
 

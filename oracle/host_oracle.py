@@ -237,3 +237,140 @@ def digamma(x):
 def trigamma(x):
     from scipy.special import polygamma
     return float(polygamma(1, x))
+
+
+# ------------------------------------------------------------------------------------ full pipeline
+def expected_run(h, alpha=0.1, beta=0.1, seed=1234, gibbs_iter=1024, max_em_iter=1000, epsilon=0.1,
+                 percentiles=(5.0, 25.0, 50.0, 75.0, 95.0), trace_len=1024):
+    """What `mmseq hits out` must produce for hits data `h` (numbers, not text): restates
+    src/mmseq.cpp:395-1669 with the keyed-stream chain of oracle/mmseq_oracle.c in the device row order."""
+    from . import binding as B
+    g = ingest(h)
+    n, rows, k = len(g["index_sid"]), g["rows"], g["k"]
+    N = g["mapped"]
+    sid = g["index_sid"]
+    l = np.array([h.efflen[s] * float(N) / 1e9 for s in sid])
+    order = device_row_order(rows)
+    d_rows = [rows[i] for i in order]
+    rp = np.cumsum([0] + [len(r) for r in d_rows]).astype(np.uint64)
+    ci = np.array([c for r in d_rows for c in r], np.uint32)
+    p = B.Problem(rp, ci, l, k=k[order].astype(np.uint32))
+    # start values in FIRST-SEEN row order on the host (deterministic), src/mmseq.cpp:617-638
+    mu0 = np.zeros(n)
+    uh = np.zeros(n, np.int64)
+    for r, kk in zip(rows, k):
+        for c in r:
+            mu0[c] += float(kk) / len(r)
+        if len(r) == 1:
+            uh[r[0]] += kk
+    mu0 /= l
+    mu_em, em_iters, ll = B.em(p, mu0, max_iter=max_em_iter, epsilon=epsilon)
+    chain = B.gibbs_keyed(p, mu_em, alpha=alpha, beta=beta, seed=seed, n_iter=gibbs_iter, trace_len=trace_len)
+    trace = chain["trace"]                                   # [n, trace_len], real scale
+    hdr_index = {name: i for i, name in enumerate(h.names)}
+    genes = list(h.genes.items())
+    # identical / gene sums, simulated traces for isoforms without hits (:927-1008)
+    t_ident = np.zeros((len(h.identical), trace_len))
+    for v, s in enumerate(h.identical):
+        for name in s:
+            if name in g["sid_index"]:
+                t_ident[v] += trace[g["sid_index"][name]]
+    t_gene = np.zeros((len(genes), trace_len))
+    simu = {}
+    for gi, (gid, ts) in enumerate(genes):
+        for name in ts:
+            if name in g["sid_index"]:
+                t_gene[gi] += trace[g["sid_index"][name]]
+            else:
+                simu[name] = B.simu_gamma_trace(seed, hdr_index[name], alpha, 1.0 / (beta + h.efflen[name] * float(N) / 1e9), trace_len)
+                t_gene[gi] += simu[name]
+    gene_of = {name: gi for gi, (gid, ts) in enumerate(genes) for name in ts}
+    prop = np.full((n, trace_len), np.nan)
+    prop_simu = {}
+    for gi, (gid, ts) in enumerate(genes):
+        for name in ts:
+            if name in g["sid_index"]:
+                prop[g["sid_index"][name]] = trace[g["sid_index"][name]] / t_gene[gi]
+            else:
+                prop_simu[name] = simu[name] / t_gene[gi]
+    pind = percentile_indices(percentiles, trace_len)
+
+    def pct(tr):
+        s = np.sort(tr)
+        return [s[i] for i in pind]
+
+    def sok(logtr):
+        rc, var, tau, m = B.sokal(logtr)
+        if rc != 0:
+            return np.sqrt(var), float(trace_len), float("nan")
+        return np.sqrt(var), np.sqrt(tau * var / trace_len), tau
+
+    def prop_summ(pt, multi):
+        with np.errstate(invalid="ignore"):
+            if multi:
+                z = probit(np.minimum(np.maximum(pt, 1e-9), 1 - 1e-9))
+            else:
+                z = np.full(trace_len, np.inf)
+            s1, s2 = z.sum(), (z * z).sum()
+            return pt.mean(), s1 / trace_len, np.sqrt((s2 - s1 * s1 / trace_len) / (trace_len - 1.0))
+
+    dig, sqtri = digamma(alpha), math.sqrt(trigamma(alpha))
+    prior = lambda name: dig - math.log(beta + h.efflen[name] * float(N) / 1e9)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ltrace, lident, lgene = np.log(trace), np.log(t_ident), np.log(t_gene)
+    tx = []
+    for name in h.names:
+        ntx = len(h.genes[[gid for gid, ts in genes if name in ts][0]])
+        if name in g["sid_index"]:
+            t = g["sid_index"][name]
+            sd, mcse, iact = sok(ltrace[t])
+            mp, mpp, sdpp = prop_summ(prop[t], ntx > 1)
+            tx.append(dict(feature_id=name, log_mu=ltrace[t].mean(), sd=sd, mcse=mcse, iact=iact, effective_length=h.efflen[name],
+                           true_length=h.truelen[name], unique_hits=int(uh[t]), mean_proportion=mp, mean_probit_proportion=mpp,
+                           sd_probit_proportion=sdpp, log_mu_em=math.log(mu_em[t]) if mu_em[t] > 0 else -math.inf, observed=1,
+                           ntranscripts=ntx, percentiles=pct(trace[t]), percentiles_proportion=pct(prop[t])))
+        else:
+            mp, mpp, sdpp = prop_summ(prop_simu[name], ntx > 1)
+            tx.append(dict(feature_id=name, log_mu=prior(name), sd=sqtri, mcse=0.0, iact=1.0, effective_length=h.efflen[name],
+                           true_length=h.truelen[name], unique_hits=0, mean_proportion=mp, mean_probit_proportion=mpp,
+                           sd_probit_proportion=sdpp, log_mu_em="NA", observed=0, ntranscripts=ntx,
+                           percentiles=pct(simu[name]), percentiles_proportion=pct(prop_simu[name])))
+    # unique hits to groups: src/uh.cpp literal semantics via the C oracle
+    pf = B.Problem(np.cumsum([0] + [len(r) for r in rows]).astype(np.uint64), np.array([c for r in rows for c in r], np.uint32), l,
+                   k=k.astype(np.uint32))
+    mem_i = np.zeros((n, max(len(h.identical), 1)), np.uint8)
+    for v, s in enumerate(h.identical):
+        for name in s:
+            if name in g["sid_index"]:
+                mem_i[g["sid_index"][name], v] = 1
+    mem_g = np.zeros((n, len(genes)), np.uint8)
+    for gi, (gid, ts) in enumerate(genes):
+        for name in ts:
+            if name in g["sid_index"]:
+                mem_g[g["sid_index"][name], gi] = 1
+    uh_i = B.uh(pf, mem_i) if h.identical else []
+    uh_g = B.uh(pf, mem_g)
+    ident = []
+    for v, s in enumerate(h.identical):
+        fid = "+".join(s)
+        m_ = lident[v].mean()
+        if np.isfinite(m_):
+            sd, mcse, iact = sok(lident[v])
+            ident.append(dict(feature_id=fid, log_mu=m_, sd=sd, mcse=mcse, iact=iact, effective_length=h.efflen[s[0]],
+                              true_length=h.truelen[s[0]], unique_hits=int(uh_i[v]), observed=1, ntranscripts=len(s),
+                              percentiles=pct(t_ident[v])))
+        else:
+            ident.append(dict(feature_id=fid, log_mu=math.log(len(s)) + prior(s[-1]), sd=sqtri, mcse=0.0, iact="NA",
+                              effective_length=h.efflen[s[0]], true_length=h.truelen[s[0]], unique_hits=0, observed=0,
+                              ntranscripts=len(s), percentiles=["NA"] * len(pind)))
+    gene = []
+    for gi, (gid, ts) in enumerate(genes):
+        sd, mcse, iact = sok(lgene[gi])
+        obs = any(name in g["sid_index"] for name in ts)
+        w = np.array([math.exp(ltrace[g["sid_index"][nm]].mean()) if nm in g["sid_index"] else math.exp(prior(nm)) for nm in ts])
+        glen = float((np.array([h.efflen[nm] for nm in ts]) * w).sum() / w.sum())
+        gene.append(dict(feature_id=gid, log_mu=lgene[gi].mean(), sd=sd, mcse=mcse if obs else sd / math.sqrt(trace_len),
+                         iact=iact if obs else 1.0, effective_length=glen, true_length="NA", unique_hits=int(uh_g[gi]) if obs else 0,
+                         ntranscripts=len(ts), observed=1 if obs else 0, percentiles=pct(t_gene[gi])))
+    return dict(ingest=g, rows=rows, k=k, mapped=N, l=l, mu0=mu0, mu_em=mu_em, em_iters=em_iters, trace=trace, t_ident=t_ident,
+                t_gene=t_gene, prop=prop, transcripts=tx, identical=ident, genes=gene, gene_ids=[gid for gid, _ in genes])

@@ -261,6 +261,15 @@ double orc_gamma_draw(uint64_t seed, uint32_t chain, uint32_t iter, uint64_t t, 
     return keyed_gamma_unit(&s, shape) * scale;
 }
 
+/* simulated trace of an isoform without hits (src/mmseq.cpp:971-978), keyed by (seed, SIMU, id, sample) */
+void orc_simu_gamma_trace(uint64_t seed, uint64_t id, double shape, double scale, int n, double *out)
+{
+    for (int i = 0; i < n; ++i) {
+        orc_stream s = stream_make(seed, 0, ORC_TAG_SIMU, id, (uint32_t)i);
+        out[i] = keyed_gamma_unit(&s, shape) * scale;
+    }
+}
+
 /* Stirling-series tail log(k!) - [ (k+1/2)log(k+1) - (k+1) + log(2pi)/2 ] */
 static inline double stirling_tail(double k)
 {
@@ -438,7 +447,10 @@ int orc_gibbs_keyed(uint64_t m, uint32_t n, const uint64_t *row_ptr, const uint3
     double *mu = (double *)malloc((size_t)n * sizeof(double));
     int nth = 1;
 #ifdef _OPENMP
+    /* threads only split the work (results do not depend on them): keep >= 4096 rows per thread, at most 32 */
     nth = omp_get_max_threads();
+    if (nth > 32) nth = 32;
+    if ((uint64_t)nth > m / 4096 + 1) nth = (int)(m / 4096 + 1);
 #endif
     int32_t *slabs = (int32_t *)malloc((size_t)n * nth * sizeof(int32_t));
     int32_t *cnt = (int32_t *)malloc((size_t)n * sizeof(int32_t));
@@ -447,7 +459,7 @@ int orc_gibbs_keyed(uint64_t m, uint32_t n, const uint64_t *row_ptr, const uint3
     if (sum_log2) memset(sum_log2, 0, (size_t)n * sizeof(double));
     for (int iter = 0; iter < n_iter; ++iter) {
         memset(slabs, 0, (size_t)n * nth * sizeof(int32_t));
-#pragma omp parallel
+#pragma omp parallel num_threads(nth)
         {
             int tid = 0;
 #ifdef _OPENMP
@@ -705,7 +717,7 @@ int orc_em(uint64_t m, uint32_t n, const uint64_t *row_ptr, const uint32_t *col_
         double s = 0.0;
         for (uint64_t j = row_ptr[i]; j < row_ptr[i + 1]; ++j) s += mu[col_idx[j]];
         d[i] = s;
-        loglik += (double)(k ? k[i] : 1u) * log(s);
+        loglik += (double)(k ? k[i] : 1u) * orc_log(s);
     }
     for (uint32_t t = 0; t < n; ++t) loglik -= mu[t] * l[t];
     double llr = epsilon + 1.0;
@@ -722,7 +734,7 @@ int orc_em(uint64_t m, uint32_t n, const uint64_t *row_ptr, const uint32_t *col_
             double s = 0.0;
             for (uint64_t j = row_ptr[i]; j < row_ptr[i + 1]; ++j) s += mu[col_idx[j]];
             d[i] = s;
-            ll += (double)(k ? k[i] : 1u) * log(s);
+            ll += (double)(k ? k[i] : 1u) * orc_log(s);
         }
         for (uint32_t t = 0; t < n; ++t) ll -= mu[t] * l[t];
         llr = ll - loglik;
@@ -916,7 +928,7 @@ void orc_synth_csr(uint64_t seed, uint64_t row0, uint64_t R, uint32_t T, const d
         row_ptr[r + 1] = row_ptr[r] + L;
     }
     if (!col_idx) return;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (R > 100000)
     for (int64_t r = 0; r < (int64_t)R; ++r) {
         uint32_t tmp[100];
         uint32_t L = orc_synth_row(seed, row0 + (uint64_t)r, T, cdf, len_cdf, uniform, tmp);

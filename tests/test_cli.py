@@ -1,0 +1,218 @@
+"""The `mmseq` drop-in CLI (mmseq_amd/csrc/host/mmseq_main.cpp).  CPU: flag surface, exit codes and
+error text of src/mmseq.cpp:156-299 and the loud failure without a device.  GPU (-m gpu): a full run on a
+small hits file compared, file by file, with the Python restatement of the pipeline (oracle.host_oracle)."""
+import gzip
+import math
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import host_oracle as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MMSEQ = os.path.join(ROOT, "mmseq_amd", "csrc", "mmseq")
+
+
+def run(args, **kw):
+    return subprocess.run([MMSEQ] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, **kw)
+
+
+def dataset(seed=3, n_t=60, n_reads=4000):
+    rng = np.random.default_rng(seed)
+    names = ["T%07d" % i for i in range(n_t)]
+    efflen = {n: float(rng.integers(200, 4000)) for n in names}
+    truelen = {n: int(efflen[n]) + 180 for n in names}
+    genes, i, g = {}, 0, 0
+    while i < n_t:
+        sz = int(1 + rng.poisson(1.5))
+        genes["G%06d" % g] = names[i:i + sz]
+        i += sz; g += 1
+    theta = np.exp(rng.normal(0, 1.5, n_t))
+    theta[rng.random(n_t) < 0.25] = 0.0            # unobserved transcripts (closed-form rows, simulated traces)
+    theta[40:44] = 0.0                               # a whole run of unobserved ones -> (likely) an unobserved gene
+    identical = [[names[5], names[6]], [names[41], names[42]]]   # one observed set, one never-hit set
+    theta[5] = theta[6] = 3.0
+    w = theta * np.array([efflen[n] for n in names])
+    w = w / w.sum()
+    reads = []
+    for r in range(n_reads):
+        t0 = int(rng.choice(n_t, p=w))
+        d = int(min(5, rng.poisson(1.2)))
+        cand = [t for t in range(max(0, t0 - 3), min(n_t, t0 + 4)) if t != t0 and theta[t] > 0]
+        extra = list(rng.choice(cand, min(d, len(cand)), replace=False)) if cand and d else []
+        ts = sorted(set([t0] + [int(x) for x in extra]))
+        if r % 97 == 0 and len(ts) > 1:
+            ts = ts + [ts[0]]                        # a within-read duplicate (doublehit, src/mmseq.cpp:404-409)
+        reads.append(("r%09d" % r, [names[t] for t in ts]))
+    return H.HitsData(names, efflen, truelen, genes, identical, reads)
+
+
+# ------------------------------------------------------------------------------------------ CPU
+def test_help_and_version_exit_1_on_stderr():
+    for flag in ("-help", "-h", "--help"):
+        r = run([flag])
+        assert r.returncode == 1 and b"Usage: mmseq [OPTIONS...] hits_file output_base" in r.stderr and r.stdout == b""
+    for flag in ("-version", "-v", "--version"):
+        r = run([flag])
+        assert r.returncode == 1 and r.stderr.startswith(b"mmseq-")
+
+
+def test_flag_validation_messages(tmp_path):
+    r = run(["-bogus", "a", "b"])
+    assert r.returncode == 1 and b"Error: unrecognised option -bogus." in r.stderr
+    r = run(["onlyone"])
+    assert r.returncode == 1 and b"Error: mandatory arguments missing." in r.stderr
+    r = run(["-gibbs_iter", "1000", "-gibbs_ss", "7", "a", "b"])
+    assert r.returncode == 1 and b"Error: gibbs_iter must be divisible by gibbs_ss." in r.stderr
+    r = run(["-percentiles", "5,120", "a", "b"])
+    assert r.returncode == 1 and b"Percentiles must be in (0,100)" in r.stderr
+    r = run(["-gibbs_iter", "1000", "-gibbs_ss", "10", "a", "b"])      # 1000 is not a multiple of 1024
+    assert r.returncode == 1 and b"gibbs_iter must be a positive multiple of 1024" in r.stderr
+    r = run([str(tmp_path / "nope.hits"), str(tmp_path / "out")])
+    assert r.returncode == 1 and b"Error reading hits file" in r.stderr
+
+
+def test_header_consistency_errors(tmp_path):
+    p = tmp_path / "h.hits"
+    p.write_bytes(b"@TranscriptMetaData\tA\t100\t280\n@TranscriptMetaData\tB\t100\t280\n@GeneIsoforms\tG1\tA\n>r\nA\n")
+    r = run([str(p), str(tmp_path / "o")])
+    assert r.returncode == 1 and b"Error: B does not belong to a gene in the @GeneIsoforms header entries." in r.stderr
+    p.write_bytes(b"@TranscriptMetaData\tA\t100\t280\n@GeneIsoforms\tG1\tA\n@GeneIsoforms\tG2\tA\n>r\nA\n")
+    r = run([str(p), str(tmp_path / "o")])
+    assert r.returncode == 1 and b"transcripts must be nested within genes" in r.stderr
+    p.write_bytes(b"@TranscriptMetaData\tA\t0\t280\n@GeneIsoforms\tG1\tA\n>r\nA\n")
+    r = run([str(p), str(tmp_path / "o")])
+    assert r.returncode == 1 and b"Error: transcript 'A' has a length of zero." in r.stderr
+
+
+def test_without_device_fails_loudly_after_writing_k_and_M(tmp_path):
+    from mmseq_amd import gibbs
+    if gibbs.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    h = dataset(n_reads=300)
+    p = tmp_path / "x.hits"
+    p.write_bytes(H.write_hits_text(h))
+    r = run([str(p), str(tmp_path / "out")])
+    assert r.returncode == 1 and b"no HIP device available" in r.stderr
+    g = H.ingest(h)
+    assert (tmp_path / "out.k").read_text().split() == [str(v) for v in g["k"]]     # src/mmseq.cpp:682-684
+    lines = (tmp_path / "out.M").read_text().split("\n")
+    assert lines[0] == "#" + "".join("\t" + s for s in g["index_sid"])               # :686-689
+    exp = ["%d\t%d" % (i, c) for i, r_ in enumerate(g["rows"]) for c in r_]
+    assert lines[1:-1] == exp
+    assert not (tmp_path / "out.mmseq").exists()
+
+
+# ------------------------------------------------------------------------------------------ GPU
+def _table(path):
+    lines = open(path).read().rstrip("\n").split("\n")
+    assert lines[0].startswith("# Mapped fragments: ")
+    hdr = lines[1].split("\t")
+    return int(lines[0].split(": ")[1]), hdr, [dict(zip(hdr, ln.split("\t"))) for ln in lines[2:]]
+
+
+def _same_number(txt, val, rel=2e-5):
+    if isinstance(val, str):
+        return txt == val
+    if isinstance(val, (int, np.integer)):
+        return txt == str(int(val))
+    val = float(val)
+    if math.isnan(val):
+        return "nan" in txt
+    if math.isinf(val):
+        return txt in ("inf", "-inf") and (txt[0] == "-") == (val < 0)
+    got = float(txt)
+    return abs(got - val) <= rel * max(abs(val), 1e-300) + 1e-12
+
+
+def _trace_file(path):
+    with gzip.open(path, "rt") as f:
+        lines = f.read().split("\n")
+    return lines[0].split(" ")[:-1], [ln.split(" ")[:-1] for ln in lines[1:-1]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["text", "binary"])
+def test_full_run_matches_python_pipeline(tmp_path, fmt, gpu):
+    h = dataset()
+    p = tmp_path / "in.hits"
+    p.write_bytes(H.write_hits_text(h) if fmt == "text" else H.write_hits_binary(h))
+    out = str(tmp_path / "out")
+    r = run(["-gibbs_iter", "2048", "-seed", "77", "-debug", str(p), out], timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    e = H.expected_run(h, seed=77, gibbs_iter=2048)
+    g = e["ingest"]
+    # .k / .M : exact
+    assert open(out + ".k").read().split() == [str(v) for v in e["k"]]
+    mlines = open(out + ".M").read().split("\n")
+    assert mlines[0] == "#" + "".join("\t" + s for s in g["index_sid"])
+    assert mlines[1:-1] == ["%d\t%d" % (i, c) for i, row in enumerate(e["rows"]) for c in row]
+    assert open(out + ".doublehits").read().split() == [str(v) for v in g["doublehits"]]
+    # the Gibbs trace: every printed value equals the oracle chain's value printed the same way
+    ids, rows = _trace_file(out + ".trace_gibbs.gz")
+    assert ids == g["index_sid"] and len(rows) == 1024
+    exp_rows = [[H.fmt6(v) for v in e["trace"][:, s]] for s in range(1024)]
+    assert rows == exp_rows
+    ids, rows = _trace_file(out + ".gene.trace_gibbs.gz")
+    keepg = [i for i in range(len(e["gene_ids"])) if np.isfinite(np.log(e["t_gene"][i, 0]))]
+    assert ids == [e["gene_ids"][i] for i in keepg]
+    assert rows[0] == [H.fmt6(e["t_gene"][i, 0]) for i in keepg] and rows[-1] == [H.fmt6(e["t_gene"][i, -1]) for i in keepg]
+    ids, rows = _trace_file(out + ".prop.trace_gibbs.gz")
+    assert ids == g["index_sid"] and rows[7] == [H.fmt6(v) for v in e["prop"][:, 7]]
+    ids, rows = _trace_file(out + ".identical.trace_gibbs.gz")
+    assert ids == ["+".join(h.identical[0])] and rows[3] == [H.fmt6(e["t_ident"][0, 3])]
+    # the three tables
+    mapped, hdr, tab = _table(out + ".mmseq")
+    assert mapped == e["mapped"]
+    assert hdr == ["feature_id", "log_mu", "sd", "mcse", "iact", "effective_length", "true_length", "unique_hits", "mean_proportion",
+                   "mean_probit_proportion", "sd_probit_proportion", "log_mu_em", "observed", "ntranscripts",
+                   "percentiles5,25,50,75,95", "percentiles_proportion5,25,50,75,95"]
+    assert [t["feature_id"] for t in tab] == h.names                      # header-transcript order (src/mmseq.cpp:1491)
+    n_unobs = 0
+    for got, exp in zip(tab, e["transcripts"]):
+        for col in hdr[1:14]:
+            assert _same_number(got[col], exp[col]), (got["feature_id"], col, got[col], exp[col])
+        for a, b in zip(got[hdr[14]].split(","), exp["percentiles"]):
+            assert _same_number(a, b)
+        for a, b in zip(got[hdr[15]].split(","), exp["percentiles_proportion"]):
+            assert _same_number(a, b)
+        n_unobs += exp["observed"] == 0
+    assert n_unobs >= 5
+    unobs = [t for t in tab if t["observed"] == "0"][0]
+    assert unobs["sd"] == "10.0714" and unobs["mcse"] == "0" and unobs["iact"] == "1" and unobs["log_mu_em"] == "NA"
+    mapped, hdr, tab = _table(out + ".identical.mmseq")
+    assert hdr[:10] == ["feature_id", "log_mu", "sd", "mcse", "iact", "effective_length", "true_length", "unique_hits", "observed",
+                        "ntranscripts"]
+    for got, exp in zip(tab, e["identical"]):
+        assert got["feature_id"] == exp["feature_id"]
+        for col in hdr[1:10]:
+            assert _same_number(got[col], exp[col]), (got["feature_id"], col, got[col], exp[col])
+        for a, b in zip(got[hdr[10]].split(","), exp["percentiles"]):
+            assert _same_number(a, b)
+    assert tab[1]["observed"] == "0" and tab[1]["iact"] == "NA" and tab[1][hdr[10]] == "NA,NA,NA,NA,NA"
+    mapped, hdr, tab = _table(out + ".gene.mmseq")
+    assert hdr[:10] == ["feature_id", "log_mu", "sd", "mcse", "iact", "effective_length", "true_length", "unique_hits", "ntranscripts",
+                        "observed"]
+    assert [t["feature_id"] for t in tab] == e["gene_ids"]                 # std::map order (src/mmseq.cpp:1630)
+    for got, exp in zip(tab, e["genes"]):
+        for col in hdr[1:10]:
+            assert _same_number(got[col], exp[col]), (got["feature_id"], col, got[col], exp[col])
+    assert any(t["observed"] == "0" for t in tab)
+    # EM trace (debug): first line = start values, one line per EM iteration
+    ids, rows = _trace_file(out + ".trace_em.gz")
+    assert len(rows) == e["em_iters"] and rows[0] == [H.fmt6(v) for v in e["mu0"]]
+
+
+@pytest.mark.gpu
+def test_runs_are_reproducible(tmp_path, gpu):
+    h = dataset(seed=8, n_reads=1500)
+    p = tmp_path / "in.hits"
+    p.write_bytes(H.write_hits_binary(h))
+    outs = []
+    for i in range(2):
+        out = str(tmp_path / ("o%d" % i))
+        assert run([str(p), out, ], timeout=300, env=dict(os.environ, OMP_NUM_THREADS=str(1 + 3 * i))).returncode == 0
+        outs.append(open(out + ".mmseq").read() + gzip.open(out + ".trace_gibbs.gz", "rt").read())
+    assert outs[0] == outs[1]          # independent of host thread count and of run (cf. src/mmseq.cpp:834-838)
