@@ -84,11 +84,28 @@ SYMBOLS = {
 }
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  Two HIP runtimes in
+    one process cannot both own the GPU, so when torch is installed its copy is loaded first and
+    libmmgibbs.so binds to it by SONAME; a later `import torch` then reuses the same object."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass  # no torch (or an unusual layout): the system HIP runtime is used
+
+
 def load():
     """Load libmmgibbs.so and bind every declared symbol; raises if anything is missing."""
     global _lib
     if _lib is not None:
         return _lib
+    _share_hip_runtime_with_torch()
     if not os.path.exists(LIB_PATH):
         raise OSError("libmmgibbs.so not built at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                       "(there is no CPU fallback)" % LIB_PATH)

@@ -720,7 +720,7 @@ int orc_em(uint64_t m, uint32_t n, const uint64_t *row_ptr, const uint32_t *col_
         loglik += (double)(k ? k[i] : 1u) * orc_log(s);
     }
     for (uint32_t t = 0; t < n; ++t) loglik -= mu[t] * l[t];
-    double llr = epsilon + 1.0;
+    double llr = INFINITY; /* the reference starts from epsilon+1 (src/mmseq.cpp:756): first sweep always runs */
     int iter = 0;
     while (iter < max_iter && llr > epsilon) {
         memset(acc, 0, (size_t)n * sizeof(double));
