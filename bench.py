@@ -22,6 +22,20 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+def pmc_traffic(args, chains):
+    """HBM bytes per K1 launch from the committed rocprofv3 PMC pass of this same workload (profiles/pmc_traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH doubled per the gfx950 correction).  PMC counters
+    cannot be collected from inside this process, so the figure is null for any other workload."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        w = d["workload"]
+        if (w["rows"], w["transcripts"], w["avg_hits"], w["chains"]) == (args.rows, args.transcripts, args.avg_hits, chains):
+            return d["hbm_read_bytes_per_launch"] + d["hbm_write_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(args, total_reads):
     """Oracle ("port" of src/mmseq.cpp:851-918, reference-structured: per-thread MT19937, count slabs,
     conditional-binomial multinomial) timed on this host's cores on a bounded sample of the same workload."""
@@ -175,7 +189,7 @@ def main():
                        "trace": "every iteration kept (fp64 mu trace resident in HBM)", "generator_seed": args.seed},
             "reads_iters_per_sec": iters_per_s * reads_per_chain,
             "roofline": {"bound": "hbm", "kernel": "k_sample (K1)", "achieved": ach, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(args, C),
                          "algorithmic_bytes_per_launch": b_k1, "avg_launch_ms": k1_ms,
                          "k_update_avg_launch_ms": k2_ms, "sweep_bytes": b_sweep,
                          "sweep_frac_of_peak": b_sweep / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
