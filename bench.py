@@ -62,9 +62,9 @@ def cpu_baseline(args, total_reads):
                      want_trace=False)
     reads_it_s_1 = Rs * max(1, iters // 8) / r1["seconds"]
     return {"value": reads_it_s / args.rows, "unit": "iterations/s", "cores": threads, "kind": "port",
-            "sample": "first %d generator rows of the same workload (T=%d, avg %.0f hits), %d iterations, all %d host "
-                      "threads; reads*iter/s scaled to the %d-read problem" % (Rs, args.transcripts, args.avg_hits,
-                                                                              iters, threads, args.rows),
+            "sample": "first %d generator rows of the same workload (T=%d, avg %.0f hits), %d iterations on %d host threads "
+                      "(best of %s on this %d-CPU host); reads*iter/s scaled to the %d-read problem"
+                      % (Rs, args.transcripts, args.avg_hits, iters, threads, cands, ncpu, args.rows),
             "reads_iters_per_sec": reads_it_s, "single_thread_iterations_per_sec": reads_it_s_1 / args.rows}
 
 
