@@ -120,10 +120,13 @@ struct RowViewWin {
 
 // fast path: the tile lies inside the LDS window and s_col holds BYTE OFFSETS into s_mu
 // ((col - wbase) * 8, written by commit), so a hit costs ds_read_b32 + ds_read_b64 + v_add_f64.
-// Full groups of UNR hits run unmasked; the <UNR tail runs one hit at a time.
-template <int UNR>
+// Full groups of UNR hits run unmasked with the NEXT group's offsets already in flight (one exposed
+// LDS latency per group); the <UNR tail is one group whose missing slots point at a 0.0 entry
+// (s_mu[WIN]), so it needs no masking of the fp64 adds and no loop.  The additions happen in row
+// order in every case (x + 0.0 == x exactly), so the result equals the plain sequential walk.
+template <int UNR, uint32_t ZERO_OFF>
 struct RowViewOff {
-    const uint32_t *cl; // row's byte offsets in LDS
+    const uint32_t *cl; // row's byte offsets in LDS (reading a few elements past the row is harmless)
     uint32_t L;
     const double *s_mu;
     __device__ __forceinline__ double wo(uint32_t off) const { return *(const double *)((const char *)s_mu + off); }
@@ -133,30 +136,39 @@ struct RowViewOff {
     {
         double t = 0.0;
         uint32_t j = 0;
-        for (; j + UNR <= L; j += UNR) {
-            uint32_t o[UNR];
-            double wv[UNR];
+        uint32_t o[UNR];
 #pragma unroll
-            for (int i = 0; i < UNR; ++i) o[i] = cl[j + i];
+        for (int i = 0; i < UNR; ++i) o[i] = cl[i];
+        for (; j + UNR <= L; j += UNR) {
+            double wv[UNR];
 #pragma unroll
             for (int i = 0; i < UNR; ++i) wv[i] = wo(o[i]);
 #pragma unroll
+            for (int i = 0; i < UNR; ++i) o[i] = cl[j + UNR + i]; // next group (or the tail), in flight during the adds
+#pragma unroll
             for (int i = 0; i < UNR; ++i) t += wv[i];
         }
-        for (; j < L; ++j) t += wo(cl[j]);
+        const uint32_t rem = L - j; // 0 .. UNR-1
+        double wv[UNR > 1 ? UNR - 1 : 1];
+#pragma unroll
+        for (int i = 0; i < UNR - 1; ++i) wv[i] = wo((uint32_t)i < rem ? o[i] : ZERO_OFF);
+#pragma unroll
+        for (int i = 0; i < UNR - 1; ++i) t += wv[i];
         return t;
     }
     __device__ __forceinline__ uint32_t pick(double target) const
     {
         double acc = 0.0;
         uint32_t j = 0;
+        uint32_t o[UNR];
+#pragma unroll
+        for (int i = 0; i < UNR; ++i) o[i] = cl[i];
         for (; j + UNR <= L; j += UNR) {
-            uint32_t o[UNR];
             double wv[UNR], pa[UNR];
 #pragma unroll
-            for (int i = 0; i < UNR; ++i) o[i] = cl[j + i];
-#pragma unroll
             for (int i = 0; i < UNR; ++i) wv[i] = wo(o[i]);
+#pragma unroll
+            for (int i = 0; i < UNR; ++i) o[i] = cl[j + UNR + i];
 #pragma unroll
             for (int i = 0; i < UNR; ++i) { acc += wv[i]; pa[i] = acc; }
             if (target < acc) { // prefix sums never decrease: the first i with target < pa[i] is in this group
@@ -166,11 +178,19 @@ struct RowViewOff {
                 return j + sel;
             }
         }
-        for (; j < L; ++j) {
-            acc += wo(cl[j]);
-            if (target < acc) return j;
+        const uint32_t rem = L - j;
+        double wv[UNR > 1 ? UNR - 1 : 1];
+#pragma unroll
+        for (int i = 0; i < UNR - 1; ++i) wv[i] = wo((uint32_t)i < rem ? o[i] : ZERO_OFF);
+        uint32_t sel = L - 1; // also the fallback when rounding leaves target >= total
+#pragma unroll
+        for (int i = UNR - 2; i >= 0; --i) {
+            double p = acc;
+#pragma unroll
+            for (int q = 0; q <= i; ++q) p += wv[q];
+            sel = ((uint32_t)i < rem && target < p) ? j + (uint32_t)i : sel;
         }
-        return L - 1;
+        return sel;
     }
 };
 
@@ -288,7 +308,7 @@ __global__ __launch_bounds__(K1_BLOCK) void k_sample(const IdxT *__restrict__ ro
     constexpr int NC = ELEMS / 4 / K1_BLOCK;        // 16-byte chunks per thread
     constexpr int NR = ROWS_CAP / K1_BLOCK + 1;     // row offsets per thread (nrows+1 entries)
     __shared__ __attribute__((aligned(16))) uint32_t s_col[ELEMS];
-    __shared__ __attribute__((aligned(16))) double s_mu[WIN];
+    __shared__ __attribute__((aligned(16))) double s_mu[WIN + 2]; // [WIN] stays 0.0: the tail group's padding slot
     __shared__ uint32_t s_rp[ROWS_CAP + K1_BLOCK];
     __shared__ uint32_t s_k[HAS_K ? ROWS_CAP + K1_BLOCK : 1];
     __shared__ int32_t s_cnt[WIN];
@@ -298,6 +318,7 @@ __global__ __launch_bounds__(K1_BLOCK) void k_sample(const IdxT *__restrict__ ro
     if (t_begin >= t_end) return;
 
     for (int i = tid; i < WIN; i += K1_BLOCK) s_cnt[i] = 0;
+    if (tid < 2) s_mu[WIN + tid] = 0.0;
     uint32_t base = 0xffffffffu;
     bool win_valid = false;
 
@@ -393,7 +414,7 @@ __global__ __launch_bounds__(K1_BLOCK) void k_sample(const IdxT *__restrict__ ro
                 auto add = [&](uint32_t off, int32_t x) { atomicAdd((int32_t *)((char *)s_cnt + (off >> 1)), x); };
                 for (uint32_t r = tid; r < d.nrows; r += K1_BLOCK) {
                     const uint32_t b = s_rp[r], L = s_rp[r + 1] - b;
-                    RowViewOff<UNR> v{s_col + b, L, s_mu};
+                    RowViewOff<UNR, (uint32_t)WIN * 8u> v{s_col + b, L, s_mu};
                     allocate_row<HAS_K>(v, add, HAS_K ? s_k[r] : 1u, a, a.row_id_base + d.r0 + r);
                 }
             } else {

@@ -22,14 +22,19 @@ struct K1Variant { int elems, win, unr, mode; };
     X(4, 4096, 2048, 8, 0)             \
     X(5, 4096, 2048, 1, 0)             \
     X(6, 4096, 2048, 4, K1M_NO_PHASE2) \
-    X(7, 8192, 2048, 8, 0)
+    X(7, 8192, 2048, 8, 0)             \
+    X(8, 5120, 1024, 4, 0)             \
+    X(9, 5120, 512, 4, 0)              \
+    X(10, 4096, 512, 4, 0)             \
+    X(11, 6144, 512, 4, 0)             \
+    X(12, 3072, 512, 4, 0)
 static const K1Variant k1_variants[] = {
 #define X(id, e, w, u, m) {e, w, u, m},
     K1_VARIANT_LIST(X)
 #undef X
 };
 static const int k1_n_variants = (int)(sizeof(k1_variants) / sizeof(k1_variants[0]));
-static const int K1_DEFAULT_VARIANT = 1;
+static const int K1_DEFAULT_VARIANT = 10;
 
 template <typename IdxT, bool HAS_K>
 static const void *k1_kernel_for(int variant)
