@@ -162,7 +162,7 @@ int mmg_host_gamma_trace(uint64_t seed, uint64_t id, double shape, double scale,
  * on that device; device == -1: the host instantiation of the same inline code). */
 int mmg_selftest_math(int device, int64_t n, const double *x, double *out_log, double *out_exp,
                       double *out_sqrt, double *out_rcp);
-/* Philox4x32-10 block: out[4] = philox(ctr[4], key[2]). */
+/* out[0..4) = Philox4x32-10(ctr[4], key[2]); out[4..6) = Philox2x32-10(ctr[0..2), key[0]). */
 int mmg_selftest_philox(int device, const uint32_t *ctr, const uint32_t *key, uint32_t *out);
 /* out[i] = shape-`shape` gamma draw of stream (seed, chain 0, iter 0, id i) times scale. */
 int mmg_selftest_gamma(int device, uint64_t seed, double shape, double scale, int64_t n, double *out);

@@ -228,11 +228,9 @@ __device__ __forceinline__ void allocate_row(const View &v, Add add, uint32_t kk
     const double total = v.total();
     const bool degenerate = !(total > 0.0) || !(total < __builtin_huge_val());
     if (!HAS_K || kk <= K_SMALL) {
-        Stream s(a.seed, a.chain, TAG_ROW, row_id, a.iter);
-        double ua = 0.0, ub = 0.0;
+        Stream2 s(a.seed, a.chain, TAG_ROW, row_id, a.iter);
         for (uint32_t d = 0; d < kk; ++d) {
-            if ((d & 1u) == 0) s.pair(ua, ub);
-            const double u = (d & 1u) ? ub : ua;
+            const double u = s.next();
             uint32_t sel;
             if (degenerate) {
                 sel = (uint32_t)(u * (double)L);
@@ -245,7 +243,7 @@ __device__ __forceinline__ void allocate_row(const View &v, Add add, uint32_t kk
         return;
     }
     // conditional-binomial chain (the published gsl_ran_multinomial scheme, src/mmseq.cpp:880)
-    SeqStream q(Stream(a.seed, a.chain, TAG_ROW, row_id, a.iter));
+    Stream2 q(a.seed, a.chain, TAG_ROW, row_id, a.iter);
     uint32_t remaining = kk;
     double rem_w = total;
     for (uint32_t j = 0; j + 1 < L && remaining > 0; ++j) {
@@ -297,34 +295,34 @@ __global__ __launch_bounds__(64) void k_tile_desc(const IdxT *__restrict__ row_p
 // order is FAST (global int32 atomics cap at ~26 G/s on MI355X, LDS atomics at >100 G/s).
 // The next tile's column ids and row offsets are prefetched into registers while the current
 // tile's rows are walked, so the only dependent global access per tile is the descriptor.
-template <typename IdxT, bool HAS_K, int ELEMS, int WIN, int UNR, int MODE>
-__global__ __launch_bounds__(K1_BLOCK) void k_sample(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
+template <typename IdxT, bool HAS_K, int ELEMS, int WIN, int UNR, int MODE, int BS, int RC>
+__global__ __launch_bounds__(BS) void k_sample(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
                                                      const uint32_t *__restrict__ kmult, const TileDesc *__restrict__ tiles,
                                                      const uint64_t *__restrict__ chunk_tile, const double *__restrict__ gmu,
                                                      int32_t *gcnt, SampleArgs a)
 {
     constexpr int TILE_NNZ = ELEMS - 8;
-    constexpr int ROWS_CAP = ELEMS / 4;             // rows per tile (host enforces)
-    constexpr int NC = ELEMS / 4 / K1_BLOCK;        // 16-byte chunks per thread
-    constexpr int NR = ROWS_CAP / K1_BLOCK + 1;     // row offsets per thread (nrows+1 entries)
+    constexpr int ROWS_CAP = RC > 0 ? RC : ELEMS / 4; // rows per tile (host enforces the same cap)
+    constexpr int NC = ELEMS / 4 / BS;        // 16-byte chunks per thread
+    constexpr int NR = ROWS_CAP / BS + 1;     // row offsets per thread (nrows+1 entries)
     __shared__ __attribute__((aligned(16))) uint32_t s_col[ELEMS];
     __shared__ __attribute__((aligned(16))) double s_mu[WIN + 2]; // [WIN] stays 0.0: the tail group's padding slot
-    __shared__ uint32_t s_rp[ROWS_CAP + K1_BLOCK];
-    __shared__ uint32_t s_k[HAS_K ? ROWS_CAP + K1_BLOCK : 1];
+    __shared__ uint32_t s_rp[ROWS_CAP + BS];
+    __shared__ uint32_t s_k[HAS_K ? ROWS_CAP + BS : 1];
     __shared__ int32_t s_cnt[WIN];
     const int tid = threadIdx.x;
 
     const uint64_t t_begin = chunk_tile[blockIdx.x], t_end = chunk_tile[blockIdx.x + 1];
     if (t_begin >= t_end) return;
 
-    for (int i = tid; i < WIN; i += K1_BLOCK) s_cnt[i] = 0;
+    for (int i = tid; i < WIN; i += BS) s_cnt[i] = 0;
     if (tid < 2) s_mu[WIN + tid] = 0.0;
     uint32_t base = 0xffffffffu;
     bool win_valid = false;
 
     auto flush_window = [&]() {
         if (!win_valid) return;
-        for (int i = tid; i < WIN; i += K1_BLOCK) {
+        for (int i = tid; i < WIN; i += BS) {
             const int32_t v = s_cnt[i];
             if (v) { global_count_add(gcnt, base + (uint32_t)i, v); s_cnt[i] = 0; }
         }
@@ -344,12 +342,12 @@ __global__ __launch_bounds__(K1_BLOCK) void k_sample(const IdxT *__restrict__ ro
         const u32x4 *__restrict__ src = (const u32x4 *)(col_idx + abase);
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
-            const uint32_t ch = min((uint32_t)tid + (uint32_t)i * K1_BLOCK, nchunks - 1);
+            const uint32_t ch = min((uint32_t)tid + (uint32_t)i * BS, nchunks - 1);
             pc[i] = __builtin_nontemporal_load(src + ch);
         }
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            const uint32_t idx = min((uint32_t)tid + (uint32_t)i * K1_BLOCK, d.nrows);
+            const uint32_t idx = min((uint32_t)tid + (uint32_t)i * BS, d.nrows);
             prp[i] = row_ptr[d.r0 + idx];
             if (HAS_K) pk[i] = kmult[d.r0 + min(idx, d.nrows - 1)];
         }
@@ -359,14 +357,14 @@ __global__ __launch_bounds__(K1_BLOCK) void k_sample(const IdxT *__restrict__ ro
         const uint32_t nchunks = (d.nnz + shift + 3) >> 2;
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
-            const uint32_t ch = (uint32_t)tid + (uint32_t)i * K1_BLOCK;
+            const uint32_t ch = (uint32_t)tid + (uint32_t)i * BS;
             // in-window tiles store byte offsets into s_mu instead of column ids (edge junk is never read)
             const u32x4 v = inwin ? (pc[i] - wbase) * 8u : pc[i];
             if (ch < nchunks) *(u32x4 *)(s_col + 4 * ch) = v;
         }
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            const uint32_t idx = (uint32_t)tid + (uint32_t)i * K1_BLOCK;
+            const uint32_t idx = (uint32_t)tid + (uint32_t)i * BS;
             if (idx <= d.nrows) s_rp[idx] = (uint32_t)((uint64_t)prp[i] - d.nz0) + shift;
             if (HAS_K && idx < d.nrows) s_k[idx] = pk[i];
         }
@@ -398,7 +396,7 @@ __global__ __launch_bounds__(K1_BLOCK) void k_sample(const IdxT *__restrict__ ro
             flush_window();
             base = d.cmin & ~15u;
             win_valid = true;
-            for (int i = tid; i < WIN; i += K1_BLOCK) {
+            for (int i = tid; i < WIN; i += BS) {
                 const uint32_t c = base + (uint32_t)i;
                 s_mu[i] = c < a.n ? gmu[c] : 0.0;
             }
@@ -412,7 +410,7 @@ __global__ __launch_bounds__(K1_BLOCK) void k_sample(const IdxT *__restrict__ ro
         if (!(MODE & K1M_NO_PHASE2)) {
             if (inwin) {
                 auto add = [&](uint32_t off, int32_t x) { atomicAdd((int32_t *)((char *)s_cnt + (off >> 1)), x); };
-                for (uint32_t r = tid; r < d.nrows; r += K1_BLOCK) {
+                for (uint32_t r = tid; r < d.nrows; r += BS) {
                     const uint32_t b = s_rp[r], L = s_rp[r + 1] - b;
                     RowViewOff<UNR, (uint32_t)WIN * 8u> v{s_col + b, L, s_mu};
                     allocate_row<HAS_K>(v, add, HAS_K ? s_k[r] : 1u, a, a.row_id_base + d.r0 + r);
@@ -423,7 +421,7 @@ __global__ __launch_bounds__(K1_BLOCK) void k_sample(const IdxT *__restrict__ ro
                     if (dd < (uint32_t)WIN) atomicAdd(&s_cnt[dd], x);
                     else global_count_add(gcnt, c, x);
                 };
-                for (uint32_t r = tid; r < d.nrows; r += K1_BLOCK) {
+                for (uint32_t r = tid; r < d.nrows; r += BS) {
                     const uint32_t b = s_rp[r], L = s_rp[r + 1] - b;
                     RowViewWin<WIN, 1, false> v{s_col + b, L, wbase, s_mu, gmu};
                     allocate_row<HAS_K>(v, add, HAS_K ? s_k[r] : 1u, a, a.row_id_base + d.r0 + r);
@@ -603,6 +601,13 @@ __host__ __device__ __forceinline__ uint32_t synth_len_from_u(const double *len_
     while (j < 99 && !(u < len_cdf[j])) ++j;
     return 1 + j;
 }
+// experiment hook (not part of the generator spec): parity 1 -> odd lengths only, 2 -> even lengths only
+__host__ __device__ __forceinline__ uint32_t synth_parity(uint32_t L, int mode)
+{
+    if (mode & 2) return L | 1u;
+    if (mode & 4) return (L & 1u) ? L + 1 : L;
+    return L;
+}
 
 __device__ __forceinline__ uint32_t synth_first(const SynthArgs &a, double ub)
 {
@@ -624,7 +629,7 @@ __global__ __launch_bounds__(256) void k_synth_len(SynthArgs a, uint32_t *lens, 
     Stream s(a.seed, 0, TAG_SYNTH_ROW, a.row0 + r, 0);
     double ua, ub;
     s.pair(ua, ub);
-    uint32_t L = synth_len_from_u(a.len_cdf, ua);
+    uint32_t L = synth_parity(synth_len_from_u(a.len_cdf, ua), a.uniform);
     if (L > a.n) L = a.n;
     lens[r] = L;
     if (!keys) return;
@@ -632,9 +637,9 @@ __global__ __launch_bounds__(256) void k_synth_len(SynthArgs a, uint32_t *lens, 
     const uint32_t T = a.n, t0 = synth_first(a, ub);
     uint32_t best = t0;
     if (L > 1) {
-        const uint32_t W = a.uniform ? T : (T < 129u ? T : 129u);
+        const uint32_t W = (a.uniform & 1) ? T : (T < 129u ? T : 129u);
         uint32_t wb = 0;
-        if (!a.uniform) {
+        if (!(a.uniform & 1)) {
             int64_t b = (int64_t)t0 - 64;
             if (b < 0) b = 0;
             if (b + (int64_t)W > (int64_t)T) b = (int64_t)T - (int64_t)W;
@@ -671,16 +676,16 @@ __global__ __launch_bounds__(256) void k_synth_fill(SynthArgs a, const IdxT *__r
     Stream s(a.seed, 0, TAG_SYNTH_ROW, a.row0 + (perm ? (uint64_t)perm[r] : r), 0);
     double ua, ub;
     s.pair(ua, ub);
-    uint32_t L = synth_len_from_u(a.len_cdf, ua);
+    uint32_t L = synth_parity(synth_len_from_u(a.len_cdf, ua), a.uniform);
     const uint32_t T = a.n;
     if (L > T) L = T;
     uint32_t *cols = col_idx + (uint64_t)row_ptr[r];
     const uint32_t t0 = synth_first(a, ub);
     cols[0] = t0;
     if (L <= 1) return;
-    const uint32_t W = a.uniform ? T : (T < 129u ? T : 129u);
+    const uint32_t W = (a.uniform & 1) ? T : (T < 129u ? T : 129u);
     uint32_t wb = 0;
-    if (!a.uniform) {
+    if (!(a.uniform & 1)) {
         int64_t b = (int64_t)t0 - 64;
         if (b < 0) b = 0;
         if (b + (int64_t)W > (int64_t)T) b = (int64_t)T - (int64_t)W;
@@ -722,6 +727,9 @@ __global__ void k_selftest_philox(const uint32_t *ctr, const uint32_t *key, uint
 {
     const U4 r = philox4x32_10(U4{ctr[0], ctr[1], ctr[2], ctr[3]}, key[0], key[1]);
     out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+    uint32_t a = ctr[0], b = ctr[1];
+    philox2x32_10(a, b, key[0]);
+    out[4] = a; out[5] = b;
 }
 __global__ void k_selftest_gamma(uint64_t seed, double shape, double scale, int64_t n, double *out)
 {
@@ -734,7 +742,7 @@ __global__ void k_selftest_binomial(uint64_t seed, uint32_t nn, double p, int64_
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    SeqStream q(Stream(seed, 0, TAG_ROW, (uint64_t)i, 0));
+    Stream2 q(seed, 0, TAG_ROW, (uint64_t)i, 0);
     out[i] = binomial(q, nn, p);
 }
 

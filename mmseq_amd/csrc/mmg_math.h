@@ -49,6 +49,19 @@ MMG_HD U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1)
     return c;
 }
 
+// Philox2x32-10: same family, 64-bit output, half the multiplies.  One call = one uniform; used for
+// the per-row allocation draw (one 52-bit uniform per read), the dominant integer work of a sweep.
+MMG_HD void philox2x32_10(uint32_t &c0, uint32_t &c1, uint32_t k)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi = mulhi32(0xD256D193u, c0), lo = 0xD256D193u * c0;
+        c0 = hi ^ k ^ c1;
+        c1 = lo;
+        k += 0x9E3779B9u;
+    }
+}
+
 // 52 random bits -> uniform strictly inside (0,1); every step exact
 MMG_HD double u52(uint32_t a, uint32_t b)
 {
@@ -71,6 +84,23 @@ struct Stream {
         ++c3;
         ua = u52(r.x, r.y);
         ub = u52(r.z, r.w);
+    }
+};
+
+// Row stream (Philox2x32): key from (seed, chain, tag, id_hi), counter (id_lo, iteration); the b-th
+// uniform uses key + b * 0xBB67AE85.
+struct Stream2 {
+    uint32_t key, c0, c1, blk;
+    MMG_HD Stream2(uint64_t seed, uint32_t chain, uint32_t tag, uint64_t id, uint32_t iter)
+        : key((uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B1u) ^ (chain * 0x85EBCA6Bu) ^ (tag << 28) ^
+              ((uint32_t)(id >> 32) * 0xC2B2AE35u)),
+          c0((uint32_t)id), c1(iter), blk(0) {}
+    MMG_HD double next()
+    {
+        uint32_t a = c0, b = c1;
+        philox2x32_10(a, b, key + blk * 0xBB67AE85u);
+        ++blk;
+        return u52(a, b);
     }
 };
 
@@ -276,7 +306,8 @@ MMG_HD double stirling_tail(double k)
 }
 
 // Binomial(n, p): sequential-search inversion below n*min(p,1-p) < 10, Hormann's BTRS above
-MMG_HD uint32_t binomial(SeqStream &q, uint32_t n, double p)
+template <typename Src>
+MMG_HD uint32_t binomial(Src &q, uint32_t n, double p)
 {
     if (n == 0 || !(p > 0.0)) return 0;
     if (p >= 1.0) return n;

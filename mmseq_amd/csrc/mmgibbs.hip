@@ -13,34 +13,47 @@
 using namespace mmg;
 
 // ------------------------------------------------------------------------------ K1 variants
-struct K1Variant { int elems, win, unr, mode; };
+struct K1Variant { int elems, win, unr, mode, bs, rows; }; // rows: host-side cap on rows per tile (0 = elems/4)
 #define K1_VARIANT_LIST(X) \
-    X(0, 4096, 2048, 4, 0)             \
-    X(1, 4096, 1024, 4, 0)             \
-    X(2, 8192, 2048, 4, 0)             \
-    X(3, 2048, 1024, 4, 0)             \
-    X(4, 4096, 2048, 8, 0)             \
-    X(5, 4096, 2048, 1, 0)             \
-    X(6, 4096, 2048, 4, K1M_NO_PHASE2) \
-    X(7, 8192, 2048, 8, 0)             \
-    X(8, 5120, 1024, 4, 0)             \
-    X(9, 5120, 512, 4, 0)              \
-    X(10, 4096, 512, 4, 0)             \
-    X(11, 6144, 512, 4, 0)             \
-    X(12, 3072, 512, 4, 0)
+    X(0, 4096, 2048, 4, 0, 256, 0) \
+    X(1, 4096, 1024, 4, 0, 256, 0) \
+    X(2, 8192, 2048, 4, 0, 256, 0) \
+    X(3, 2048, 1024, 4, 0, 256, 0) \
+    X(4, 4096, 2048, 8, 0, 256, 0) \
+    X(5, 4096, 2048, 1, 0, 256, 0) \
+    X(6, 4096, 2048, 4, K1M_NO_PHASE2, 256, 0) \
+    X(7, 8192, 2048, 8, 0, 256, 0) \
+    X(8, 5120, 1024, 4, 0, 256, 0) \
+    X(9, 5120, 512, 4, 0, 256, 0) \
+    X(10, 4096, 512, 4, 0, 256, 0) \
+    X(11, 6144, 512, 4, 0, 256, 0) \
+    X(12, 3072, 512, 4, 0, 256, 0) \
+    X(13, 1536, 256, 4, 0, 64, 64) \
+    X(14, 1536, 512, 4, 0, 64, 64) \
+    X(15, 2048, 512, 4, 0, 128, 128) \
+    X(16, 3072, 512, 4, 0, 128, 128) \
+    X(17, 1024, 256, 4, 0, 64, 64) \
+    X(18, 2560, 512, 4, 0, 128, 128) \
+    X(19, 6144, 512, 4, 0, 256, 256)  \
+    X(20, 1280, 256, 4, 0, 64, 64) \
+    X(21, 2560, 256, 4, 0, 128, 128) \
+    X(22, 2560, 384, 4, 0, 128, 128) \
+    X(23, 3072, 256, 4, 0, 128, 128) \
+    X(24, 4096, 512, 4, 0, 256, 256) \
+    X(25, 5120, 512, 4, 0, 256, 256)
 static const K1Variant k1_variants[] = {
-#define X(id, e, w, u, m) {e, w, u, m},
+#define X(id, e, w, u, m, bs, rows) {e, w, u, m, bs, rows},
     K1_VARIANT_LIST(X)
 #undef X
 };
 static const int k1_n_variants = (int)(sizeof(k1_variants) / sizeof(k1_variants[0]));
-static const int K1_DEFAULT_VARIANT = 10;
+static const int K1_DEFAULT_VARIANT = 21;
 
 template <typename IdxT, bool HAS_K>
 static const void *k1_kernel_for(int variant)
 {
     switch (variant) {
-#define X(id, e, w, u, m) case id: return (const void *)&k_sample<IdxT, HAS_K, e, w, u, m>;
+#define X(id, e, w, u, m, bs, rows) case id: return (const void *)&k_sample<IdxT, HAS_K, e, w, u, m, bs, rows>;
         K1_VARIANT_LIST(X)
 #undef X
     }
@@ -160,8 +173,11 @@ static int problem_finish(mmg_problem *p, const uint64_t *h_row_ptr)
         if (v < 0 || v >= k1_n_variants) return fail(MMG_ERR_ARG, "MMG_K1_VARIANT out of range");
         p->variant = v;
     }
-    build_tiles(h_row_ptr, p->m, (uint64_t)k1_variants[p->variant].elems - 8, (uint64_t)k1_variants[p->variant].elems / 4, tiles,
-                p->max_row_len);
+    {
+        const K1Variant &kv = k1_variants[p->variant];
+        const uint64_t rows_cap = kv.rows > 0 ? std::min<uint64_t>(kv.rows, kv.elems / 4) : (uint64_t)kv.elems / 4;
+        build_tiles(h_row_ptr, p->m, (uint64_t)kv.elems - 8, rows_cap, tiles, p->max_row_len);
+    }
     p->n_tiles = tiles.empty() ? 0 : tiles.size() - 1;
     p->idx64 = p->nnz >= 0xffffffffull;
     if (p->idx64) {
@@ -182,12 +198,13 @@ static int problem_finish(mmg_problem *p, const uint64_t *h_row_ptr)
     // Persistent grid: every resident workgroup (4 per CU at 40 KiB LDS) walks q contiguous
     // chunks of tiles, so its LDS window slides monotonically over the sorted rows.
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k1_kernel(p->variant, p->idx64, false), K1_BLOCK, 0) != hipSuccess || per_cu < 1) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k1_kernel(p->variant, p->idx64, false), k1_variants[p->variant].bs, 0) != hipSuccess || per_cu < 1) {
         (void)hipGetLastError();
         per_cu = 4;
     }
-    if (per_cu > 8) per_cu = 8;
-    if (const char *ev = getenv("MMG_K1_BLOCKS_PER_CU")) { const int v = atoi(ev); if (v >= 1 && v <= 8) per_cu = v; }
+    const int max_blocks = 2048 / k1_variants[p->variant].bs > 32 ? 32 : 2048 / k1_variants[p->variant].bs; // 32 waves per CU
+    if (per_cu > max_blocks) per_cu = max_blocks;
+    if (const char *ev = getenv("MMG_K1_BLOCKS_PER_CU")) { const int v = atoi(ev); if (v >= 1 && v <= 32) per_cu = v; }
     const uint64_t resident = (uint64_t)p->cu_count * (uint64_t)per_cu;
     const uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>(p->n_tiles, resident));
     p->n_chunks = p->n_tiles ? grid : 0; // one contiguous tile range per workgroup
@@ -634,7 +651,7 @@ extern "C" int mmg_sampler_sample(mmg_sampler *s)
             const double *mu = s->d_mu + (size_t)c * p->n;
             int32_t *cnt = s->d_cnt + (size_t)c * p->n;
             void *kargs[] = {(void *)&rp, (void *)&ci, (void *)&kk, (void *)&td, (void *)&ct, (void *)&mu, (void *)&cnt, (void *)&a};
-            HIP_TRY(hipLaunchKernel(k1_kernel(p->variant, p->idx64, p->d_k != nullptr), dim3(p->grid_sample), dim3(K1_BLOCK), kargs, 0, s->cur));
+            HIP_TRY(hipLaunchKernel(k1_kernel(p->variant, p->idx64, p->d_k != nullptr), dim3(p->grid_sample), dim3(k1_variants[p->variant].bs), kargs, 0, s->cur));
         }
         HIP_TRY(hipGetLastError());
     }
@@ -881,16 +898,19 @@ extern "C" int mmg_selftest_philox(int device, const uint32_t *ctr, const uint32
     if (device < 0) {
         const U4 r = philox4x32_10(U4{ctr[0], ctr[1], ctr[2], ctr[3]}, key[0], key[1]);
         out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+        uint32_t a = ctr[0], b = ctr[1];
+        philox2x32_10(a, b, key[0]);
+        out[4] = a; out[5] = b;
         return MMG_OK;
     }
     int rc = require_device(device);
     if (rc) return rc;
     uint32_t *d = nullptr;
-    HIP_TRY(hipMalloc((void **)&d, 10 * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&d, 12 * sizeof(uint32_t)));
     hipError_t e = hipMemcpy(d, ctr, 16, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d + 4, key, 8, hipMemcpyHostToDevice);
     if (e == hipSuccess) { hipLaunchKernelGGL(k_selftest_philox, dim3(1), dim3(1), 0, 0, d, d + 4, d + 6); e = hipDeviceSynchronize(); }
-    if (e == hipSuccess) e = hipMemcpy(out, d + 6, 16, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out, d + 6, 24, hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(MMG_ERR_HIP, std::string("selftest_philox: ") + hipGetErrorString(e));
     return MMG_OK;
@@ -919,7 +939,7 @@ extern "C" int mmg_selftest_binomial(int device, uint64_t seed, uint32_t nn, dou
 {
     if (n < 0 || !out) return fail(MMG_ERR_ARG, "bad argument");
     if (device < 0) {
-        for (int64_t i = 0; i < n; ++i) { SeqStream q(Stream(seed, 0, TAG_ROW, (uint64_t)i, 0)); out[i] = binomial(q, nn, p); }
+        for (int64_t i = 0; i < n; ++i) { Stream2 q(seed, 0, TAG_ROW, (uint64_t)i, 0); out[i] = binomial(q, nn, p); }
         return MMG_OK;
     }
     int rc = require_device(device);

@@ -212,7 +212,7 @@ def selftest_math(x, device):
 def selftest_philox(ctr, key, device):
     ctr = np.ascontiguousarray(ctr, np.uint32)
     key = np.ascontiguousarray(key, np.uint32)
-    out = np.zeros(4, np.uint32)
+    out = np.zeros(6, np.uint32)
     check(_lib.load().mmg_selftest_philox(device, _ptr(ctr), _ptr(key), _ptr(out)))
     return out
 

@@ -33,6 +33,7 @@ def lib():
         build()
     L = C.CDLL(path)
     L.orc_philox.argtypes = [u32p, u32p, u32p]
+    L.orc_philox2x32.argtypes = [u32p, C.c_uint32, u32p]
     L.orc_log_v.argtypes = [C.c_int64, f64p, f64p]
     L.orc_exp_v.argtypes = [C.c_int64, f64p, f64p]
     L.orc_gamma_draw.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_double, C.c_double]
@@ -87,6 +88,12 @@ def _optr(a):
 def philox(ctr, key):
     out = np.zeros(4, np.uint32)
     lib().orc_philox(np.asarray(ctr, np.uint32), np.asarray(key, np.uint32), out)
+    return out
+
+
+def philox2x32(ctr, key):
+    out = np.zeros(2, np.uint32)
+    lib().orc_philox2x32(np.asarray(ctr, np.uint32), int(key), out)
     return out
 
 

@@ -78,6 +78,28 @@ void orc_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
     memcpy(out, c.v, sizeof c.v);
 }
 
+/* Philox2x32-10 (same family, 64-bit output): one call = one uniform.  Used for the per-row allocation
+ * draws, which need a single 52-bit uniform per read and dominate the sweep's integer work. */
+static inline void philox2x32_10(uint32_t *c0, uint32_t *c1, uint32_t k)
+{
+    uint32_t a = *c0, b = *c1;
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p = (uint64_t)0xD256D193u * a;
+        uint32_t na = (uint32_t)(p >> 32) ^ k ^ b;
+        b = (uint32_t)p;
+        a = na;
+        k += 0x9E3779B9u;
+    }
+    *c0 = a; *c1 = b;
+}
+
+void orc_philox2x32(const uint32_t ctr[2], uint32_t key, uint32_t out[2])
+{
+    uint32_t a = ctr[0], b = ctr[1];
+    philox2x32_10(&a, &b, key);
+    out[0] = a; out[1] = b;
+}
+
 /* 52-bit uniform strictly inside (0,1): (x + 1/2) * 2^-52, every step exact */
 static inline double u52(uint32_t a, uint32_t b)
 {
@@ -103,6 +125,29 @@ static inline orc_stream stream_make(uint64_t seed, uint32_t chain, uint32_t tag
     s.c2 = iter;
     s.c3 = 0;
     return s;
+}
+
+/* Row stream: key from (seed, chain, tag, id_hi), counter (id_lo, iteration); the b-th uniform of the
+ * stream uses key + b * 0xBB67AE85. */
+typedef struct { uint32_t key, c0, c1, blk; } orc_stream2;
+
+static inline orc_stream2 stream2_make(uint64_t seed, uint32_t chain, uint32_t tag, uint64_t id, uint32_t iter)
+{
+    orc_stream2 s;
+    s.key = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B1u) ^ (chain * 0x85EBCA6Bu) ^ (tag << 28) ^
+            ((uint32_t)(id >> 32) * 0xC2B2AE35u);
+    s.c0 = (uint32_t)id;
+    s.c1 = iter;
+    s.blk = 0;
+    return s;
+}
+
+static inline double stream2_next(orc_stream2 *s)
+{
+    uint32_t a = s->c0, b = s->c1;
+    philox2x32_10(&a, &b, s->key + s->blk * 0xBB67AE85u);
+    s->blk++;
+    return u52(a, b);
 }
 
 /* one Philox block = one pair of uniforms */
@@ -338,22 +383,12 @@ static uint32_t binomial_draw(orc_unif_fn U, void *st, uint32_t n, double p,
     return flip ? n - res : res;
 }
 
-/* Philox stream as a one-uniform-at-a-time source (first of each pair, then second) */
-typedef struct { orc_stream s; double spare; int have; } orc_seq;
-static double seq_unif(void *p)
-{
-    orc_seq *q = (orc_seq *)p;
-    if (q->have) { q->have = 0; return q->spare; }
-    double ua, ub;
-    stream_pair(&q->s, &ua, &ub);
-    q->spare = ub; q->have = 1;
-    return ua;
-}
+static double seq2_unif(void *p) { return stream2_next((orc_stream2 *)p); }
 
 uint32_t orc_binomial_keyed(uint64_t seed, uint64_t id, uint32_t n, double p)
 {
-    orc_seq q; q.s = stream_make(seed, 0, ORC_TAG_ROW, id, 0); q.have = 0;
-    return binomial_draw(seq_unif, &q, n, p, orc_log, orc_exp);
+    orc_stream2 q = stream2_make(seed, 0, ORC_TAG_ROW, id, 0);
+    return binomial_draw(seq2_unif, &q, n, p, orc_log, orc_exp);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -382,17 +417,15 @@ static void keyed_row_allocate(const uint32_t *cols, uint32_t L, uint32_t k, con
     double total = 0.0;
     for (uint32_t j = 0; j < L; ++j) total += mu[cols[j]];
     if (k <= ORC_K_SMALL) {
-        orc_stream s = stream_make(seed, chain, ORC_TAG_ROW, row_id, iter);
-        double ua = 0, ub = 0;
+        orc_stream2 s = stream2_make(seed, chain, ORC_TAG_ROW, row_id, iter);
         for (uint32_t d = 0; d < k; ++d) {
-            if ((d & 1u) == 0) stream_pair(&s, &ua, &ub);
-            double u = (d & 1u) ? ub : ua;
+            double u = stream2_next(&s);
             cnt[cols[pick_index(cols, L, mu, total, u)]] += 1;
         }
         return;
     }
     /* multinomial by conditional binomials (published gsl_ran_multinomial algorithm) */
-    orc_seq q; q.s = stream_make(seed, chain, ORC_TAG_ROW, row_id, iter); q.have = 0;
+    orc_stream2 q = stream2_make(seed, chain, ORC_TAG_ROW, row_id, iter);
     uint32_t remaining = k;
     double rem_w = total;
     int degenerate = !(total > 0.0) || !(total < INFINITY);
@@ -400,7 +433,7 @@ static void keyed_row_allocate(const uint32_t *cols, uint32_t L, uint32_t k, con
         double w = mu[cols[j]];
         double p = degenerate ? 1.0 / (double)(L - j) : (rem_w > 0.0 ? w / rem_w : 1.0);
         if (p > 1.0) p = 1.0;
-        uint32_t x = binomial_draw(seq_unif, &q, remaining, p, orc_log, orc_exp);
+        uint32_t x = binomial_draw(seq2_unif, &q, remaining, p, orc_log, orc_exp);
         cnt[cols[j]] += (int32_t)x;
         remaining -= x;
         rem_w -= w;

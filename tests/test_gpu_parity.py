@@ -41,9 +41,9 @@ def test_device_math_matches_oracle(gpu, orc):
 
 def test_device_philox_kat(gpu):
     assert [hex(v) for v in gpu.selftest_philox([0, 0, 0, 0], [0, 0], 0)] == \
-        ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+        ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8", "0xff1dae59", "0x6cd10df2"]
     assert [hex(v) for v in gpu.selftest_philox([0xffffffff] * 4, [0xffffffff] * 2, 0)] == \
-        ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+        ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd", "0x2c3f628b", "0xab4fd7ad"]
 
 
 @pytest.mark.parametrize("shape", [0.1, 0.9, 1.0, 1.1, 7.3, 1234.1])

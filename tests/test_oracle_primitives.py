@@ -15,6 +15,12 @@ def test_philox_random123_known_answers(orc):
         ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
 
 
+def test_philox2x32_random123_known_answers(orc):
+    assert [hex(v) for v in orc.philox2x32([0, 0], 0)] == ["0xff1dae59", "0x6cd10df2"]
+    assert [hex(v) for v in orc.philox2x32([0xffffffff, 0xffffffff], 0xffffffff)] == ["0x2c3f628b", "0xab4fd7ad"]
+    assert [hex(v) for v in orc.philox2x32([0x243f6a88, 0x85a308d3], 0x13198a2e)] == ["0xdd7ce038", "0xf62a4c12"]
+
+
 def test_mt19937_known_answers(orc):
     o = orc.mt19937(5489, 10000)
     assert o[0] == 3499211612 and o[9999] == 4123659995   # C++11 [rand.predef] mt19937 10000th value

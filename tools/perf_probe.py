@@ -16,9 +16,9 @@ def parity(variant):
     s.close(); prob.close()
     return ok
 
-def probe(R, T, avg, iters=20, chains=1, uniform=False, sort=True, tag="", check=True):
+def probe(R, T, avg, iters=20, chains=1, uniform=0, sort=True, tag="", check=True):
     t0 = time.time()
-    prob = Problem.synthetic(R, T, avg, seed=1234, uniform=uniform, sort=sort)
+    prob = Problem.synthetic(R, T, avg, seed=1234, uniform=int(os.environ.get('MMG_PROBE_UNIFORM', uniform)), sort=sort)
     inf = prob.info
     t1 = time.time()
     mu0, uh = prob.start_values()
