@@ -179,7 +179,7 @@ static int problem_finish(mmg_problem *p, const uint64_t *h_row_ptr)
         build_tiles(h_row_ptr, p->m, (uint64_t)kv.elems - 8, rows_cap, tiles, p->max_row_len);
     }
     p->n_tiles = tiles.empty() ? 0 : tiles.size() - 1;
-    p->idx64 = p->nnz >= 0xffffffffull;
+    p->idx64 = p->nnz >= 0xffffffffull || getenv("MMG_FORCE_IDX64") != nullptr; // the env knob lets small tests cover the 64-bit path
     if (p->idx64) {
         HIP_TRY(hipMalloc(&p->d_row_ptr, (p->m + 1) * sizeof(uint64_t)));
         HIP_TRY(hipMemcpy(p->d_row_ptr, h_row_ptr, (p->m + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));

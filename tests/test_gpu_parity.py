@@ -260,3 +260,31 @@ def test_torch_view_of_device_buffers_and_single_rank_collectives(gpu, orc):
     ref = orc.gibbs_keyed(p, mu0, seed=3, n_iter=8, trace_len=8)
     assert np.array_equal(s.trace(0), ref["trace"])
     assert np.array_equal(mom.cpu().numpy()[:900], ref["sum_log"])
+
+
+def test_64bit_row_offsets_path(gpu, orc, monkeypatch):
+    """nnz >= 2^32 switches the device row_ptr to u64; MMG_FORCE_IDX64 exercises that instantiation on a small problem."""
+    monkeypatch.setenv("MMG_FORCE_IDX64", "1")
+    p, mu0, uh = _mk(orc, 30000, 900, 7)
+    rng = np.random.default_rng(2)
+    k = rng.choice([1, 1, 1, 2, 9, 300], size=p.m).astype(np.uint32)
+    pk = orc.Problem(p.row_ptr, p.col_idx, p.l * 10, k=k)
+    mu0, _ = orc.start_values(pk)
+    prob = gpu.Problem.from_csr(pk.row_ptr, pk.col_idx, pk.l, k=pk.k)
+    assert prob.info.index_bits == 64
+    g_mu0, g_uh = prob.start_values()
+    np.testing.assert_allclose(g_mu0, mu0, rtol=1e-12)
+    em_g, it_g, _ = prob.em(mu0)
+    em_o, it_o, _ = orc.em(pk, mu0)
+    assert it_g == it_o and np.array_equal(em_g, em_o)
+    s = gpu.Sampler(prob, mu0, seed=4, gibbs_iter=32, trace_len=32)
+    s.run(32)
+    ref = orc.gibbs_keyed(pk, mu0, seed=4, n_iter=32, trace_len=32)
+    assert np.array_equal(s.trace(0), ref["trace"]) and np.array_equal(s.counts(0), ref["cnt"])
+    rp, ci = prob.download()
+    assert np.array_equal(rp, pk.row_ptr) and np.array_equal(ci, pk.col_idx)
+    syn = gpu.Problem.synthetic(5000, 300, 6, seed=1234)
+    assert syn.info.index_bits == 64
+    q, _ = orc.synth_problem(R=5000, T=300, avg_hits=6, seed=1234)
+    rp, ci = syn.download()
+    assert np.array_equal(rp, q.row_ptr) and np.array_equal(ci, q.col_idx)
