@@ -35,6 +35,8 @@ struct TileDesc {
     uint32_t clast; // leading transcript of the last non-empty row
     uint32_t cmax;  // largest transcript id in the tile
     uint32_t call;  // smallest transcript id in the tile (== cmin when rows are sorted)
+    uint32_t nnz4;  // hits when every row is padded to a multiple of 4 (size of the tile in the 16-bit stream)
+    uint32_t pad_;
 };
 
 struct SampleArgs {
@@ -267,17 +269,19 @@ __global__ __launch_bounds__(64) void k_tile_desc(const IdxT *__restrict__ row_p
     if (tile >= n_tiles) return;
     const uint64_t r0 = tile_row[tile], r1 = tile_row[tile + 1];
     const uint64_t nz0 = row_ptr[r0], nz1 = row_ptr[r1];
-    uint32_t mx = 0, mn = 0xffffffffu;
+    uint32_t mx = 0, mn = 0xffffffffu, n4 = 0;
     for (uint64_t j = nz0 + threadIdx.x; j < nz1; j += 64) { const uint32_t c = col_idx[j]; mx = max(mx, c); mn = min(mn, c); }
+    for (uint64_t r = r0 + threadIdx.x; r < r1; r += 64) n4 += ((uint32_t)((uint64_t)row_ptr[r + 1] - (uint64_t)row_ptr[r]) + 3u) & ~3u;
     for (int off = 32; off > 0; off >>= 1) {
         mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
         mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
+        n4 += (uint32_t)__shfl_xor((int)n4, off);
     }
     if (threadIdx.x == 0) {
         TileDesc d;
         d.nz0 = nz0; d.r0 = r0; d.nrows = (uint32_t)(r1 - r0);
         d.nnz = (uint32_t)min((uint64_t)0xffffffffu, nz1 - nz0);
-        d.cmin = 0; d.clast = 0; d.cmax = mx; d.call = mn;
+        d.cmin = 0; d.clast = 0; d.cmax = mx; d.call = mn; d.nnz4 = n4; d.pad_ = 0;
         if (nz1 > nz0) {
             d.cmin = col_idx[nz0];
             uint64_t rl = r1 - 1;
@@ -374,7 +378,7 @@ __global__ __launch_bounds__(BS) void k_sample(const IdxT *__restrict__ row_ptr,
     issue(d);
     for (uint64_t tile = t_begin; tile < t_end; ++tile) {
         TileDesc nd;
-        nd.nnz = 0; nd.nrows = 0; nd.nz0 = 0; nd.r0 = 0; nd.cmin = nd.clast = nd.cmax = nd.call = 0;
+        nd.nnz = 0; nd.nrows = 0; nd.nz0 = 0; nd.r0 = 0; nd.cmin = nd.clast = nd.cmax = nd.call = 0; nd.nnz4 = 0; nd.pad_ = 0;
         if (tile + 1 < t_end) nd = tiles[tile + 1];
         if (d.nnz > (uint32_t)TILE_NNZ) {
             // a single row longer than a tile: one lane walks it straight from global memory
@@ -432,6 +436,295 @@ __global__ __launch_bounds__(BS) void k_sample(const IdxT *__restrict__ row_ptr,
         d = nd;
     }
     flush_window();
+}
+
+// =============================================================================================
+// K1 on the 16-bit tile stream (the default when the tiles qualify).
+//
+// Same workgroup shape and row walk as k_sample, but the tile arrives as ONE contiguous block of
+// 16-bit words built once per problem (k_encode16): (nrows+1) row entries, then the hits as
+// `(col - window_base) * 8`, i.e. ready-made byte offsets into the LDS window, rows padded to 4 hits
+// with the offset of the window's 0.0 slot.  Half the HBM bytes, a one-instruction unpack instead of a
+// compare/select/subtract/shift per hit, half the prefetch registers -- which pays for a depth-2
+// prefetch (tiles i+1 and i+2 in flight while tile i is walked).  The window policy (base per tile,
+// when it slides) is a pure function of the tile descriptors and the workgroup's tile range and is
+// precomputed on the host into S16Tile.  Tiles that do not qualify are walked straight from the
+// 32-bit CSR in global memory: correct for any input, fast for the sorted layout.
+struct S16Tile {
+    uint64_t s16;     // 16-byte-unit offset of the tile's block in the stream (fast tiles)
+    uint64_t r0;      // first row
+    uint32_t nrows;
+    uint32_t nnz4;    // padded hits in the block
+    uint32_t wbase;   // LDS window base in force while this tile is walked
+    uint32_t flags;   // S16_*
+};
+enum : uint32_t { S16_FAST = 1, S16_SHIFT = 2, S16_EMPTY = 4 };
+typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
+
+// fast path view: rows are padded to 4 hits in LDS, every group is one aligned ds_read_b128
+struct RowView4 {
+    const uint32_t *cl; // 16-byte aligned; reading one group past the row is harmless
+    uint32_t L4;        // padded length (multiple of 4)
+    uint32_t L;         // true length
+    const double *s_mu;
+    __device__ __forceinline__ double wo(uint32_t off) const { return *(const double *)((const char *)s_mu + off); }
+    __device__ __forceinline__ uint32_t col(uint32_t j) const { return cl[j]; } // a byte offset: add() understands it
+    __device__ __forceinline__ double w(uint32_t j) const { return wo(cl[j]); }
+    __device__ __forceinline__ double total() const
+    {
+        const u32x4 *g = (const u32x4 *)cl;
+        const uint32_t ng = L4 >> 2;
+        u32x4 o = g[0];
+        double t = 0.0;
+        for (uint32_t i = 0; i < ng; ++i) {
+            const double w0 = wo(o.x), w1 = wo(o.y), w2 = wo(o.z), w3 = wo(o.w);
+            o = g[i + 1];
+            t += w0; t += w1; t += w2; t += w3;
+        }
+        return t;
+    }
+    __device__ __forceinline__ uint32_t pick(double target) const
+    {
+        const u32x4 *g = (const u32x4 *)cl;
+        const uint32_t ng = L4 >> 2;
+        u32x4 o = g[0];
+        double acc = 0.0;
+        for (uint32_t i = 0; i < ng; ++i) {
+            const double w0 = wo(o.x), w1 = wo(o.y), w2 = wo(o.z), w3 = wo(o.w);
+            o = g[i + 1];
+            const double p0 = acc + w0, p1 = p0 + w1, p2 = p1 + w2, p3 = p2 + w3;
+            if (target < p3) { // prefix sums never decrease; a zero-weight pad can never be the first to exceed
+                const uint32_t sel = target < p0 ? 0u : (target < p1 ? 1u : (target < p2 ? 2u : 3u));
+                return 4 * i + sel;
+            }
+            acc = p3;
+        }
+        return L - 1; // rounding left target >= total: the last real hit
+    }
+};
+
+// rows of a slow tile: column ids and row extents straight from the 32-bit device CSR
+template <int WIN>
+struct RowViewGlobalWin {
+    const uint32_t *cl;
+    uint32_t L;
+    uint32_t wbase;
+    const double *s_mu;
+    const double *gmu;
+    __device__ __forceinline__ uint32_t col(uint32_t j) const { return cl[j]; }
+    __device__ __forceinline__ double w(uint32_t j) const
+    {
+        const uint32_t c = cl[j], d = c - wbase;
+        return d < (uint32_t)WIN ? s_mu[d] : gmu[c];
+    }
+    __device__ __forceinline__ double total() const
+    {
+        double t = 0.0;
+        for (uint32_t j = 0; j < L; ++j) t += w(j);
+        return t;
+    }
+    __device__ __forceinline__ uint32_t pick(double target) const
+    {
+        double acc = 0.0;
+        for (uint32_t j = 0; j < L; ++j) {
+            acc += w(j);
+            if (target < acc) return j;
+        }
+        return L - 1;
+    }
+};
+
+// Stream builder: one 64-lane workgroup per fast tile.  Block = ceil((nrows+1)/8) chunks of u16 row
+// entries (start | pad, in hits, relative to the tile, start a multiple of 4) followed by ceil(nnz4/8)
+// chunks of u16 byte offsets (col - wbase) * 8, rows closed with ZERO_OFF = win * 8.
+template <typename IdxT>
+__global__ __launch_bounds__(64) void k_encode16(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
+                                                 const S16Tile *__restrict__ tiles, uint64_t n_tiles, uint32_t win, uint16_t *stream)
+{
+    __shared__ uint32_t s_start[1024 + 1];
+    const uint64_t tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    const S16Tile d = tiles[tile];
+    if (!(d.flags & S16_FAST)) return;
+    uint16_t *blk = stream + d.s16 * 8;
+    if (threadIdx.x == 0) {
+        uint32_t pos = 0;
+        for (uint32_t r = 0; r < d.nrows; ++r) {
+            s_start[r] = pos;
+            pos += ((uint32_t)((uint64_t)row_ptr[d.r0 + r + 1] - (uint64_t)row_ptr[d.r0 + r]) + 3u) & ~3u;
+        }
+        s_start[d.nrows] = pos;
+    }
+    __syncthreads();
+    const uint32_t rpe = ((d.nrows + 8) >> 3) << 3;
+    for (uint32_t i = threadIdx.x; i < rpe; i += 64) {
+        uint32_t e = 0;
+        if (i < d.nrows) {
+            const uint32_t L = (uint32_t)((uint64_t)row_ptr[d.r0 + i + 1] - (uint64_t)row_ptr[d.r0 + i]);
+            e = s_start[i] | (((L + 3u) & ~3u) - L);
+        } else if (i == d.nrows) {
+            e = s_start[i];
+        }
+        blk[i] = (uint16_t)e;
+    }
+    uint16_t *cb = blk + rpe;
+    const uint16_t zero_off = (uint16_t)(win * 8u);
+    for (uint32_t r = 0; r < d.nrows; ++r) { // rows are short: one wave sweeps a row at a time
+        const uint64_t b = row_ptr[d.r0 + r];
+        const uint32_t L = (uint32_t)((uint64_t)row_ptr[d.r0 + r + 1] - b), L4 = (L + 3u) & ~3u;
+        for (uint32_t j = threadIdx.x; j < L4; j += 64)
+            cb[s_start[r] + j] = j < L ? (uint16_t)((col_idx[b + j] - d.wbase) * 8u) : zero_off;
+    }
+    const uint32_t ce = ((d.nnz4 + 7) >> 3) << 3;
+    for (uint32_t j = d.nnz4 + threadIdx.x; j < ce; j += 64) cb[j] = zero_off;
+}
+
+template <typename IdxT, bool HAS_K, int ELEMS, int WIN, int BS, int RC, int MODE>
+__global__ __launch_bounds__(BS) void k_sample16(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
+                                                 const uint32_t *__restrict__ kmult, const S16Tile *__restrict__ tiles,
+                                                 const uint64_t *__restrict__ chunk_tile, const double *__restrict__ gmu,
+                                                 const u32x4 *__restrict__ stream16, int32_t *gcnt, SampleArgs a)
+{
+    constexpr int ROWS_CAP = RC;
+    constexpr int RPCH = (ROWS_CAP + 8) / 8;                         // chunks of row entries
+    constexpr int NC = (RPCH + ELEMS / 8 + BS - 1) / BS;             // 16-byte chunks per thread
+    constexpr int NK = (ROWS_CAP + BS - 1) / BS;
+    static_assert((uint32_t)WIN * 8u + 8u < 65536u, "window offsets must fit 16 bits");
+    __shared__ __attribute__((aligned(16))) uint32_t s_col[ELEMS + 8];
+    __shared__ __attribute__((aligned(16))) uint32_t s_rp[RPCH * 8];
+    __shared__ __attribute__((aligned(16))) double s_mu[WIN + 2];    // [WIN] stays 0.0: what pad slots read
+    __shared__ uint32_t s_k[HAS_K ? ROWS_CAP : 1];
+    __shared__ int32_t s_cnt[WIN];
+    const int tid = threadIdx.x;
+
+    const uint64_t t_begin = chunk_tile[blockIdx.x], t_end = chunk_tile[blockIdx.x + 1];
+    if (t_begin >= t_end) return;
+    const uint64_t nt = t_end - t_begin;
+    const S16Tile *__restrict__ T = tiles + t_begin;
+
+    for (int i = tid; i < WIN; i += BS) s_cnt[i] = 0;
+    if (tid < 2) s_mu[WIN + tid] = 0.0;
+
+    auto flush_window = [&](uint32_t base) {
+        for (int i = tid; i < WIN; i += BS) {
+            const int32_t v = s_cnt[i];
+            if (v) { global_count_add(gcnt, base + (uint32_t)i, v); s_cnt[i] = 0; }
+        }
+    };
+    auto load_window = [&](uint32_t base) {
+        for (int i = tid; i < WIN; i += BS) {
+            const uint32_t c = base + (uint32_t)i;
+            s_mu[i] = c < a.n ? gmu[c] : 0.0;
+        }
+    };
+
+    struct Buf {
+        u32x4 pc[NC];
+        uint32_t pk[HAS_K ? NK : 1];
+    };
+    // request a tile's block: raw values only, unconditional loads with clamped indices
+    auto issue = [&](const S16Tile &d, Buf &bf) {
+        if (!(d.flags & S16_FAST)) return; // uniform
+        const uint32_t nch = ((d.nrows + 8) >> 3) + ((d.nnz4 + 7) >> 3);
+        const u32x4 *__restrict__ src = stream16 + d.s16;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const uint32_t ch = min((uint32_t)tid + (uint32_t)i * BS, nch - 1);
+            bf.pc[i] = __builtin_nontemporal_load(src + ch);
+        }
+        if (HAS_K) {
+#pragma unroll
+            for (int i = 0; i < NK; ++i) bf.pk[i] = kmult[d.r0 + min((uint32_t)tid + (uint32_t)i * BS, d.nrows - 1)];
+        }
+    };
+    // unpack the block into LDS: u16 -> u32, nothing else
+    auto commit = [&](const S16Tile &d, const Buf &bf) {
+        const uint32_t rpch = (d.nrows + 8) >> 3, nch = rpch + ((d.nnz4 + 7) >> 3);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const uint32_t ch = (uint32_t)tid + (uint32_t)i * BS;
+            const u32x4 v = bf.pc[i];
+            const u32x4 lo = {v.x & 0xffffu, v.x >> 16, v.y & 0xffffu, v.y >> 16};
+            const u32x4 hi = {v.z & 0xffffu, v.z >> 16, v.w & 0xffffu, v.w >> 16};
+            if (ch < rpch) {
+                *(u32x4 *)(s_rp + 8 * ch) = lo;
+                *(u32x4 *)(s_rp + 8 * ch + 4) = hi;
+            } else if (ch < nch) {
+                const uint32_t at = 8 * (ch - rpch);
+                *(u32x4 *)(s_col + at) = lo;
+                *(u32x4 *)(s_col + at + 4) = hi;
+            }
+        }
+        if (HAS_K) {
+#pragma unroll
+            for (int i = 0; i < NK; ++i) {
+                const uint32_t idx = (uint32_t)tid + (uint32_t)i * BS;
+                if (idx < d.nrows) s_k[idx] = bf.pk[i];
+            }
+        }
+    };
+
+    // one tile: (window slide) -> commit its buffer -> refill the buffer with the tile two ahead -> walk the rows
+    auto process = [&](const S16Tile &d, uint32_t prev_base, const S16Tile &refill, Buf &bf) {
+        if (d.flags & S16_EMPTY) { issue(refill, bf); return; }
+        if (d.flags & S16_SHIFT) { flush_window(prev_base); load_window(d.wbase); }
+        if (d.flags & S16_FAST) {
+            commit(d, bf);
+            issue(refill, bf);
+            __syncthreads();
+            if (MODE & K1M_NO_PHASE2) {
+                for (uint32_t r = tid; r < d.nrows; r += BS) atomicAdd(&s_cnt[(s_col[s_rp[r] & ~3u] >> 3) & (WIN - 1)], 1);
+            } else {
+                auto add = [&](uint32_t off, int32_t x) { atomicAdd((int32_t *)((char *)s_cnt + (off >> 1)), x); };
+                for (uint32_t r = tid; r < d.nrows; r += BS) {
+                    const uint32_t e0 = s_rp[r], e1 = s_rp[r + 1];
+                    const uint32_t b = e0 & ~3u, L4 = (e1 & ~3u) - b;
+                    RowView4 v{s_col + b, L4, L4 - (e0 & 3u), s_mu};
+                    allocate_row<HAS_K>(v, add, HAS_K ? s_k[r] : 1u, a, a.row_id_base + d.r0 + r);
+                }
+            }
+            __syncthreads();
+            return;
+        }
+        // slow tile: rows straight from the 32-bit CSR (window lookups / LDS counts where possible)
+        issue(refill, bf);
+        __syncthreads(); // the window (re)load above must be visible
+        const uint32_t wbase = d.wbase;
+        auto add = [&](uint32_t c, int32_t x) {
+            const uint32_t dd = c - wbase;
+            if (dd < (uint32_t)WIN) atomicAdd(&s_cnt[dd], x);
+            else global_count_add(gcnt, c, x);
+        };
+        for (uint32_t r = tid; r < d.nrows; r += BS) {
+            const uint64_t st = (uint64_t)row_ptr[d.r0 + r];
+            RowViewGlobalWin<WIN> v{col_idx + st, (uint32_t)((uint64_t)row_ptr[d.r0 + r + 1] - st), wbase, s_mu, gmu};
+            allocate_row<HAS_K>(v, add, HAS_K ? kmult[d.r0 + r] : 1u, a, a.row_id_base + d.r0 + r);
+        }
+        __syncthreads();
+    };
+
+    S16Tile none;
+    none.s16 = 0; none.r0 = 0; none.nrows = 0; none.nnz4 = 0; none.wbase = 0; none.flags = S16_EMPTY;
+    auto tile_at = [&](uint64_t i) { return i < nt ? T[i] : none; };
+
+    S16Tile dA = tile_at(0), dB = tile_at(1);
+    Buf bufA, bufB; // A: even tiles of the range, B: odd tiles
+    issue(dA, bufA);
+    issue(dB, bufB);
+    load_window(dA.wbase); // the first tile's window (its SHIFT flag is never set)
+    uint32_t cur_base = dA.wbase; // window base in force = wbase of the tile processed last
+    for (uint64_t i = 0; i < nt; i += 2) {
+        const S16Tile nA = tile_at(i + 2), nB = tile_at(i + 3); // scalar loads: in flight while A and B are walked
+        process(dA, cur_base, nA, bufA);
+        cur_base = dA.wbase;
+        if (i + 1 < nt) {
+            process(dB, cur_base, nB, bufB);
+            cur_base = dB.wbase;
+        }
+        dA = nA;
+        dB = nB;
+    }
+    flush_window(cur_base);
 }
 
 struct UpdateArgs {

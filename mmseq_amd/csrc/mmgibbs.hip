@@ -21,7 +21,7 @@ struct K1Variant { int elems, win, unr, mode, bs, rows; }; // rows: host-side ca
     X(3, 2048, 1024, 4, 0, 256, 0) \
     X(4, 4096, 2048, 8, 0, 256, 0) \
     X(5, 4096, 2048, 1, 0, 256, 0) \
-    X(6, 4096, 2048, 4, K1M_NO_PHASE2, 256, 0) \
+    X(6, 2560, 256, 4, K1M_NO_PHASE2, 128, 128) \
     X(7, 8192, 2048, 8, 0, 256, 0) \
     X(8, 5120, 1024, 4, 0, 256, 0) \
     X(9, 5120, 512, 4, 0, 256, 0) \
@@ -46,6 +46,27 @@ static const K1Variant k1_variants[] = {
     K1_VARIANT_LIST(X)
 #undef X
 };
+// 16-bit-stream kernel instances, keyed by the k_sample variant whose tile caps they share
+template <typename IdxT, bool HAS_K>
+static const void *k1_s16_kernel_for(int variant)
+{
+    switch (variant) {
+    case 21: return (const void *)&k_sample16<IdxT, HAS_K, 2560, 256, 128, 128, 0>;
+    case 22: return (const void *)&k_sample16<IdxT, HAS_K, 2560, 384, 128, 128, 0>;
+    case 23: return (const void *)&k_sample16<IdxT, HAS_K, 3072, 256, 128, 128, 0>;
+    case 24: return (const void *)&k_sample16<IdxT, HAS_K, 4096, 512, 256, 256, 0>;
+    case 20: return (const void *)&k_sample16<IdxT, HAS_K, 1280, 256, 64, 64, 0>;
+    case 18: return (const void *)&k_sample16<IdxT, HAS_K, 2560, 512, 128, 128, 0>;
+    case 6: return (const void *)&k_sample16<IdxT, HAS_K, 2560, 256, 128, 128, K1M_NO_PHASE2>; // ablation
+    }
+    return nullptr;
+}
+static const void *k1_s16_kernel(int variant, bool idx64, bool has_k)
+{
+    if (idx64) return has_k ? k1_s16_kernel_for<uint64_t, true>(variant) : k1_s16_kernel_for<uint64_t, false>(variant);
+    return has_k ? k1_s16_kernel_for<uint32_t, true>(variant) : k1_s16_kernel_for<uint32_t, false>(variant);
+}
+
 static const int k1_n_variants = (int)(sizeof(k1_variants) / sizeof(k1_variants[0]));
 static const int K1_DEFAULT_VARIANT = 21;
 
@@ -117,6 +138,13 @@ struct mmg_problem {
     uint32_t *d_k = nullptr;
     double *d_l = nullptr;
     TileDesc *d_tiles = nullptr;
+    uint16_t *d_stream16 = nullptr; // 16-bit tile stream of k_sample16 (built by k_encode16)
+    uint64_t stream16_bytes = 0;
+    S16Tile *d_s16tiles = nullptr;
+    uint64_t *d_chunk_tile16 = nullptr;
+    int grid16 = 0;
+    bool use16 = false;
+    double s16_fast_fraction = 0.0;
     uint64_t *d_col_ptr = nullptr; // CSC transpose for the deterministic EM (lazy)
     uint32_t *d_row_of = nullptr;
     uint64_t *d_chunk_tile = nullptr;
@@ -136,6 +164,9 @@ static void problem_free(mmg_problem *p)
     if (p->d_k) (void)hipFree(p->d_k);
     if (p->d_l) (void)hipFree(p->d_l);
     if (p->d_tiles) (void)hipFree(p->d_tiles);
+    if (p->d_stream16) (void)hipFree(p->d_stream16);
+    if (p->d_s16tiles) (void)hipFree(p->d_s16tiles);
+    if (p->d_chunk_tile16) (void)hipFree(p->d_chunk_tile16);
     if (p->d_col_ptr) (void)hipFree(p->d_col_ptr);
     if (p->d_row_of) (void)hipFree(p->d_row_of);
     if (p->d_chunk_tile) (void)hipFree(p->d_chunk_tile);
@@ -151,14 +182,14 @@ static void build_tiles(const uint64_t *row_ptr, uint64_t m, uint64_t tile_nnz, 
     uint64_t cur_nnz = 0, cur_rows = 0;
     max_len = 0;
     for (uint64_t r = 0; r < m; ++r) {
-        const uint64_t L = row_ptr[r + 1] - row_ptr[r];
+        const uint64_t L = row_ptr[r + 1] - row_ptr[r], L4 = (L + 3) & ~(uint64_t)3; // the 16-bit stream pads rows to 4 hits
         if (L > max_len) max_len = (uint32_t)std::min<uint64_t>(L, 0xffffffffu);
-        if (cur_rows > 0 && (cur_nnz + L > tile_nnz || cur_rows >= tile_rows)) {
+        if (cur_rows > 0 && (cur_nnz + L4 > tile_nnz || cur_rows >= tile_rows)) {
             tile_row.push_back(r);
             cur_nnz = 0;
             cur_rows = 0;
         }
-        cur_nnz += L;
+        cur_nnz += L4;
         cur_rows += 1;
     }
     if (m > 0) tile_row.push_back(m);
@@ -236,6 +267,69 @@ static int problem_build_desc(mmg_problem *p)
         (void)hipFree(d_tile_row);
         if (e != hipSuccess) return fail(MMG_ERR_HIP, std::string("tile descriptors: ") + hipGetErrorString(e));
         p->device_bytes += p->n_tiles * sizeof(TileDesc);
+        // ---- 16-bit stream kernel: grid, contiguous tile ranges, per-tile window policy, stream placement, encode
+        const void *k16 = k1_s16_kernel(p->variant, p->idx64, p->d_k != nullptr);
+        const char *ev16 = getenv("MMG_K1_S16");
+        if (p->n_tiles && k16 && !(ev16 && atoi(ev16) == 0)) {
+            const K1Variant &kv = k1_variants[p->variant];
+            std::vector<TileDesc> td(p->n_tiles);
+            HIP_TRY(hipMemcpy(td.data(), p->d_tiles, p->n_tiles * sizeof(TileDesc), hipMemcpyDeviceToHost));
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k16, kv.bs, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 4; }
+            if (per_cu > 2048 / kv.bs) per_cu = 2048 / kv.bs;
+            if (const char *e2 = getenv("MMG_K1_BLOCKS_PER_CU")) { const int v = atoi(e2); if (v >= 1 && v <= 32) per_cu = v; }
+            const uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>(p->n_tiles, (uint64_t)p->cu_count * per_cu));
+            std::vector<uint64_t> chunk(grid + 1);
+            for (uint64_t c = 0; c <= grid; ++c) chunk[c] = (uint64_t)(((unsigned __int128)p->n_tiles * c) / grid);
+            std::vector<S16Tile> st(p->n_tiles);
+            uint64_t n_fast = 0, n_live = 0, pos = 0;
+            const uint32_t WIN = (uint32_t)kv.win;
+            const uint32_t rows_cap = kv.rows > 0 ? (uint32_t)std::min(kv.rows, kv.elems / 4) : (uint32_t)kv.elems / 4;
+            for (uint64_t c = 0; c < grid; ++c) {
+                bool have = false;
+                uint32_t cur = 0;
+                for (uint64_t t = chunk[c]; t < chunk[c + 1]; ++t) if (td[t].nnz) { cur = td[t].cmin & ~15u; break; }
+                for (uint64_t t = chunk[c]; t < chunk[c + 1]; ++t) {
+                    const TileDesc &d = td[t];
+                    S16Tile &q = st[t];
+                    q.s16 = 0; q.r0 = d.r0; q.nrows = d.nrows; q.nnz4 = d.nnz4; q.flags = 0;
+                    if (d.nnz == 0) { q.flags = S16_EMPTY; q.wbase = cur; continue; }
+                    const bool keep = have && d.cmin >= cur && (uint64_t)d.clast + K1_WIN_MARGIN <= (uint64_t)cur + WIN;
+                    if (!keep) {
+                        const uint32_t nb = d.cmin & ~15u;
+                        if (have && nb != cur) q.flags |= S16_SHIFT;
+                        cur = nb;
+                        have = true;
+                    }
+                    q.wbase = cur;
+                    const bool inwin = d.call >= cur && (uint64_t)d.cmax < (uint64_t)cur + WIN;
+                    if (inwin && d.nrows <= rows_cap && d.nnz4 <= (uint32_t)kv.elems && d.nnz4 > 0) {
+                        q.flags |= S16_FAST;
+                        q.s16 = pos;
+                        pos += ((d.nrows + 8) >> 3) + ((d.nnz4 + 7) >> 3);
+                        ++n_fast;
+                    }
+                    ++n_live;
+                }
+            }
+            p->s16_fast_fraction = n_live ? (double)n_fast / (double)n_live : 0.0;
+            p->use16 = p->s16_fast_fraction >= 0.9 || (ev16 && atoi(ev16) == 2);
+            if (p->use16) {
+                p->stream16_bytes = pos * 16;
+                HIP_TRY(hipMalloc((void **)&p->d_stream16, p->stream16_bytes + 64));
+                HIP_TRY(hipMemset(p->d_stream16, 0, p->stream16_bytes + 64));
+                HIP_TRY(hipMalloc((void **)&p->d_s16tiles, p->n_tiles * sizeof(S16Tile)));
+                HIP_TRY(hipMemcpy(p->d_s16tiles, st.data(), p->n_tiles * sizeof(S16Tile), hipMemcpyHostToDevice));
+                HIP_TRY(hipMalloc((void **)&p->d_chunk_tile16, chunk.size() * sizeof(uint64_t)));
+                HIP_TRY(hipMemcpy(p->d_chunk_tile16, chunk.data(), chunk.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+                if (p->idx64) hipLaunchKernelGGL(k_encode16<uint64_t>, dim3((unsigned)p->n_tiles), dim3(64), 0, 0, (const uint64_t *)p->d_row_ptr, p->d_col, p->d_s16tiles, p->n_tiles, WIN, p->d_stream16);
+                else hipLaunchKernelGGL(k_encode16<uint32_t>, dim3((unsigned)p->n_tiles), dim3(64), 0, 0, (const uint32_t *)p->d_row_ptr, p->d_col, p->d_s16tiles, p->n_tiles, WIN, p->d_stream16);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipDeviceSynchronize());
+                p->grid16 = (int)grid;
+                p->device_bytes += p->stream16_bytes + p->n_tiles * sizeof(S16Tile);
+            }
+        }
         std::vector<uint64_t>().swap(tiles);
     return MMG_OK;
 }
@@ -650,8 +744,16 @@ extern "C" int mmg_sampler_sample(mmg_sampler *s)
             const uint64_t *ct = p->d_chunk_tile;
             const double *mu = s->d_mu + (size_t)c * p->n;
             int32_t *cnt = s->d_cnt + (size_t)c * p->n;
-            void *kargs[] = {(void *)&rp, (void *)&ci, (void *)&kk, (void *)&td, (void *)&ct, (void *)&mu, (void *)&cnt, (void *)&a};
-            HIP_TRY(hipLaunchKernel(k1_kernel(p->variant, p->idx64, p->d_k != nullptr), dim3(p->grid_sample), dim3(k1_variants[p->variant].bs), kargs, 0, s->cur));
+            if (p->use16) {
+                const S16Tile *t16 = p->d_s16tiles;
+                const uint64_t *c16 = p->d_chunk_tile16;
+                const void *s16 = p->d_stream16;
+                void *kargs[] = {(void *)&rp, (void *)&ci, (void *)&kk, (void *)&t16, (void *)&c16, (void *)&mu, (void *)&s16, (void *)&cnt, (void *)&a};
+                HIP_TRY(hipLaunchKernel(k1_s16_kernel(p->variant, p->idx64, p->d_k != nullptr), dim3(p->grid16), dim3(k1_variants[p->variant].bs), kargs, 0, s->cur));
+            } else {
+                void *kargs[] = {(void *)&rp, (void *)&ci, (void *)&kk, (void *)&td, (void *)&ct, (void *)&mu, (void *)&cnt, (void *)&a};
+                HIP_TRY(hipLaunchKernel(k1_kernel(p->variant, p->idx64, p->d_k != nullptr), dim3(p->grid_sample), dim3(k1_variants[p->variant].bs), kargs, 0, s->cur));
+            }
         }
         HIP_TRY(hipGetLastError());
     }

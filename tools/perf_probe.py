@@ -51,5 +51,6 @@ if __name__ == "__main__":
         else:
             os.environ.pop("MMG_K1_BLOCKS_PER_CU", None)
         ok = parity(v) if v != 6 else None
-        probe(5_000_000, 50_000, 8, tag=f"[v{spec} parity={ok}]", check=(v != 6))
-        probe(50_000_000, 200_000, 20, iters=10, tag=f"[v{spec} parity={ok}]", check=(v != 6))
+        tag = f"[v{spec} s16={os.environ.get('MMG_K1_S16', '1')} parity={ok}]"
+        probe(5_000_000, 50_000, 8, tag=tag, check=(v != 6))
+        probe(50_000_000, 200_000, 20, iters=10, tag=tag, check=(v != 6))
