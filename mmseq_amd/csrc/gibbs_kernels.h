@@ -579,7 +579,91 @@ __global__ __launch_bounds__(64) void k_encode16(const IdxT *__restrict__ row_pt
     for (uint32_t j = d.nnz4 + threadIdx.x; j < ce; j += 64) cb[j] = zero_off;
 }
 
-template <typename IdxT, bool HAS_K, int ELEMS, int WIN, int BS, int RC, int MODE>
+// Fused walk of C chains over one row (k == 1): the row's offsets are read once per group and feed C
+// independent accumulation chains (window c lives at s_mu + c*MU_STRIDE doubles, counts at
+// s_cnt + c*WIN).  Every chain performs exactly the additions of the single-chain walk, in the same
+// order, and draws from its own keyed stream, so chain c is bit-identical to a C = 1 run.
+template <int C, int WIN, int MU_STRIDE>
+__device__ __forceinline__ void walk_row_fused(const uint32_t *cl, uint32_t L4, uint32_t L, const double *s_mu, int32_t *s_cnt,
+                                               const SampleArgs &a, uint64_t row_id)
+{
+    if (L == 0) return;
+    if (L == 1) {
+        const uint32_t off = cl[0];
+#pragma unroll
+        for (int c = 0; c < C; ++c) atomicAdd((int32_t *)((char *)(s_cnt + c * WIN) + (off >> 1)), 1);
+        return;
+    }
+    const u32x4 *g = (const u32x4 *)cl;
+    const uint32_t ng = L4 >> 2;
+    double t[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) t[c] = 0.0;
+    u32x4 o = g[0];
+    for (uint32_t i = 0; i < ng; ++i) {
+        double w[C][4];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const char *m = (const char *)(s_mu + c * MU_STRIDE);
+            w[c][0] = *(const double *)(m + o.x); w[c][1] = *(const double *)(m + o.y);
+            w[c][2] = *(const double *)(m + o.z); w[c][3] = *(const double *)(m + o.w);
+        }
+        o = g[i + 1];
+#pragma unroll
+        for (int c = 0; c < C; ++c) { t[c] += w[c][0]; t[c] += w[c][1]; t[c] += w[c][2]; t[c] += w[c][3]; }
+    }
+    double target[C];
+    uint32_t sel[C];
+    bool pending[C];
+    bool any = false;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        Stream2 s(a.seed, a.chain + (uint32_t)c, TAG_ROW, row_id, a.iter);
+        const double u = s.next();
+        const bool degenerate = !(t[c] > 0.0) || !(t[c] < __builtin_huge_val());
+        if (degenerate) {
+            uint32_t j = (uint32_t)(u * (double)L);
+            sel[c] = j < L ? j : L - 1;
+            pending[c] = false;
+        } else {
+            target[c] = u * t[c];
+            sel[c] = L - 1;
+            pending[c] = true;
+            any = true;
+        }
+    }
+    if (any) {
+        double acc[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = 0.0;
+        o = g[0];
+        for (uint32_t i = 0; i < ng && any; ++i) {
+            double w[C][4];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const char *m = (const char *)(s_mu + c * MU_STRIDE);
+                w[c][0] = *(const double *)(m + o.x); w[c][1] = *(const double *)(m + o.y);
+                w[c][2] = *(const double *)(m + o.z); w[c][3] = *(const double *)(m + o.w);
+            }
+            o = g[i + 1];
+            any = false;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const double p0 = acc[c] + w[c][0], p1 = p0 + w[c][1], p2 = p1 + w[c][2], p3 = p2 + w[c][3];
+                if (pending[c] && target[c] < p3) {
+                    sel[c] = 4 * i + (target[c] < p0 ? 0u : (target[c] < p1 ? 1u : (target[c] < p2 ? 2u : 3u)));
+                    pending[c] = false;
+                }
+                acc[c] = p3;
+                any = any || pending[c];
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) atomicAdd((int32_t *)((char *)(s_cnt + c * WIN) + (cl[sel[c]] >> 1)), 1);
+}
+
+template <typename IdxT, bool HAS_K, int ELEMS, int WIN, int BS, int RC, int MODE, int C = 1>
 __global__ __launch_bounds__(BS) void k_sample16(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
                                                  const uint32_t *__restrict__ kmult, const S16Tile *__restrict__ tiles,
                                                  const uint64_t *__restrict__ chunk_tile, const double *__restrict__ gmu,
@@ -592,9 +676,10 @@ __global__ __launch_bounds__(BS) void k_sample16(const IdxT *__restrict__ row_pt
     static_assert((uint32_t)WIN * 8u + 8u < 65536u, "window offsets must fit 16 bits");
     __shared__ __attribute__((aligned(16))) uint32_t s_col[ELEMS + 8];
     __shared__ __attribute__((aligned(16))) uint32_t s_rp[RPCH * 8];
-    __shared__ __attribute__((aligned(16))) double s_mu[WIN + 2];    // [WIN] stays 0.0: what pad slots read
+    constexpr int MU_STRIDE = WIN + 2;                               // per-chain window; [WIN] stays 0.0: what pad slots read
+    __shared__ __attribute__((aligned(16))) double s_mu[C * MU_STRIDE];
     __shared__ uint32_t s_k[HAS_K ? ROWS_CAP : 1];
-    __shared__ int32_t s_cnt[WIN];
+    __shared__ int32_t s_cnt[C * WIN];
     const int tid = threadIdx.x;
 
     const uint64_t t_begin = chunk_tile[blockIdx.x], t_end = chunk_tile[blockIdx.x + 1];
@@ -602,19 +687,20 @@ __global__ __launch_bounds__(BS) void k_sample16(const IdxT *__restrict__ row_pt
     const uint64_t nt = t_end - t_begin;
     const S16Tile *__restrict__ T = tiles + t_begin;
 
-    for (int i = tid; i < WIN; i += BS) s_cnt[i] = 0;
-    if (tid < 2) s_mu[WIN + tid] = 0.0;
+    for (int i = tid; i < C * WIN; i += BS) s_cnt[i] = 0;
+    if (tid < 2 * C) s_mu[(tid >> 1) * MU_STRIDE + WIN + (tid & 1)] = 0.0;
 
+    // chain c of this launch: mu at gmu + c*n, counts at gcnt + c*n (chain-major, as k_update expects)
     auto flush_window = [&](uint32_t base) {
-        for (int i = tid; i < WIN; i += BS) {
+        for (int i = tid; i < C * WIN; i += BS) {
             const int32_t v = s_cnt[i];
-            if (v) { global_count_add(gcnt, base + (uint32_t)i, v); s_cnt[i] = 0; }
+            if (v) { global_count_add(gcnt + (size_t)(i / WIN) * a.n, base + (uint32_t)(i % WIN), v); s_cnt[i] = 0; }
         }
     };
     auto load_window = [&](uint32_t base) {
-        for (int i = tid; i < WIN; i += BS) {
-            const uint32_t c = base + (uint32_t)i;
-            s_mu[i] = c < a.n ? gmu[c] : 0.0;
+        for (int i = tid; i < C * WIN; i += BS) {
+            const uint32_t c = base + (uint32_t)(i % WIN);
+            s_mu[(i / WIN) * MU_STRIDE + (i % WIN)] = c < a.n ? gmu[(size_t)(i / WIN) * a.n + c] : 0.0;
         }
     };
 
@@ -673,14 +759,25 @@ __global__ __launch_bounds__(BS) void k_sample16(const IdxT *__restrict__ row_pt
             issue(refill, bf);
             __syncthreads();
             if (MODE & K1M_NO_PHASE2) {
-                for (uint32_t r = tid; r < d.nrows; r += BS) atomicAdd(&s_cnt[(s_col[s_rp[r] & ~3u] >> 3) & (WIN - 1)], 1);
+                for (uint32_t r = tid; r < d.nrows; r += BS) atomicAdd(&s_cnt[(s_col[s_rp[r] & ~3u] >> 3) & (WIN - 1)], C);
             } else {
-                auto add = [&](uint32_t off, int32_t x) { atomicAdd((int32_t *)((char *)s_cnt + (off >> 1)), x); };
                 for (uint32_t r = tid; r < d.nrows; r += BS) {
                     const uint32_t e0 = s_rp[r], e1 = s_rp[r + 1];
                     const uint32_t b = e0 & ~3u, L4 = (e1 & ~3u) - b;
-                    RowView4 v{s_col + b, L4, L4 - (e0 & 3u), s_mu};
-                    allocate_row<HAS_K>(v, add, HAS_K ? s_k[r] : 1u, a, a.row_id_base + d.r0 + r);
+                    const uint32_t kk = HAS_K ? s_k[r] : 1u;
+                    if (C > 1 && kk == 1) {
+                        walk_row_fused<C, WIN, MU_STRIDE>(s_col + b, L4, L4 - (e0 & 3u), s_mu, s_cnt, a, a.row_id_base + d.r0 + r);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < C; ++c) { // one chain at a time (always the case for C == 1)
+                            int32_t *cc = s_cnt + c * WIN;
+                            auto add = [&](uint32_t off, int32_t x) { atomicAdd((int32_t *)((char *)cc + (off >> 1)), x); };
+                            SampleArgs ac = a;
+                            ac.chain = a.chain + (uint32_t)c;
+                            RowView4 v{s_col + b, L4, L4 - (e0 & 3u), s_mu + c * MU_STRIDE};
+                            allocate_row<HAS_K>(v, add, kk, ac, a.row_id_base + d.r0 + r);
+                        }
+                    }
                 }
             }
             __syncthreads();
@@ -690,15 +787,23 @@ __global__ __launch_bounds__(BS) void k_sample16(const IdxT *__restrict__ row_pt
         issue(refill, bf);
         __syncthreads(); // the window (re)load above must be visible
         const uint32_t wbase = d.wbase;
-        auto add = [&](uint32_t c, int32_t x) {
-            const uint32_t dd = c - wbase;
-            if (dd < (uint32_t)WIN) atomicAdd(&s_cnt[dd], x);
-            else global_count_add(gcnt, c, x);
-        };
         for (uint32_t r = tid; r < d.nrows; r += BS) {
             const uint64_t st = (uint64_t)row_ptr[d.r0 + r];
-            RowViewGlobalWin<WIN> v{col_idx + st, (uint32_t)((uint64_t)row_ptr[d.r0 + r + 1] - st), wbase, s_mu, gmu};
-            allocate_row<HAS_K>(v, add, HAS_K ? kmult[d.r0 + r] : 1u, a, a.row_id_base + d.r0 + r);
+            const uint32_t L = (uint32_t)((uint64_t)row_ptr[d.r0 + r + 1] - st);
+            const uint32_t kk = HAS_K ? kmult[d.r0 + r] : 1u;
+            for (int c = 0; c < C; ++c) {
+                int32_t *cc = s_cnt + c * WIN;
+                int32_t *gc = gcnt + (size_t)c * a.n;
+                auto add = [&](uint32_t col, int32_t x) {
+                    const uint32_t dd = col - wbase;
+                    if (dd < (uint32_t)WIN) atomicAdd(&cc[dd], x);
+                    else global_count_add(gc, col, x);
+                };
+                SampleArgs ac = a;
+                ac.chain = a.chain + (uint32_t)c;
+                RowViewGlobalWin<WIN> v{col_idx + st, L, wbase, s_mu + c * MU_STRIDE, gmu + (size_t)c * a.n};
+                allocate_row<HAS_K>(v, add, kk, ac, a.row_id_base + d.r0 + r);
+            }
         }
         __syncthreads();
     };

@@ -48,8 +48,12 @@ static const K1Variant k1_variants[] = {
 };
 // 16-bit-stream kernel instances, keyed by the k_sample variant whose tile caps they share
 template <typename IdxT, bool HAS_K>
-static const void *k1_s16_kernel_for(int variant)
+static const void *k1_s16_kernel_for(int variant, int fuse = 1)
 {
+    if (variant == 21 && fuse == 2) return (const void *)&k_sample16<IdxT, HAS_K, 2560, 256, 128, 128, 0, 2>;
+    if (variant == 21 && fuse == 4) return (const void *)&k_sample16<IdxT, HAS_K, 2560, 256, 128, 128, 0, 4>;
+    if (variant == 21 && fuse == 8) return (const void *)&k_sample16<IdxT, HAS_K, 2560, 256, 128, 128, 0, 8>;
+    if (fuse != 1) return nullptr;
     switch (variant) {
     case 21: return (const void *)&k_sample16<IdxT, HAS_K, 2560, 256, 128, 128, 0>;
     case 22: return (const void *)&k_sample16<IdxT, HAS_K, 2560, 384, 128, 128, 0>;
@@ -61,10 +65,10 @@ static const void *k1_s16_kernel_for(int variant)
     }
     return nullptr;
 }
-static const void *k1_s16_kernel(int variant, bool idx64, bool has_k)
+static const void *k1_s16_kernel(int variant, bool idx64, bool has_k, int fuse = 1)
 {
-    if (idx64) return has_k ? k1_s16_kernel_for<uint64_t, true>(variant) : k1_s16_kernel_for<uint64_t, false>(variant);
-    return has_k ? k1_s16_kernel_for<uint32_t, true>(variant) : k1_s16_kernel_for<uint32_t, false>(variant);
+    if (idx64) return has_k ? k1_s16_kernel_for<uint64_t, true>(variant, fuse) : k1_s16_kernel_for<uint64_t, false>(variant, fuse);
+    return has_k ? k1_s16_kernel_for<uint32_t, true>(variant, fuse) : k1_s16_kernel_for<uint32_t, false>(variant, fuse);
 }
 
 static const int k1_n_variants = (int)(sizeof(k1_variants) / sizeof(k1_variants[0]));
@@ -733,7 +737,15 @@ extern "C" int mmg_sampler_sample(mmg_sampler *s)
         HIP_TRY(hipEventRecord(s->ev_pool[e0], s->cur));
     }
     if (p->n_tiles > 0) {
-        for (int c = 0; c < s->cfg.n_chains; ++c) {
+        int fuse_cap = 8;
+        if (const char *ev = getenv("MMG_K1_FUSE")) { fuse_cap = atoi(ev); if (fuse_cap < 1) fuse_cap = 1; }
+        for (int c = 0; c < s->cfg.n_chains;) {
+            // chains are advanced in fused groups of 8 / 4 / 2 / 1 (the walk reads each hit's offset once per group)
+            int fuse = 1;
+            if (p->use16) {
+                for (int f = 8; f > 1; f >>= 1)
+                    if (f <= fuse_cap && c + f <= s->cfg.n_chains && k1_s16_kernel(p->variant, p->idx64, p->d_k != nullptr, f)) { fuse = f; break; }
+            }
             SampleArgs a;
             a.seed = s->cfg.seed; a.row_id_base = p->row_id_base; a.n = p->n;
             a.chain = (uint32_t)(s->cfg.chain_base + c);
@@ -749,11 +761,13 @@ extern "C" int mmg_sampler_sample(mmg_sampler *s)
                 const uint64_t *c16 = p->d_chunk_tile16;
                 const void *s16 = p->d_stream16;
                 void *kargs[] = {(void *)&rp, (void *)&ci, (void *)&kk, (void *)&t16, (void *)&c16, (void *)&mu, (void *)&s16, (void *)&cnt, (void *)&a};
-                HIP_TRY(hipLaunchKernel(k1_s16_kernel(p->variant, p->idx64, p->d_k != nullptr), dim3(p->grid16), dim3(k1_variants[p->variant].bs), kargs, 0, s->cur));
+                // fused instances need more LDS per workgroup: fewer fit per CU, the tile ranges stay those of grid16
+                HIP_TRY(hipLaunchKernel(k1_s16_kernel(p->variant, p->idx64, p->d_k != nullptr, fuse), dim3(p->grid16), dim3(k1_variants[p->variant].bs), kargs, 0, s->cur));
             } else {
                 void *kargs[] = {(void *)&rp, (void *)&ci, (void *)&kk, (void *)&td, (void *)&ct, (void *)&mu, (void *)&cnt, (void *)&a};
                 HIP_TRY(hipLaunchKernel(k1_kernel(p->variant, p->idx64, p->d_k != nullptr), dim3(p->grid_sample), dim3(k1_variants[p->variant].bs), kargs, 0, s->cur));
             }
+            c += fuse;
         }
         HIP_TRY(hipGetLastError());
     }

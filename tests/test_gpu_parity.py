@@ -288,3 +288,16 @@ def test_64bit_row_offsets_path(gpu, orc, monkeypatch):
     q, _ = orc.synth_problem(R=5000, T=300, avg_hits=6, seed=1234)
     rp, ci = syn.download()
     assert np.array_equal(rp, q.row_ptr) and np.array_equal(ci, q.col_idx)
+
+
+@pytest.mark.parametrize("n_chains", [2, 4, 8, 11])
+def test_fused_chains_equal_independent_single_chains(gpu, orc, n_chains):
+    """Chains advanced together by the fused walk (groups of 8/4/2/1) are bit-identical to single-chain runs."""
+    p, mu0, _ = _mk(orc, 40000, 1500, 9)
+    prob = gpu.Problem.from_csr(p.row_ptr, p.col_idx, p.l)
+    s = gpu.Sampler(prob, mu0, seed=21, n_chains=n_chains, chain_base=3, gibbs_iter=16, trace_len=16)
+    s.run(16)
+    for c in sorted({0, 1, n_chains // 2, n_chains - 1}):
+        ref = orc.gibbs_keyed(p, mu0, seed=21, chain=3 + c, n_iter=16, trace_len=16)
+        assert np.array_equal(s.trace(c), ref["trace"]), c
+        assert np.array_equal(s.counts(c), ref["cnt"]), c

@@ -34,7 +34,7 @@ def probe(R, T, avg, iters=20, chains=1, uniform=0, sort=True, tag="", check=Tru
     wall = (t4 - t3) / iters * 1e3
     print(f"{tag} R={R} T={T} avg={avg} C={chains} sort={sort} tiles={inf.n_tiles} gen={t1-t0:.1f}s "
           f"K1={k1:.3f}ms K2={k2:.3f}ms wall/iter={wall:.3f}ms K1 GB/s={(4*(inf.m+1)+4*inf.nnz)/k1/1e6:.0f} "
-          f"iter/s={1e3/wall:.1f} frac8TB={B/(wall*1e-3)/8e12:.3f}", flush=True)
+          f"iter/s={1e3/wall:.1f} chain-it/s={chains*1e3/wall:.1f} frac8TB={B/(wall*1e-3)/8e12:.3f}", flush=True)
     if check:
         cnt = s.counts(0)
         assert int(cnt.sum()) == inf.total_k, (cnt.sum(), inf.total_k)
@@ -42,6 +42,7 @@ def probe(R, T, avg, iters=20, chains=1, uniform=0, sort=True, tag="", check=Tru
 
 if __name__ == "__main__":
     specs = (sys.argv[1] if len(sys.argv) > 1 else "0,1,2,3,4,5,6,7").split(",")
+    chains = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     for spec in specs:
         v, _, bpc = spec.partition(":")
         v = int(v)
@@ -52,5 +53,5 @@ if __name__ == "__main__":
             os.environ.pop("MMG_K1_BLOCKS_PER_CU", None)
         ok = parity(v) if v != 6 else None
         tag = f"[v{spec} s16={os.environ.get('MMG_K1_S16', '1')} parity={ok}]"
-        probe(5_000_000, 50_000, 8, tag=tag, check=(v != 6))
-        probe(50_000_000, 200_000, 20, iters=10, tag=tag, check=(v != 6))
+        probe(5_000_000, 50_000, 8, tag=tag, check=(v != 6), chains=chains)
+        probe(50_000_000, 200_000, 20, iters=10, tag=tag, check=(v != 6), chains=chains)
