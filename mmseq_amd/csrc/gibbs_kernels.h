@@ -461,12 +461,18 @@ struct S16Tile {
 enum : uint32_t { S16_FAST = 1, S16_SHIFT = 2, S16_EMPTY = 4 };
 typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
 
-// fast path view: rows are padded to 4 hits in LDS, every group is one aligned ds_read_b128
+// fast path view: rows are padded to 4 hits in LDS, every group is one aligned ds_read_b128.
+// total() keeps the running sum at the first NGC group boundaries in registers, so pick() locates the
+// group with compares and re-reads ONE group instead of walking the row again (the walk is bound by
+// LDS throughput).  The prefix it resumes from is the very value the first pass produced, so the
+// selected hit is the one the plain sequential walk selects.
 struct RowView4 {
+    static constexpr int NGC = 8;
     const uint32_t *cl; // 16-byte aligned; reading one group past the row is harmless
     uint32_t L4;        // padded length (multiple of 4)
     uint32_t L;         // true length
     const double *s_mu;
+    mutable double P[NGC];
     __device__ __forceinline__ double wo(uint32_t off) const { return *(const double *)((const char *)s_mu + off); }
     __device__ __forceinline__ uint32_t col(uint32_t j) const { return cl[j]; } // a byte offset: add() understands it
     __device__ __forceinline__ double w(uint32_t j) const { return wo(cl[j]); }
@@ -476,27 +482,49 @@ struct RowView4 {
         const uint32_t ng = L4 >> 2;
         u32x4 o = g[0];
         double t = 0.0;
-        for (uint32_t i = 0; i < ng; ++i) {
+#pragma unroll
+        for (int i = 0; i < NGC; ++i) {
+            if ((uint32_t)i < ng) {
+                const double w0 = wo(o.x), w1 = wo(o.y), w2 = wo(o.z), w3 = wo(o.w);
+                o = g[i + 1];
+                t += w0; t += w1; t += w2; t += w3;
+            }
+            P[i] = t;
+        }
+        for (uint32_t i = NGC; i < ng; ++i) {
             const double w0 = wo(o.x), w1 = wo(o.y), w2 = wo(o.z), w3 = wo(o.w);
             o = g[i + 1];
             t += w0; t += w1; t += w2; t += w3;
         }
         return t;
     }
+    __device__ __forceinline__ uint32_t in_group(const u32x4 *g, uint32_t i, double acc, double target, double &p3) const
+    {
+        const u32x4 o = g[i];
+        const double p0 = acc + wo(o.x), p1 = p0 + wo(o.y), p2 = p1 + wo(o.z);
+        p3 = p2 + wo(o.w);
+        return target < p0 ? 0u : (target < p1 ? 1u : (target < p2 ? 2u : 3u));
+    }
     __device__ __forceinline__ uint32_t pick(double target) const
     {
         const u32x4 *g = (const u32x4 *)cl;
         const uint32_t ng = L4 >> 2;
-        u32x4 o = g[0];
-        double acc = 0.0;
-        for (uint32_t i = 0; i < ng; ++i) {
-            const double w0 = wo(o.x), w1 = wo(o.y), w2 = wo(o.z), w3 = wo(o.w);
-            o = g[i + 1];
-            const double p0 = acc + w0, p1 = p0 + w1, p2 = p1 + w2, p3 = p2 + w3;
-            if (target < p3) { // prefix sums never decrease; a zero-weight pad can never be the first to exceed
-                const uint32_t sel = target < p0 ? 0u : (target < p1 ? 1u : (target < p2 ? 2u : 3u));
-                return 4 * i + sel;
-            }
+        // first cached boundary the target falls below (prefix sums never decrease)
+        uint32_t gs = NGC;
+#pragma unroll
+        for (int i = NGC - 1; i >= 0; --i) gs = (target < P[i]) ? (uint32_t)i : gs;
+        double p3;
+        if (gs < NGC) {
+            if (gs >= ng) return L - 1; // cannot happen (P[ng-1] is the total); keeps the index in range
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < NGC - 1; ++i) acc = (gs == (uint32_t)i + 1) ? P[i] : acc;
+            return 4 * gs + in_group(g, gs, acc, target, p3);
+        }
+        double acc = P[NGC - 1];
+        for (uint32_t i = NGC; i < ng; ++i) {
+            const uint32_t sel = in_group(g, i, acc, target, p3);
+            if (target < p3) return 4 * i + sel;
             acc = p3;
         }
         return L - 1; // rounding left target >= total: the last real hit
@@ -774,7 +802,7 @@ __global__ __launch_bounds__(BS) void k_sample16(const IdxT *__restrict__ row_pt
                             auto add = [&](uint32_t off, int32_t x) { atomicAdd((int32_t *)((char *)cc + (off >> 1)), x); };
                             SampleArgs ac = a;
                             ac.chain = a.chain + (uint32_t)c;
-                            RowView4 v{s_col + b, L4, L4 - (e0 & 3u), s_mu + c * MU_STRIDE};
+                            RowView4 v{s_col + b, L4, L4 - (e0 & 3u), s_mu + c * MU_STRIDE, {}};
                             allocate_row<HAS_K>(v, add, kk, ac, a.row_id_base + d.r0 + r);
                         }
                     }
