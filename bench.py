@@ -191,6 +191,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_sample (K1)", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(args, C),
                          "algorithmic_bytes_per_launch": b_k1, "avg_launch_ms": k1_ms,
+                         "traffic_frac_of_peak": (pmc_traffic(args, C) / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                         if pmc_traffic(args, C) else None,
+                         "note": "achieved = algorithmic bytes of the u32 CSR (SURVEY 8d) / K1 time; the kernel streams a 16-bit "
+                                 "encoding of that CSR, so its PMC HBM traffic is about 0.56x the algorithmic bytes",
                          "k_update_avg_launch_ms": k2_ms, "sweep_bytes": b_sweep,
                          "sweep_frac_of_peak": b_sweep / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
         }
