@@ -13,66 +13,24 @@
 using namespace mmg;
 
 // ------------------------------------------------------------------------------ K1 variants
-struct K1Variant { int elems, win, unr, mode, bs, rows; }; // rows: host-side cap on rows per tile (0 = elems/4)
+// Tile geometry variants.  Each names the caps the host tile builder uses and the k_sample instance
+// (u32 stream) that serves as fallback; k1_s16_kernel() maps the same id to the k_sample16 instance.
+// elems: hits per tile (LDS staging), win: LDS window width, unr: walk unroll of k_sample, bs: workgroup
+// size, rows: rows per tile.  MMG_K1_VARIANT selects one (experiments); 0 is the default.
+struct K1Variant { int elems, win, unr, mode, bs, rows; };
 #define K1_VARIANT_LIST(X) \
-    X(0, 4096, 2048, 4, 0, 256, 0) \
-    X(1, 4096, 1024, 4, 0, 256, 0) \
-    X(2, 8192, 2048, 4, 0, 256, 0) \
-    X(3, 2048, 1024, 4, 0, 256, 0) \
-    X(4, 4096, 2048, 8, 0, 256, 0) \
-    X(5, 4096, 2048, 1, 0, 256, 0) \
-    X(6, 2560, 256, 4, K1M_NO_PHASE2, 128, 128) \
-    X(7, 8192, 2048, 8, 0, 256, 0) \
-    X(8, 5120, 1024, 4, 0, 256, 0) \
-    X(9, 5120, 512, 4, 0, 256, 0) \
-    X(10, 4096, 512, 4, 0, 256, 0) \
-    X(11, 6144, 512, 4, 0, 256, 0) \
-    X(12, 3072, 512, 4, 0, 256, 0) \
-    X(13, 1536, 256, 4, 0, 64, 64) \
-    X(14, 1536, 512, 4, 0, 64, 64) \
-    X(15, 2048, 512, 4, 0, 128, 128) \
-    X(16, 3072, 512, 4, 0, 128, 128) \
-    X(17, 1024, 256, 4, 0, 64, 64) \
-    X(18, 2560, 512, 4, 0, 128, 128) \
-    X(19, 6144, 512, 4, 0, 256, 256)  \
-    X(20, 1280, 256, 4, 0, 64, 64) \
-    X(21, 2560, 256, 4, 0, 128, 128) \
-    X(22, 2560, 384, 4, 0, 128, 128) \
-    X(23, 3072, 256, 4, 0, 128, 128) \
-    X(24, 4096, 512, 4, 0, 256, 256) \
-    X(25, 5120, 512, 4, 0, 256, 256)
+    X(0, 2560, 256, 4, 0, 128, 128) \
+    X(1, 4096, 512, 4, 0, 256, 256) \
+    X(2, 2560, 512, 4, 0, 128, 128) \
+    X(3, 3072, 256, 4, 0, 128, 128) \
+    X(4, 1280, 256, 4, 0, 64, 64)   \
+    X(5, 2560, 256, 4, K1M_NO_PHASE2, 128, 128)
 static const K1Variant k1_variants[] = {
 #define X(id, e, w, u, m, bs, rows) {e, w, u, m, bs, rows},
     K1_VARIANT_LIST(X)
 #undef X
 };
-// 16-bit-stream kernel instances, keyed by the k_sample variant whose tile caps they share
-template <typename IdxT, bool HAS_K>
-static const void *k1_s16_kernel_for(int variant, int fuse = 1)
-{
-    if (variant == 21 && fuse == 2) return (const void *)&k_sample16<IdxT, HAS_K, 2560, 256, 128, 128, 0, 2>;
-    if (variant == 21 && fuse == 4) return (const void *)&k_sample16<IdxT, HAS_K, 2560, 256, 128, 128, 0, 4>;
-    if (variant == 21 && fuse == 8) return (const void *)&k_sample16<IdxT, HAS_K, 2560, 256, 128, 128, 0, 8>;
-    if (fuse != 1) return nullptr;
-    switch (variant) {
-    case 21: return (const void *)&k_sample16<IdxT, HAS_K, 2560, 256, 128, 128, 0>;
-    case 22: return (const void *)&k_sample16<IdxT, HAS_K, 2560, 384, 128, 128, 0>;
-    case 23: return (const void *)&k_sample16<IdxT, HAS_K, 3072, 256, 128, 128, 0>;
-    case 24: return (const void *)&k_sample16<IdxT, HAS_K, 4096, 512, 256, 256, 0>;
-    case 20: return (const void *)&k_sample16<IdxT, HAS_K, 1280, 256, 64, 64, 0>;
-    case 18: return (const void *)&k_sample16<IdxT, HAS_K, 2560, 512, 128, 128, 0>;
-    case 6: return (const void *)&k_sample16<IdxT, HAS_K, 2560, 256, 128, 128, K1M_NO_PHASE2>; // ablation
-    }
-    return nullptr;
-}
-static const void *k1_s16_kernel(int variant, bool idx64, bool has_k, int fuse = 1)
-{
-    if (idx64) return has_k ? k1_s16_kernel_for<uint64_t, true>(variant, fuse) : k1_s16_kernel_for<uint64_t, false>(variant, fuse);
-    return has_k ? k1_s16_kernel_for<uint32_t, true>(variant, fuse) : k1_s16_kernel_for<uint32_t, false>(variant, fuse);
-}
-
-static const int k1_n_variants = (int)(sizeof(k1_variants) / sizeof(k1_variants[0]));
-static const int K1_DEFAULT_VARIANT = 21;
+static const int K1_DEFAULT_VARIANT = 0;
 
 template <typename IdxT, bool HAS_K>
 static const void *k1_kernel_for(int variant)
@@ -89,6 +47,32 @@ static const void *k1_kernel(int variant, bool idx64, bool has_k)
     if (idx64) return has_k ? k1_kernel_for<uint64_t, true>(variant) : k1_kernel_for<uint64_t, false>(variant);
     return has_k ? k1_kernel_for<uint32_t, true>(variant) : k1_kernel_for<uint32_t, false>(variant);
 }
+
+// 16-bit-stream kernel instances, keyed by the k_sample variant whose tile caps they share
+template <typename IdxT, bool HAS_K>
+static const void *k1_s16_kernel_for(int variant, int fuse = 1)
+{
+    if (variant == 0 && fuse == 2) return (const void *)&k_sample16<IdxT, HAS_K, 2560, 256, 128, 128, 0, 2>;
+    if (variant == 0 && fuse == 4) return (const void *)&k_sample16<IdxT, HAS_K, 2560, 256, 128, 128, 0, 4>;
+    if (variant == 0 && fuse == 8) return (const void *)&k_sample16<IdxT, HAS_K, 2560, 256, 128, 128, 0, 8>;
+    if (fuse != 1) return nullptr;
+    switch (variant) {
+    case 0: return (const void *)&k_sample16<IdxT, HAS_K, 2560, 256, 128, 128, 0>;
+    case 1: return (const void *)&k_sample16<IdxT, HAS_K, 4096, 512, 256, 256, 0>;
+    case 2: return (const void *)&k_sample16<IdxT, HAS_K, 2560, 512, 128, 128, 0>;
+    case 3: return (const void *)&k_sample16<IdxT, HAS_K, 3072, 256, 128, 128, 0>;
+    case 4: return (const void *)&k_sample16<IdxT, HAS_K, 1280, 256, 64, 64, 0>;
+    case 5: return (const void *)&k_sample16<IdxT, HAS_K, 2560, 256, 128, 128, K1M_NO_PHASE2>; // ablation (timing only)
+    }
+    return nullptr;
+}
+static const void *k1_s16_kernel(int variant, bool idx64, bool has_k, int fuse = 1)
+{
+    if (idx64) return has_k ? k1_s16_kernel_for<uint64_t, true>(variant, fuse) : k1_s16_kernel_for<uint64_t, false>(variant, fuse);
+    return has_k ? k1_s16_kernel_for<uint32_t, true>(variant, fuse) : k1_s16_kernel_for<uint32_t, false>(variant, fuse);
+}
+
+static const int k1_n_variants = (int)(sizeof(k1_variants) / sizeof(k1_variants[0]));
 
 // ------------------------------------------------------------------------------ errors
 static thread_local std::string g_err;

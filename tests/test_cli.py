@@ -220,3 +220,43 @@ def test_runs_are_reproducible(tmp_path, gpu):
         assert run([str(p), out, ], timeout=300, env=dict(os.environ, OMP_NUM_THREADS=str(1 + 3 * i))).returncode == 0
         outs.append(open(out + ".mmseq").read() + gzip.open(out + ".trace_gibbs.gz", "rt").read())
     assert outs[0] == outs[1]          # independent of host thread count and of run (cf. src/mmseq.cpp:834-838)
+
+
+def config1_dataset(orc):
+    """BASELINE.json configs[0]: 10k reads, 1k transcripts, hits/read = 1+Poisson(3), from the App. D generator."""
+    p, aux = orc.synth_problem(R=10000, T=1000, avg_hits=4, seed=1234, sort=False)
+    rng = np.random.default_rng(1234)
+    names = ["T%07d" % i for i in range(1000)]
+    genes, i, g = {}, 0, 0
+    while i < 1000:
+        sz = int(1 + rng.poisson(3))
+        genes["G%06d" % g] = names[i:i + sz]
+        i += sz; g += 1
+    efflen = {n: float(aux["efflen"][i]) for i, n in enumerate(names)}
+    truelen = {n: int(aux["efflen"][i]) + 180 for i, n in enumerate(names)}
+    rp = p.row_ptr.astype(np.int64)
+    reads = [("r%09d" % r, [names[c] for c in p.col_idx[rp[r]:rp[r + 1]]]) for r in range(10000)]
+    return H.HitsData(names, efflen, truelen, genes, [[names[0], names[1]]], reads)
+
+
+@pytest.mark.gpu
+def test_config1_plumbing_text_and_binary_agree(tmp_path, gpu, orc):
+    """configs[0] through the full CLI, 1024 iterations, text and binary hits files: identical outputs, and the
+    transcript table equals the Python pipeline's."""
+    h = config1_dataset(orc)
+    (tmp_path / "t.hits").write_bytes(H.write_hits_text(h))
+    (tmp_path / "b.hits").write_bytes(H.write_hits_binary(h))
+    outs = {}
+    for f in ("t", "b"):
+        out = str(tmp_path / ("out_" + f))
+        r = run(["-gibbs_iter", "1024", str(tmp_path / (f + ".hits")), out], timeout=300)
+        assert r.returncode == 0, r.stderr.decode()
+        outs[f] = {ext: open(out + ext, "rb").read() for ext in (".mmseq", ".gene.mmseq", ".identical.mmseq", ".k", ".M")}
+        outs[f]["trace"] = gzip.open(out + ".trace_gibbs.gz", "rb").read()
+    assert outs["t"] == outs["b"]
+    e = H.expected_run(h, gibbs_iter=1024)
+    mapped, hdr, tab = _table(str(tmp_path / "out_t") + ".mmseq")
+    assert mapped == 10000 and len(tab) == 1000
+    for got, exp in zip(tab, e["transcripts"]):
+        for col in ("log_mu", "sd", "mcse", "iact", "unique_hits", "log_mu_em", "observed", "mean_proportion"):
+            assert _same_number(got[col], exp[col]), (got["feature_id"], col, got[col], exp[col])
