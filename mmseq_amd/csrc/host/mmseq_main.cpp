@@ -89,50 +89,115 @@ static int powerof2(unsigned int x)
         }                                                                                 \
     } while (0)
 
-// gzip text sink with ostream-compatible number formatting ("%g" == default ostream, 6 digits)
+// gzip text sink: ONE standard gzip member whose deflate stream is produced chunk-wise in parallel.
+// Every chunk is compressed independently as raw deflate and closed with a sync flush (byte-aligned,
+// no dictionary carried over), so the concatenation is a valid deflate stream; the CRCs are merged with
+// crc32_combine.  Any gzip reader (zlib, Boost gzip_decompressor of mmcollapse, R) reads it unchanged.
+// Numbers are formatted with "%g" == default ostream formatting (6 significant digits).
 struct GzText {
-    gzFile f = nullptr;
-    string buf;
+    FILE *f = nullptr;
+    uLong crc = 0;
+    unsigned long long total = 0;
+    string pending; // small writes are gathered here and compressed on flush
     explicit GzText(const string &path)
     {
-        f = gzopen(path.c_str(), "wb");
+        f = fopen(path.c_str(), "wb");
         if (!f) { cerr << "Error: cannot open " << path << " for writing.\n"; exit(1); }
-        buf.reserve(1 << 20);
+        const unsigned char hdr[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};
+        fwrite(hdr, 1, 10, f);
+        crc = crc32(0L, Z_NULL, 0);
     }
-    void str(const string &s) { buf += s; maybe_flush(); }
+    static string deflate_chunk(const string &in, bool last)
+    {
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
+            cerr << "Error initialising zlib.\n";
+            exit(1);
+        }
+        string out;
+        out.resize(deflateBound(&zs, (uLong)in.size()) + 16);
+        zs.next_in = (Bytef *)in.data();
+        zs.avail_in = (uInt)in.size();
+        zs.next_out = (Bytef *)&out[0];
+        zs.avail_out = (uInt)out.size();
+        deflate(&zs, last ? Z_FINISH : Z_SYNC_FLUSH);
+        out.resize(out.size() - zs.avail_out);
+        deflateEnd(&zs);
+        return out;
+    }
+    // chunks (<= 1 GiB each) are compressed in parallel and appended in order
+    void write_chunks(vector<string> &chunks)
+    {
+        flush_pending();
+        vector<string> comp(chunks.size());
+        vector<uLong> crcs(chunks.size());
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int64_t i = 0; i < (int64_t)chunks.size(); ++i) {
+            comp[i] = deflate_chunk(chunks[i], false);
+            crcs[i] = crc32(crc32(0L, Z_NULL, 0), (const Bytef *)chunks[i].data(), (uInt)chunks[i].size());
+        }
+        for (size_t i = 0; i < chunks.size(); ++i) {
+            fwrite(comp[i].data(), 1, comp[i].size(), f);
+            crc = crc32_combine(crc, crcs[i], (z_off_t)chunks[i].size());
+            total += chunks[i].size();
+        }
+    }
+    void flush_pending()
+    {
+        if (pending.empty()) return;
+        string c = deflate_chunk(pending, false);
+        fwrite(c.data(), 1, c.size(), f);
+        crc = crc32(crc, (const Bytef *)pending.data(), (uInt)pending.size());
+        total += pending.size();
+        pending.clear();
+    }
+    void str(const string &s) { pending += s; if (pending.size() > (1u << 24)) flush_pending(); }
     void num(double v)
     {
         char tmp[40];
         int n = snprintf(tmp, sizeof tmp, "%g", v);
-        buf.append(tmp, n);
+        pending.append(tmp, n);
     }
-    void maybe_flush() { if (buf.size() > (1 << 20) - 64) flush(); }
-    void flush() { if (!buf.empty()) { gzwrite(f, buf.data(), (unsigned)buf.size()); buf.clear(); } }
-    void close() { flush(); gzclose(f); f = nullptr; }
+    void close()
+    {
+        flush_pending();
+        const string fin = deflate_chunk(string(), true); // final (empty) block
+        fwrite(fin.data(), 1, fin.size(), f);
+        unsigned char tr[8];
+        const uint32_t c = (uint32_t)crc, n = (uint32_t)(total & 0xffffffffull);
+        for (int i = 0; i < 4; ++i) { tr[i] = (unsigned char)(c >> (8 * i)); tr[4 + i] = (unsigned char)(n >> (8 * i)); }
+        fwrite(tr, 1, 8, f);
+        fclose(f);
+        f = nullptr;
+    }
 };
 
-// rows of n numbers, each followed by a space, one line per sample (src/mmseq.cpp:912-916):
-// lines are formatted in parallel, compressed serially
+// rows of n numbers, each followed by a space, one line per sample (src/mmseq.cpp:912-916).
+// Chunks of whole lines (>= ~256 KiB of text) are formatted AND compressed in parallel.
 static void write_trace_lines(GzText &gz, int n_lines, size_t n_cols, const function<double(int, size_t)> &at,
                               const function<bool(size_t)> &keep)
 {
-    const int B = 16;
-    vector<string> lines(B);
-    for (int i0 = 0; i0 < n_lines; i0 += B) {
-        const int nb = min(B, n_lines - i0);
+    const int lines_per_chunk = (int)max<size_t>(1, (size_t)262144 / max<size_t>(1, n_cols * 9));
+    const int batch = max(1, omp_get_max_threads() * 2);
+    for (int l0 = 0; l0 < n_lines; l0 += lines_per_chunk * batch) {
+        const int nchunks = min(batch, (n_lines - l0 + lines_per_chunk - 1) / lines_per_chunk);
+        vector<string> chunks(nchunks);
 #pragma omp parallel for schedule(dynamic, 1)
-        for (int b = 0; b < nb; ++b) {
-            string &s = lines[b];
-            s.clear();
+        for (int c = 0; c < nchunks; ++c) {
+            string &s = chunks[c];
             char tmp[40];
-            for (size_t c = 0; c < n_cols; ++c) {
-                if (!keep(c)) continue;
-                int len = snprintf(tmp, sizeof tmp, "%g ", at(i0 + b, c));
-                s.append(tmp, len);
+            const int lb = l0 + c * lines_per_chunk, le = min(n_lines, lb + lines_per_chunk);
+            for (int i = lb; i < le; ++i) {
+                for (size_t col = 0; col < n_cols; ++col) {
+                    if (!keep(col)) continue;
+                    int len = snprintf(tmp, sizeof tmp, "%g ", at(i, col));
+                    s.append(tmp, len);
+                }
+                s += "\n";
             }
-            s += "\n";
         }
-        for (int b = 0; b < nb; ++b) { gz.flush(); gzwrite(gz.f, lines[b].data(), (unsigned)lines[b].size()); }
+        gz.write_chunks(chunks);
     }
 }
 
