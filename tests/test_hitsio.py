@@ -100,3 +100,18 @@ def test_ingest_oracle_first_seen_order():
     assert g["rows"] == [(0, 1), (2,), (2, 3)]                 # sorted combos in first-seen order (:412-418)
     assert g["k"].tolist() == [3, 1, 1] and g["mapped"] == 5
     assert g["doublehits"] == [1, 0, 0, 0]                     # within-read duplicate counted (:404-409)
+
+
+def test_t2g_hits_gene_level_records(tmp_path):
+    """src/t2g_hits.cpp:33-121: transcripts -> genes per read, de-duplicated, sorted; records only."""
+    h = _dataset(3)
+    t2g = {t: g for g, ts in h.genes.items() for t in ts}
+    exp = "".join(">%s\n%s" % (rid, "".join(g + "\n" for g in sorted({t2g[t] for t in ts}))) for rid, ts in h.reads).encode()
+    exe = os.path.join(ROOT, "mmseq_amd", "csrc", "t2g_hits")
+    for data in (H.write_hits_text(h), H.write_hits_binary(h)):
+        p = tmp_path / "in.hits"
+        p.write_bytes(data)
+        r = subprocess.run([exe, str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0 and r.stdout == exp
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"Usage: t2g_hits" in r.stderr
