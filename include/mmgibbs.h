@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MMG_ABI_VERSION 1
+#define MMG_ABI_VERSION 2
 
 enum {
     MMG_OK = 0,
@@ -118,6 +118,20 @@ int mmg_problem_start_values(const mmg_problem *p, double *mu0, int32_t *unique_
  * gain <= epsilon or after max_iter sweeps. */
 int mmg_problem_em(const mmg_problem *p, double *mu, int max_iter, double epsilon, int *iters,
                    double *loglik);
+
+/* ---- EM, sweep by sweep (src/mmseq.cpp:741-811) ------------------------------------------
+ * mmg_em_create uploads the start value and returns its log-likelihood (:745-754);
+ * mmg_em_step performs one sweep of :761-806 and returns the new log-likelihood, so the caller
+ * owns the loop, its stopping rule (:761) and its per-iteration output (:762-768).  mu stays on
+ * the device between sweeps; mmg_em_get_mu downloads it (n doubles).  The sums are accumulated
+ * exactly (fixed point, integer atomics): results do not depend on the traversal order. */
+typedef struct mmg_em mmg_em;
+int mmg_em_create(const mmg_problem *p, const double *mu0, mmg_em **out, double *loglik0);
+int mmg_em_step(mmg_em *e, double *loglik);
+int mmg_em_get_mu(mmg_em *e, double *mu);
+/* sweeps done, rows passes repeated on measured scale exponents, 1 if the tile-stream kernel runs */
+int mmg_em_stats(const mmg_em *e, int *sweeps, int *repeated_passes, int *stream_kernel);
+void mmg_em_destroy(mmg_em *e);
 void mmg_problem_destroy(mmg_problem *p);
 
 /* ---- sampler ------------------------------------------------------------------------ */

@@ -59,6 +59,11 @@ SYMBOLS = {
     "mmg_problem_em": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_int),
                                  C.POINTER(C.c_double)]),
     "mmg_problem_destroy": (None, [C.c_void_p]),
+    "mmg_em_create": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_double)]),
+    "mmg_em_step": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "mmg_em_get_mu": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mmg_em_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mmg_em_destroy": (None, [C.c_void_p]),
     "mmg_sampler_create": (C.c_int, [C.c_void_p, C.POINTER(Config), C.c_void_p, C.POINTER(C.c_void_p)]),
     "mmg_sampler_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mmg_sampler_run": (C.c_int, [C.c_void_p, C.c_int]),

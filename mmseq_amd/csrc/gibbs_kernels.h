@@ -939,79 +939,6 @@ __global__ void k_div(double *acc, const double *l, uint32_t n)
     if (t < n) acc[t] = acc[t] / l[t];
 }
 
-// ---------------------------------------------------------------- EM (src/mmseq.cpp:741-811)
-// Deterministic: no floating-point atomics.  Row pass: d_i = sum_{t in row i} mu_t in row order,
-// q_i = k_i / d_i, log-likelihood part k_i log d_i.  Column pass (over the CSC transpose, rows
-// ascending): mu_t <- mu_t * (sum_i q_i) / l_t, penalty mu_t l_t.  Both passes leave one partial sum
-// per workgroup (fixed LDS tree); k_em_finish adds the partials in index order.
-__device__ __forceinline__ double block_sum_256(double v, double *red)
-{
-    red[threadIdx.x] = v;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-        __syncthreads();
-    }
-    return red[0];
-}
-
-template <typename IdxT>
-__global__ __launch_bounds__(256) void k_em_rows(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
-                                                 const uint32_t *__restrict__ k, uint64_t m, const double *__restrict__ mu,
-                                                 double *__restrict__ q, double *__restrict__ partial)
-{
-    __shared__ double red[256];
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    double ll = 0.0;
-    if (r < m) {
-        const uint64_t b = row_ptr[r], e = row_ptr[r + 1];
-        double qq = 0.0;
-        if (e > b) {
-            double d = 0.0;
-            for (uint64_t j = b; j < e; ++j) d += mu[col_idx[j]];
-            const double kk = k ? (double)k[r] : 1.0;
-            ll = kk * dlog(d);
-            qq = kk / d;
-        }
-        q[r] = qq;
-    }
-    const double tot = block_sum_256(ll, red);
-    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
-}
-
-// apply != 0: mu_t <- mu_t * acc_t / l_t first.  partial[blockIdx] = sum of mu_t l_t over the block.
-__global__ __launch_bounds__(256) void k_em_cols(const uint64_t *__restrict__ col_ptr, const uint32_t *__restrict__ row_of,
-                                                 const double *__restrict__ q, double *mu, const double *__restrict__ l, uint32_t n,
-                                                 double *__restrict__ partial, int apply)
-{
-    __shared__ double red[256];
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    double pen = 0.0;
-    if (t < n) {
-        double mval = mu[t];
-        if (apply) {
-            double acc = 0.0;
-            for (uint64_t j = col_ptr[t]; j < col_ptr[t + 1]; ++j) acc += q[row_of[j]];
-            mval = mval * acc / l[t];
-            mu[t] = mval;
-        }
-        pen = mval * l[t];
-    }
-    const double tot = block_sum_256(pen, red);
-    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
-}
-
-// out[0] = sum(pa[0..na)) - sum(pb[0..nb)), each in index order by one lane
-__global__ void k_em_finish(const double *pa, uint32_t na, const double *pb, uint32_t nb, double *out)
-{
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        double a = 0.0, b = 0.0;
-        for (uint32_t i = 0; i < na; ++i) a += pa[i];
-        for (uint32_t i = 0; i < nb; ++i) b += pb[i];
-        out[0] = a - b;
-    }
-}
-
 // ---------------------------------------------------------------- synthetic generator
 struct SynthArgs {
     uint64_t seed, row0, rows;

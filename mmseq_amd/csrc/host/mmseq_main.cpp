@@ -535,27 +535,33 @@ int main(int argc, char **argv)
         MMG_TRY(mmg_problem_create(&pd, device, &prob));
     }
 
-    // ---- EM on the device (src/mmseq.cpp:741-811), one sweep per call so the per-iteration output matches
+    // ---- EM on the device (src/mmseq.cpp:741-811): mu stays there; this loop owns the stopping rule and the output
     GzText *gz_em = debug ? new GzText(output_base + ".trace_em.gz") : nullptr;
     if (gz_em) { for (uint32_t t = 0; t < n; t++) { gz_em->str(sid(t)); gz_em->str(" "); } gz_em->str("\n"); }
     {
         double loglik = 0.0;
-        int its = 0;
-        MMG_TRY(mmg_problem_em(prob, mu.data(), 0, epsilon, &its, &loglik));
+        mmg_em *em = nullptr;
+        MMG_TRY(mmg_em_create(prob, mu.data(), &em, &loglik));
         double llr = epsilon + 1;
         int iter = 0;
         cout.precision(5);
         cout.setf(ios::fixed, ios::floatfield);
         while (iter < max_em_iter && llr > epsilon) {
             cout << "EM iteration " << iter << flush;
-            if (gz_em) { for (uint32_t t = 0; t < n; t++) { gz_em->num(mu[t]); gz_em->str(" "); } gz_em->str("\n"); }
+            if (gz_em) {
+                if (iter) MMG_TRY(mmg_em_get_mu(em, mu.data()));
+                for (uint32_t t = 0; t < n; t++) { gz_em->num(mu[t]); gz_em->str(" "); }
+                gz_em->str("\n");
+            }
             double ll = 0.0;
-            MMG_TRY(mmg_problem_em(prob, mu.data(), 1, -numeric_limits<double>::max(), &its, &ll));
+            MMG_TRY(mmg_em_step(em, &ll));
             llr = ll - loglik;
             loglik = ll;
             cout << ", log likelihood ratio: " << llr << "            \r";
             iter++;
         }
+        MMG_TRY(mmg_em_get_mu(em, mu.data()));
+        mmg_em_destroy(em);
         cout << endl;
         cout.unsetf(ios::floatfield);
         cout.precision(6);

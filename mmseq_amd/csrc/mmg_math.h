@@ -242,6 +242,14 @@ MMG_HD double dfloor(double x)
     return __builtin_floor(x);
 #endif
 }
+// ilogb for x > 0 finite (subnormals included); host and device agree by construction
+MMG_HD int dilogb(double x)
+{
+    const uint64_t b = bits_of(x);
+    const int e = (int)((b >> 52) & 0x7ff);
+    if (e) return e - 1023;
+    return 63 - __builtin_clzll(b & 0xfffffffffffffull) - 1074;
+}
 MMG_HD double dabs(double x) { return double_of(bits_of(x) & 0x7fffffffffffffffull); }
 
 // ------------------------------------------------------------------ samplers

@@ -2,6 +2,7 @@
 // Host side of the device boundary that replaces src/mmseq.cpp:833-925 of the reference.
 #include "../../include/mmgibbs.h"
 #include "gibbs_kernels.h"
+#include "em_kernels.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -133,8 +134,7 @@ struct mmg_problem {
     int grid16 = 0;
     bool use16 = false;
     double s16_fast_fraction = 0.0;
-    uint64_t *d_col_ptr = nullptr; // CSC transpose for the deterministic EM (lazy)
-    uint32_t *d_row_of = nullptr;
+    uint32_t *d_colcnt = nullptr;   // hits per transcript, for the EM scale words (lazy)
     uint64_t *d_chunk_tile = nullptr;
     uint64_t n_chunks = 0;
     int grid_sample = 1;
@@ -155,8 +155,7 @@ static void problem_free(mmg_problem *p)
     if (p->d_stream16) (void)hipFree(p->d_stream16);
     if (p->d_s16tiles) (void)hipFree(p->d_s16tiles);
     if (p->d_chunk_tile16) (void)hipFree(p->d_chunk_tile16);
-    if (p->d_col_ptr) (void)hipFree(p->d_col_ptr);
-    if (p->d_row_of) (void)hipFree(p->d_row_of);
+    if (p->d_colcnt) (void)hipFree(p->d_colcnt);
     if (p->d_chunk_tile) (void)hipFree(p->d_chunk_tile);
     delete p;
 }
@@ -539,78 +538,208 @@ extern "C" int mmg_problem_start_values(const mmg_problem *p, double *mu0, int32
 }
 
 // CSC transpose (rows ascending within a column), built on the host from the resident CSR on first use
-static int problem_build_csc(mmg_problem *p)
+// ------------------------------------------------------------------------------ EM
+struct mmg_em {
+    mmg_problem *p = nullptr;
+    double *d_mu = nullptr, *d_pc = nullptr;
+    uint32_t *d_word = nullptr;
+    uint64_t *d_hi = nullptr, *d_lo = nullptr, *d_ll = nullptr;
+    int32_t *d_xe = nullptr, *d_sexp = nullptr;
+    EmOut *d_out = nullptr;
+    uint64_t *d_chunk[2] = {nullptr, nullptr}; // tile ranges of the accumulate / measure kernels
+    int grid[2] = {0, 0};
+    bool fast = false;
+    bool first = true;
+    int sweeps = 0, repeats = 0;
+    double loglik = 0.0;
+};
+
+static void em_free(mmg_em *e)
 {
-    if (p->d_col_ptr) return MMG_OK;
-    if (p->m >= 0xffffffffull) return fail(MMG_ERR_ARG, "EM needs fewer than 2^32 rows per device");
-    std::vector<uint64_t> rp(p->m + 1);
-    std::vector<uint32_t> ci(p->nnz);
-    int rc = mmg_problem_download(p, rp.data(), ci.data());
-    if (rc) return rc;
-    std::vector<uint64_t> cp((size_t)p->n + 1, 0);
-    for (uint64_t j = 0; j < p->nnz; ++j) cp[(size_t)ci[j] + 1]++;
-    for (uint32_t t = 0; t < p->n; ++t) cp[t + 1] += cp[t];
-    std::vector<uint32_t> rows(p->nnz);
-    {
-        std::vector<uint64_t> cur(cp.begin(), cp.end() - 1);
-        for (uint64_t r = 0; r < p->m; ++r)
-            for (uint64_t j = rp[r]; j < rp[r + 1]; ++j) rows[cur[ci[j]]++] = (uint32_t)r;
+    if (!e) return;
+    (void)hipSetDevice(e->p->device);
+    for (void *x : {(void *)e->d_mu, (void *)e->d_pc, (void *)e->d_word, (void *)e->d_hi, (void *)e->d_lo, (void *)e->d_ll,
+                    (void *)e->d_xe, (void *)e->d_sexp, (void *)e->d_out, (void *)e->d_chunk[0], (void *)e->d_chunk[1]})
+        if (x) (void)hipFree(x);
+    delete e;
+}
+
+// the stream kernel is instantiated for the default K1 tile shape only; anything else takes the row-per-thread kernel
+template <bool MEASURE>
+static const void *em16_kernel(const mmg_problem *p)
+{
+    if (!p->use16 || p->variant != 0) return nullptr;
+    const bool hk = p->d_k != nullptr;
+    if (p->idx64) return hk ? (const void *)k_em16<uint64_t, true, 2560, 256, 128, 128, MEASURE> : (const void *)k_em16<uint64_t, false, 2560, 256, 128, 128, MEASURE>;
+    return hk ? (const void *)k_em16<uint32_t, true, 2560, 256, 128, 128, MEASURE> : (const void *)k_em16<uint32_t, false, 2560, 256, 128, 128, MEASURE>;
+}
+
+static int em_launch_rows(mmg_em *e, bool measure)
+{
+    mmg_problem *p = e->p;
+    EmArgs a;
+    a.n = p->n; a.mu = e->d_mu; a.word = e->d_word; a.hi = e->d_hi; a.lo = e->d_lo; a.xe = e->d_xe; a.ll = e->d_ll;
+    if (p->m == 0) return MMG_OK;
+    if (e->fast) {
+        const int w = measure ? 1 : 0;
+        const void *fn = measure ? em16_kernel<true>(p) : em16_kernel<false>(p);
+        const void *rp = p->d_row_ptr;
+        const uint32_t *col = p->d_col, *kk = p->d_k;
+        const S16Tile *tiles = p->d_s16tiles;
+        const uint64_t *chunk = e->d_chunk[w];
+        const u32x4 *stream = (const u32x4 *)p->d_stream16;
+        void *args[] = {(void *)&rp, (void *)&col, (void *)&kk, (void *)&tiles, (void *)&chunk, (void *)&stream, (void *)&a};
+        HIP_TRY(hipLaunchKernel(fn, dim3((unsigned)e->grid[w]), dim3(128), args, 0, 0));
+        return MMG_OK;
     }
-    HIP_TRY(hipMalloc((void **)&p->d_col_ptr, cp.size() * sizeof(uint64_t)));
-    HIP_TRY(hipMalloc((void **)&p->d_row_of, std::max<uint64_t>(p->nnz, 1) * sizeof(uint32_t)));
-    HIP_TRY(hipMemcpy(p->d_col_ptr, cp.data(), cp.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-    if (p->nnz) HIP_TRY(hipMemcpy(p->d_row_of, rows.data(), p->nnz * sizeof(uint32_t), hipMemcpyHostToDevice));
-    p->device_bytes += cp.size() * 8 + p->nnz * 4;
+    const unsigned gr = (unsigned)((p->m + 255) / 256);
+    if (p->idx64) {
+        if (measure) hipLaunchKernelGGL((k_em_rows_global<uint64_t, true>), dim3(gr), dim3(256), 0, 0, (const uint64_t *)p->d_row_ptr, p->d_col, p->d_k, p->m, a);
+        else hipLaunchKernelGGL((k_em_rows_global<uint64_t, false>), dim3(gr), dim3(256), 0, 0, (const uint64_t *)p->d_row_ptr, p->d_col, p->d_k, p->m, a);
+    } else {
+        if (measure) hipLaunchKernelGGL((k_em_rows_global<uint32_t, true>), dim3(gr), dim3(256), 0, 0, (const uint32_t *)p->d_row_ptr, p->d_col, p->d_k, p->m, a);
+        else hipLaunchKernelGGL((k_em_rows_global<uint32_t, false>), dim3(gr), dim3(256), 0, 0, (const uint32_t *)p->d_row_ptr, p->d_col, p->d_k, p->m, a);
+    }
+    HIP_TRY(hipGetLastError());
     return MMG_OK;
 }
+
+// One validated rows pass for the current mu: accumulators, log-likelihood.  Carried exponents first
+// (unless this is the first pass), repeated on measured exponents if a check failed.
+static int em_rows_pass(mmg_em *e)
+{
+    mmg_problem *p = e->p;
+    const unsigned gn = (p->n + 255) / 256;
+    for (int measured = e->first ? 1 : 0; measured < 2; ++measured) {
+        if (measured) {
+            hipLaunchKernelGGL(k_fill_i32, dim3(gn), dim3(256), 0, 0, e->d_xe, p->n, INT32_MIN);
+            int rc = em_launch_rows(e, true);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(k_em_prepare, dim3(gn), dim3(256), 0, 0, p->n, e->d_mu, p->d_l, p->d_colcnt,
+                           measured ? e->d_xe : e->d_sexp, measured, e->d_word, e->d_hi, e->d_lo, e->d_pc, e->d_ll);
+        int rc = em_launch_rows(e, false);
+        if (rc) return rc;
+        if (!measured) hipLaunchKernelGGL(k_em_check, dim3(gn), dim3(256), 0, 0, p->n, e->d_word, e->d_hi, e->d_ll);
+        hipLaunchKernelGGL(k_em_finish, dim3(1), dim3(1), 0, 0, e->d_pc, gn, e->d_ll, e->d_out);
+        EmOut out;
+        HIP_TRY(hipMemcpy(&out, e->d_out, sizeof(out), hipMemcpyDeviceToHost));
+        e->loglik = out.loglik;
+        if (!out.flag) break;
+        if (measured) return fail(MMG_ERR_STATE, "EM: a measured pass failed its own check");
+        ++e->repeats;
+    }
+    e->first = false;
+    return MMG_OK;
+}
+
+extern "C" int mmg_em_create(const mmg_problem *cp, const double *mu0, mmg_em **out, double *loglik0)
+{
+    if (!cp || !mu0 || !out) return fail(MMG_ERR_ARG, "NULL argument");
+    mmg_problem *p = const_cast<mmg_problem *>(cp); // the lazily built column counts are a cache
+    HIP_TRY(hipSetDevice(p->device));
+    if (!p->d_colcnt) {
+        HIP_TRY(hipMalloc((void **)&p->d_colcnt, p->n * sizeof(uint32_t)));
+        HIP_TRY(hipMemset(p->d_colcnt, 0, p->n * sizeof(uint32_t)));
+        if (p->nnz) {
+            const unsigned g = (unsigned)std::min<uint64_t>((p->nnz + 255) / 256, (uint64_t)p->cu_count * 32);
+            hipLaunchKernelGGL(k_em_colcount, dim3(g), dim3(256), 0, 0, p->d_col, p->nnz, p->d_colcnt);
+            HIP_TRY(hipGetLastError());
+        }
+        p->device_bytes += p->n * 4;
+    }
+    mmg_em *e = new mmg_em();
+    e->p = p;
+    const unsigned gn = (p->n + 255) / 256;
+#define EM_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { em_free(e); return fail(MMG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
+    EM_TRY(hipMalloc((void **)&e->d_mu, p->n * sizeof(double)));
+    EM_TRY(hipMalloc((void **)&e->d_pc, gn * sizeof(double)));
+    EM_TRY(hipMalloc((void **)&e->d_word, p->n * sizeof(uint32_t)));
+    EM_TRY(hipMalloc((void **)&e->d_hi, p->n * sizeof(uint64_t)));
+    EM_TRY(hipMalloc((void **)&e->d_lo, p->n * sizeof(uint64_t)));
+    EM_TRY(hipMalloc((void **)&e->d_ll, 4 * sizeof(uint64_t)));
+    EM_TRY(hipMalloc((void **)&e->d_xe, p->n * sizeof(int32_t)));
+    EM_TRY(hipMalloc((void **)&e->d_sexp, p->n * sizeof(int32_t)));
+    EM_TRY(hipMalloc((void **)&e->d_out, sizeof(EmOut)));
+    EM_TRY(hipMemcpy(e->d_mu, mu0, p->n * sizeof(double), hipMemcpyHostToDevice));
+    e->fast = em16_kernel<false>(p) != nullptr && p->n_tiles > 0;
+    if (const char *ev = getenv("MMG_EM_STREAM")) { if (atoi(ev) == 0) e->fast = false; }
+    if (e->fast) {
+        for (int w = 0; w < 2; ++w) {
+            const void *fn = w ? em16_kernel<true>(p) : em16_kernel<false>(p);
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 128, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 4; }
+            if (per_cu > 16) per_cu = 16;
+            uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>(p->n_tiles, (uint64_t)p->cu_count * per_cu));
+            if (const char *eg = getenv("MMG_EM_GRID")) { const long v = atol(eg); if (v >= 1 && (uint64_t)v < grid) grid = (uint64_t)v; } // tests: long tile ranges on small problems
+            std::vector<uint64_t> chunk(grid + 1);
+            for (uint64_t c = 0; c <= grid; ++c) chunk[c] = (uint64_t)(((unsigned __int128)p->n_tiles * c) / grid);
+            EM_TRY(hipMalloc((void **)&e->d_chunk[w], chunk.size() * sizeof(uint64_t)));
+            EM_TRY(hipMemcpy(e->d_chunk[w], chunk.data(), chunk.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+            e->grid[w] = (int)grid;
+        }
+    }
+#undef EM_TRY
+    // log-likelihood of the start value (src/mmseq.cpp:745-754)
+    int rc = em_rows_pass(e);
+    if (rc) { em_free(e); return rc; }
+    if (loglik0) *loglik0 = e->loglik;
+    *out = e;
+    return MMG_OK;
+}
+
+extern "C" int mmg_em_step(mmg_em *e, double *loglik)
+{
+    if (!e) return fail(MMG_ERR_ARG, "NULL argument");
+    mmg_problem *p = e->p;
+    HIP_TRY(hipSetDevice(p->device));
+    hipLaunchKernelGGL(k_em_apply, dim3((p->n + 255) / 256), dim3(256), 0, 0, p->n, e->d_mu, p->d_l, e->d_word, e->d_hi, e->d_lo, e->d_sexp);
+    int rc = em_rows_pass(e);
+    if (rc) return rc;
+    ++e->sweeps;
+    if (loglik) *loglik = e->loglik;
+    return MMG_OK;
+}
+
+extern "C" int mmg_em_get_mu(mmg_em *e, double *mu)
+{
+    if (!e || !mu) return fail(MMG_ERR_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(e->p->device));
+    HIP_TRY(hipMemcpy(mu, e->d_mu, e->p->n * sizeof(double), hipMemcpyDeviceToHost));
+    return MMG_OK;
+}
+
+extern "C" int mmg_em_stats(const mmg_em *e, int *sweeps, int *repeated_passes, int *stream_kernel)
+{
+    if (!e) return fail(MMG_ERR_ARG, "NULL argument");
+    if (sweeps) *sweeps = e->sweeps;
+    if (repeated_passes) *repeated_passes = e->repeats;
+    if (stream_kernel) *stream_kernel = e->fast ? 1 : 0;
+    return MMG_OK;
+}
+
+extern "C" void mmg_em_destroy(mmg_em *e) { em_free(e); }
 
 extern "C" int mmg_problem_em(const mmg_problem *cp, double *mu, int max_iter, double epsilon, int *iters, double *loglik)
 {
     if (!cp || !mu) return fail(MMG_ERR_ARG, "NULL argument");
-    mmg_problem *p = const_cast<mmg_problem *>(cp); // the lazily built transpose is a cache
-    HIP_TRY(hipSetDevice(p->device));
-    int rc = problem_build_csc(p);
-    if (rc) return rc;
-    const unsigned gr = (unsigned)std::max<uint64_t>((p->m + 255) / 256, 1), gc = (p->n + 255) / 256;
-    double *d_mu = nullptr, *d_q = nullptr, *d_pr = nullptr, *d_pc = nullptr, *d_ll = nullptr;
-    auto cleanup = [&]() { for (double *x : {d_mu, d_q, d_pr, d_pc, d_ll}) if (x) (void)hipFree(x); };
-#define EM_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail(MMG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
-    EM_TRY(hipMalloc((void **)&d_mu, p->n * sizeof(double)));
-    EM_TRY(hipMalloc((void **)&d_q, std::max<uint64_t>(p->m, 1) * sizeof(double)));
-    EM_TRY(hipMalloc((void **)&d_pr, gr * sizeof(double)));
-    EM_TRY(hipMalloc((void **)&d_pc, gc * sizeof(double)));
-    EM_TRY(hipMalloc((void **)&d_ll, sizeof(double)));
-    EM_TRY(hipMemcpy(d_mu, mu, p->n * sizeof(double), hipMemcpyHostToDevice));
-    auto rows_pass = [&]() {
-        if (p->idx64) hipLaunchKernelGGL(k_em_rows<uint64_t>, dim3(gr), dim3(256), 0, 0, (const uint64_t *)p->d_row_ptr, p->d_col, p->d_k, p->m, d_mu, d_q, d_pr);
-        else hipLaunchKernelGGL(k_em_rows<uint32_t>, dim3(gr), dim3(256), 0, 0, (const uint32_t *)p->d_row_ptr, p->d_col, p->d_k, p->m, d_mu, d_q, d_pr);
-    };
-    auto cols_pass = [&](int apply) {
-        hipLaunchKernelGGL(k_em_cols, dim3(gc), dim3(256), 0, 0, p->d_col_ptr, p->d_row_of, d_q, d_mu, p->d_l, p->n, d_pc, apply);
-    };
-    auto read_ll = [&](double &ll) -> hipError_t {
-        hipLaunchKernelGGL(k_em_finish, dim3(1), dim3(1), 0, 0, d_pr, gr, d_pc, gc, d_ll);
-        return hipMemcpy(&ll, d_ll, sizeof(double), hipMemcpyDeviceToHost);
-    };
-    // log-likelihood of the start value (src/mmseq.cpp:745-754)
+    mmg_em *e = nullptr;
     double ll_prev = 0.0;
-    rows_pass();
-    cols_pass(0);
-    EM_TRY(read_ll(ll_prev));
+    int rc = mmg_em_create(cp, mu, &e, &ll_prev);
+    if (rc) return rc;
     double llr = __builtin_huge_val(); // the reference starts from epsilon+1 (src/mmseq.cpp:756): first sweep always runs
     int it = 0;
     while (it < max_iter && llr > epsilon) {
-        cols_pass(1); // uses q of the current mu, leaves the new mu and its penalty
-        rows_pass();  // q and log-likelihood part of the new mu
         double ll = 0.0;
-        EM_TRY(read_ll(ll));
+        rc = mmg_em_step(e, &ll);
+        if (rc) { em_free(e); return rc; }
         llr = ll - ll_prev;
         ll_prev = ll;
         ++it;
     }
-    EM_TRY(hipMemcpy(mu, d_mu, p->n * sizeof(double), hipMemcpyDeviceToHost));
-#undef EM_TRY
-    cleanup();
+    rc = mmg_em_get_mu(e, mu);
+    em_free(e);
+    if (rc) return rc;
     if (iters) *iters = it;
     if (loglik) *loglik = ll_prev;
     return MMG_OK;

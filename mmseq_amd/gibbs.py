@@ -88,9 +88,56 @@ class Problem:
         check(self._lib.mmg_problem_em(self._h, _ptr(mu), max_iter, epsilon, C.byref(it), C.byref(ll)))
         return mu, it.value, ll.value
 
+    def em_stepper(self, mu0):
+        """Sweep-by-sweep EM (mmg_em_*): the caller owns the loop, as at src/mmseq.cpp:761."""
+        return Em(self, mu0)
+
     def close(self):
         if self._h:
             self._lib.mmg_problem_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Em:
+    """EM sweeps on the device (src/mmseq.cpp:741-811); `loglik` is the log-likelihood of the current mu."""
+
+    def __init__(self, prob, mu0):
+        self._lib = prob._lib
+        self._prob = prob
+        self._n = prob.info.n
+        mu0 = np.ascontiguousarray(mu0, np.float64)
+        assert mu0.size == self._n
+        h = C.c_void_p()
+        ll = C.c_double(0.0)
+        check(self._lib.mmg_em_create(prob._h, _ptr(mu0), C.byref(h), C.byref(ll)))
+        self._h = h
+        self.loglik = ll.value
+
+    def step(self):
+        ll = C.c_double(0.0)
+        check(self._lib.mmg_em_step(self._h, C.byref(ll)))
+        self.loglik = ll.value
+        return ll.value
+
+    def mu(self):
+        out = np.empty(self._n, np.float64)
+        check(self._lib.mmg_em_get_mu(self._h, _ptr(out)))
+        return out
+
+    def stats(self):
+        a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+        check(self._lib.mmg_em_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"sweeps": a.value, "repeated_passes": b.value, "stream_kernel": bool(c.value)}
+
+    def close(self):
+        if self._h:
+            self._lib.mmg_em_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -63,6 +63,10 @@ def lib():
     L.orc_em.argtypes = [C.c_uint64, C.c_uint32, u64p, u32p, C.c_void_p, f64p, f64p, C.c_int, C.c_double,
                          C.POINTER(C.c_double)]
     L.orc_em.restype = C.c_int
+    L.orc_em_seq.argtypes = L.orc_em.argtypes
+    L.orc_em_x.argtypes = L.orc_em.argtypes + [C.POINTER(C.c_int)]
+    L.orc_em_x.restype = C.c_int
+    L.orc_em_seq.restype = C.c_int
     L.orc_uh.argtypes = [C.c_uint64, C.c_uint32, u64p, u32p, C.c_void_p, C.c_uint32, u8p, i32p]
     L.orc_sokal.argtypes = [C.c_int, f64p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.orc_sokal.restype = C.c_int
@@ -202,6 +206,23 @@ def em(p, mu, max_iter=1000, epsilon=0.1):
     mu = np.array(mu, np.float64, copy=True)
     ll = C.c_double(0.0)
     it = lib().orc_em(p.m, p.n, p.row_ptr, p.col_idx, _kptr(p.k), p.l, mu, max_iter, epsilon, C.byref(ll))
+    return mu, it, ll.value
+
+
+def em_x(p, mu, max_iter=1000, epsilon=0.1):
+    """em() that also reports how many rows passes were repeated on the safe scale: (mu, iterations, loglik, redo)."""
+    mu = np.array(mu, np.float64, copy=True)
+    ll = C.c_double(0.0)
+    redo = C.c_int(0)
+    it = lib().orc_em_x(p.m, p.n, p.row_ptr, p.col_idx, _kptr(p.k), p.l, mu, max_iter, epsilon, C.byref(ll), C.byref(redo))
+    return mu, it, ll.value, redo.value
+
+
+def em_seq(p, mu, max_iter=1000, epsilon=0.1):
+    """EM in the reference's own summation order (src/mmseq.cpp:761-811); pins em() to the reference arithmetic."""
+    mu = np.array(mu, np.float64, copy=True)
+    ll = C.c_double(0.0)
+    it = lib().orc_em_seq(p.m, p.n, p.row_ptr, p.col_idx, _kptr(p.k), p.l, mu, max_iter, epsilon, C.byref(ll))
     return mu, it, ll.value
 
 

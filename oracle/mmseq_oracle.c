@@ -737,10 +737,11 @@ void orc_start_values(uint64_t m, uint32_t n, const uint64_t *row_ptr, const uin
     for (uint32_t t = 0; t < n; ++t) mu0[t] /= l[t];
 }
 
-/* src/mmseq.cpp:741-811: EM until llr <= epsilon or max_iter.  mu is updated in
- * place; returns the iteration count.  Row denominators are cached (same value
+/* src/mmseq.cpp:741-811 in the reference's own summation order (per transcript over rows ascending,
+ * log-likelihood over rows then transcripts): EM until llr <= epsilon or max_iter.  mu is updated in
+ * place; returns the iteration count.  Kept to pin orc_em (below) to the reference's arithmetic.  Row denominators are cached (same value
  * the reference recomputes per (t,row) at :787-791). */
-int orc_em(uint64_t m, uint32_t n, const uint64_t *row_ptr, const uint32_t *col_idx, const uint32_t *k,
+int orc_em_seq(uint64_t m, uint32_t n, const uint64_t *row_ptr, const uint32_t *col_idx, const uint32_t *k,
            const double *l, double *mu, int max_iter, double epsilon, double *loglik_out)
 {
     double *d = (double *)malloc((size_t)m * sizeof(double));
@@ -777,6 +778,139 @@ int orc_em(uint64_t m, uint32_t n, const uint64_t *row_ptr, const uint32_t *col_
     if (loglik_out) *loglik_out = loglik;
     free(d); free(acc);
     return iter;
+}
+
+
+/* ---- EM with order-independent accumulation: the specification the device implements bit for bit.
+ * Same fixed point as src/mmseq.cpp:761-811 (mu_t <- mu_t/l_t * S_t, S_t = sum_{i contains t} x_i, x_i = k_i/d_i,
+ * d_i = sum_{t in i} mu_t, stop when the log-likelihood gain <= epsilon), but the two big sums are accumulated EXACTLY in
+ * fixed point, so any traversal order (threads, workgroups, shards) gives the same bits:
+ *   once: N_t = hits in column t, sl_t = 63 - bitlen(N_t).  N_t terms below 2^(sl_t-1) sum below 2^62.
+ *   per rows pass, a scale exponent E_t per live transcript (mu_t == 0 or not finite: dead, it is left alone):
+ *       measured:  XE_t = max_i ilogb(x_i) from a pass of its own (integer max), E_t = sl_t - 2 - XE_t: every term is
+ *                  below 2^(sl_t-1) by construction.  Used for the first pass and for repeats.
+ *       carried:   E_t = sl_t - 2 - ilogb(S_t(last pass)) - ORC_EM_MARGIN, i.e. the last sum with MARGIN bits of head room;
+ *                  every term is checked (ilogb(x_i) + E_t < sl_t - 1), and so is every sum (HI_t >= 2^(sl_t-2-MARGIN-SHRINK):
+ *                  the sum did not shrink by more than SHRINK bits); if any check fails anywhere, the whole pass is
+ *                  repeated on measured exponents.
+ *   row i: d_i in row order; rows with k_i = 0 or d_i outside [2^-900, 2^900] are skipped (degenerate state);
+ *       for each hit t:  Y = ldexp(x_i, E_t);  HI_t += trunc(Y);  LO_t += trunc(ldexp(Y - trunc(Y), sl_t) + 0.5)
+ *       v = k_i*log(d_i)*2^12:  LLH += floor(v);  LLL += trunc((v - floor(v))*2^31)               (none can overflow 64 bits)
+ *   S_t = ldexp((double)HI_t + ldexp((double)LO_t, -sl_t), -E_t);  mu_t <- mu_t*S_t/l_t
+ *   loglik = ((double)LLH*2^-12 + (double)LLL*2^-43) - pen,  pen = sum_t mu_t l_t by 256-blocks (halving tree inside a
+ *       block, blocks added in index order).
+ * A term is rounded at 2^-(2 sl_t - 2) of the largest term (measured) or at most 2^-(2 sl_t - 18) of S_t (carried), with
+ * sl_t >= 31 (>= 37 below 2^26 hits per transcript): below the fp64 rounding of the reference's own sums; tests pin this against orc_em_seq. */
+static inline int em_bitlen(uint64_t v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
+#define ORC_EM_DEAD (-32768)
+#define ORC_EM_MARGIN 8
+#define ORC_EM_SHRINK 8
+static inline int em_alive(double v) { return v > 0.0 && v < INFINITY; }
+static double em_pen(uint32_t n, const double *mu, const double *l)
+{
+    double tot = 0.0, red[256];
+    for (uint32_t b0 = 0; b0 < n; b0 += 256) {
+        for (uint32_t i = 0; i < 256; ++i) red[i] = (b0 + i < n) ? mu[b0 + i] * l[b0 + i] : 0.0;
+        for (int s = 128; s > 0; s >>= 1) for (int i = 0; i < s; ++i) red[i] += red[i + s];
+        tot += red[0];
+    }
+    return tot;
+}
+/* One rows pass.  measure != 0: only XE (max ilogb(x_i) per column, INT32_MIN where none).  Otherwise HI/LO and the
+ * log-likelihood limbs from mu / E; returns 1 if a checked term failed. */
+static int em_rows_pass(int measure, uint64_t m, const uint64_t *row_ptr, const uint32_t *col_idx, const uint32_t *k,
+                        const double *mu, const int32_t *E, const int32_t *cap, const int32_t *sl, int32_t *XE, uint64_t *HI,
+                        uint64_t *LO, int64_t *llh, uint64_t *lll)
+{
+    int64_t h = 0; uint64_t lo = 0;
+    int viol = 0;
+    for (uint64_t i = 0; i < m; ++i) {
+        const uint64_t b = row_ptr[i], e = row_ptr[i + 1];
+        if (e == b) continue;
+        double d = 0.0;
+        for (uint64_t j = b; j < e; ++j) d += mu[col_idx[j]];
+        if ((k && k[i] == 0) || !(d >= 0x1p-900 && d <= 0x1p900)) continue;
+        const double kk = (double)(k ? k[i] : 1u), x = kk / d;
+        const int xe = ilogb(x);
+        if (measure) {
+            for (uint64_t j = b; j < e; ++j) if (xe > XE[col_idx[j]]) XE[col_idx[j]] = xe;
+            continue;
+        }
+        const double v = kk * orc_log(d) * 4096.0, fv = floor(v);
+        h += (int64_t)fv;
+        lo += (uint64_t)((v - fv) * 2147483648.0);
+        for (uint64_t j = b; j < e; ++j) {
+            const uint32_t t = col_idx[j];
+            if (E[t] == ORC_EM_DEAD) continue;
+            if (xe + E[t] >= cap[t]) { viol = 1; continue; }
+            const double Y = ldexp(x, E[t]);
+            const uint64_t yh = (uint64_t)Y;
+            HI[t] += yh;
+            LO[t] += (uint64_t)(ldexp(Y - (double)yh, sl[t]) + 0.5);
+        }
+    }
+    if (!measure) { *llh = h; *lll = lo; }
+    return viol;
+}
+/* redo_out (optional): number of passes that had to be repeated on measured exponents */
+int orc_em_x(uint64_t m, uint32_t n, const uint64_t *row_ptr, const uint32_t *col_idx, const uint32_t *k,
+             const double *l, double *mu, int max_iter, double epsilon, double *loglik_out, int *redo_out)
+{
+    int32_t *sl = (int32_t *)malloc(n * sizeof(int32_t)), *XE = (int32_t *)malloc(n * sizeof(int32_t));
+    int32_t *E = (int32_t *)malloc(n * sizeof(int32_t)), *sexp = (int32_t *)malloc(n * sizeof(int32_t));
+    int32_t *cap = (int32_t *)malloc(n * sizeof(int32_t));
+    uint64_t *HI = (uint64_t *)calloc(n, sizeof(uint64_t)), *LO = (uint64_t *)malloc(n * sizeof(uint64_t));
+    for (uint64_t j = 0; j < row_ptr[m]; ++j) HI[col_idx[j]]++;
+    for (uint32_t t = 0; t < n; ++t) { sl[t] = 63 - em_bitlen(HI[t]); sexp[t] = INT32_MIN; }
+    int64_t llh = 0; uint64_t lll = 0;
+    int redo = 0, first = 1;
+#define EM_PASS() do { \
+        for (int measured = first; measured < 2; ++measured) { \
+            if (measured) { \
+                for (uint32_t t = 0; t < n; ++t) XE[t] = INT32_MIN; \
+                em_rows_pass(1, m, row_ptr, col_idx, k, mu, NULL, NULL, sl, XE, NULL, NULL, NULL, NULL); \
+            } \
+            for (uint32_t t = 0; t < n; ++t) { \
+                const int32_t ref = measured ? XE[t] : sexp[t]; \
+                HI[t] = 0; LO[t] = 0; \
+                if (!em_alive(mu[t]) || ref == INT32_MIN) { E[t] = ORC_EM_DEAD; cap[t] = 63; } \
+                else if (measured) { E[t] = sl[t] - 2 - ref; cap[t] = 63; } \
+                else { E[t] = sl[t] - 2 - ref - ORC_EM_MARGIN; cap[t] = sl[t] - 1; } \
+            } \
+            int viol = em_rows_pass(0, m, row_ptr, col_idx, k, mu, E, cap, sl, NULL, HI, LO, &llh, &lll); \
+            if (!measured) for (uint32_t t = 0; t < n; ++t) \
+                if (E[t] != ORC_EM_DEAD && (HI[t] >> (sl[t] - 2 - ORC_EM_MARGIN - ORC_EM_SHRINK)) == 0) viol = 1; \
+            if (!viol) break; \
+            ++redo; \
+        } first = 0; } while (0)
+#define EM_LL() (((double)llh * 0x1p-12 + (double)lll * 0x1p-43) - em_pen(n, mu, l))
+    EM_PASS();
+    double loglik = EM_LL();
+    double llr = INFINITY; /* the reference starts from epsilon+1 (src/mmseq.cpp:756): first sweep always runs */
+    int iter = 0;
+    while (iter < max_iter && llr > epsilon) {
+        for (uint32_t t = 0; t < n; ++t) {
+            const double S = E[t] == ORC_EM_DEAD ? 0.0 : ldexp((double)HI[t] + ldexp((double)LO[t], -sl[t]), -E[t]);
+            mu[t] = mu[t] * S / l[t];
+            sexp[t] = em_alive(S) ? (int32_t)ilogb(S) : INT32_MIN;
+        }
+        EM_PASS();
+        const double ll = EM_LL();
+        llr = ll - loglik;
+        loglik = ll;
+        iter++;
+    }
+#undef EM_PASS
+#undef EM_LL
+    if (loglik_out) *loglik_out = loglik;
+    if (redo_out) *redo_out = redo;
+    free(sl); free(XE); free(E); free(sexp); free(cap); free(HI); free(LO);
+    return iter;
+}
+int orc_em(uint64_t m, uint32_t n, const uint64_t *row_ptr, const uint32_t *col_idx, const uint32_t *k,
+           const double *l, double *mu, int max_iter, double epsilon, double *loglik_out)
+{
+    return orc_em_x(m, n, row_ptr, col_idx, k, l, mu, max_iter, epsilon, loglik_out, NULL);
 }
 
 /* src/uh.cpp:3-26 literally: for each group g, sum k_i over rows whose every column

@@ -183,16 +183,85 @@ def test_start_values_and_em_match_oracle(gpu, orc):
     em_o, it_o, ll_o = orc.em(p, mu0)
     em_g, it_g, ll_g = prob.em(mu0)
     assert it_g == it_o
-    np.testing.assert_allclose(ll_g, ll_o, rtol=1e-12)      # only the summation tree of the log-likelihood differs
-    assert np.array_equal(em_g, em_o)                        # the EM trajectory itself is deterministic and bit-exact
+    assert ll_g == ll_o                                      # exact fixed-point sums: the log-likelihood too
+    assert np.array_equal(em_g, em_o)                        # the EM trajectory is order-independent and bit-exact
     em_g2, _, _ = prob.em(mu0)
     assert np.array_equal(em_g, em_g2)
-    # single-sweep calls (how the CLI drives it) compose to the same trajectory
-    mu = mu0
+    # single-sweep calls restart the scale carry-over, on the device as in the oracle
+    mu, mo = mu0, mu0
     for _ in range(3):
         mu, it1, _ = prob.em(mu, max_iter=1, epsilon=-1e308)
+        mo = orc.em(p, mo, max_iter=1, epsilon=-1e308)[0]
         assert it1 == 1
-    assert np.array_equal(mu, orc.em(p, mu0, max_iter=3, epsilon=-1e308)[0])
+    assert np.array_equal(mu, mo)
+    np.testing.assert_allclose(mu, orc.em(p, mu0, max_iter=3, epsilon=-1e308)[0], rtol=1e-13)
+
+
+@pytest.mark.parametrize("sort,stream_env,grid", [(True, None, None), (True, None, "7"), (True, "0", None), (False, None, None)])
+def test_em_stepper_paths_match_oracle(gpu, orc, monkeypatch, sort, stream_env, grid):
+    """Tile-stream kernel (sorted rows), row-per-thread kernel (forced / unsorted rows): same bits as the oracle,
+    with multiplicities, dead transcripts and an empty row; the oracle in turn tracks the reference's summation order."""
+    if stream_env is not None:
+        monkeypatch.setenv("MMG_EM_STREAM", stream_env)
+    if grid is not None:
+        monkeypatch.setenv("MMG_EM_GRID", grid)      # few workgroups: long tile ranges, the window slides many times
+    p, aux = orc.synth_problem(R=60000, T=2500, avg_hits=7, seed=11, sort=sort)
+    rng = np.random.default_rng(5)
+    k = rng.choice([1, 1, 1, 2, 7, 1000], size=p.m).astype(np.uint32)
+    rp = np.concatenate([p.row_ptr[:1000], p.row_ptr[999:]])          # an empty row in the middle
+    k = np.concatenate([k[:999], [3], k[999:]]).astype(np.uint32)
+    pk = orc.Problem(rp, p.col_idx, p.l * 20, k=k)
+    mu0, _ = orc.start_values(pk)
+    mu0[5::97] = 0.0                                                    # dead from the start
+    prob = gpu.Problem.from_csr(pk.row_ptr, pk.col_idx, pk.l, k=pk.k)
+    em = prob.em_stepper(mu0)
+    st = em.stats()
+    assert st["stream_kernel"] == (sort and stream_env is None)
+    lls = [em.loglik]
+    for _ in range(12):
+        lls.append(em.step())
+    mu_g = em.mu()
+    assert em.stats()["sweeps"] == 12
+    for it in (0, 1, 12):
+        mu_o, _, ll_o = orc.em(pk, mu0, max_iter=it, epsilon=-1e308)
+        assert lls[it] == ll_o
+    assert np.array_equal(mu_g, mu_o)
+    assert (mu_g[5::97] == 0).all()
+    em.close()
+    # without dead transcripts and the empty row (the reference's arithmetic turns those into NaN), the same device
+    # path follows the reference's own summation order to rounding
+    mu1, _ = orc.start_values(pk)
+    keep = np.ones(pk.m, bool)
+    keep[999] = False
+    p2 = orc.Problem(p.row_ptr, p.col_idx, pk.l, k=pk.k[keep])
+    prob2 = gpu.Problem.from_csr(p2.row_ptr, p2.col_idx, p2.l, k=p2.k)
+    mu_g2, it_g2, ll_g2 = prob2.em(mu1, max_iter=12, epsilon=-1e308)
+    mu_s, _, ll_s = orc.em_seq(p2, mu1, max_iter=12, epsilon=-1e308)
+    np.testing.assert_allclose(mu_g2, mu_s, rtol=1e-11)
+    np.testing.assert_allclose(ll_g2, ll_s, rtol=1e-12)
+    prob.close()
+    prob2.close()
+
+
+@pytest.mark.parametrize("scale", [1e-200, 1e-30, 1e30, 1e150])
+def test_em_wild_start_values_take_the_repeat_path(gpu, orc, scale):
+    """Start values spanning hundreds of orders of magnitude force passes to be repeated on measured exponents:
+    the device takes the same decisions as the oracle (same bits) and both stay on the reference trajectory."""
+    p, aux = orc.synth_problem(R=20000, T=900, avg_hits=6, seed=5)
+    mu0, _ = orc.start_values(p)
+    mu0[::7] *= scale
+    mu0[3] = 0.0
+    prob = gpu.Problem.from_csr(p.row_ptr, p.col_idx, p.l)
+    em = prob.em_stepper(mu0)
+    for _ in range(20):
+        em.step()
+    mu_o, _, ll_o, redo = orc.em_x(p, mu0, max_iter=20, epsilon=-1e308)
+    assert redo >= 1 and em.stats()["repeated_passes"] == redo
+    assert np.array_equal(em.mu(), mu_o) and em.loglik == ll_o
+    mu_s, _, _ = orc.em_seq(p, mu0, max_iter=20, epsilon=-1e308)
+    live = mu_s > 0
+    np.testing.assert_allclose(mu_o[live], mu_s[live], rtol=1e-11)
+    assert np.array_equal(mu_o == 0, mu_s == 0)
 
 
 def test_errors_are_loud(gpu):

@@ -178,3 +178,34 @@ def test_uh_literal_semantics(orc):
     p = _problem(orc, [[0], [0, 1], [2], [], [1, 2]], [3, 4, 5, 7, 1], [1, 1, 1])
     member = np.array([[1, 0], [1, 0], [0, 1]], np.uint8)   # group0={0,1}, group1={2}
     assert orc.uh(p, member).tolist() == [3 + 4 + 7, 5 + 7]
+
+
+def test_em_fixed_point_spec_tracks_reference_order(orc):
+    """orc.em (exact fixed-point sums, the spec the device implements) against orc.em_seq (src/mmseq.cpp:761-811 in the
+    reference's own summation order): same iteration counts, same zero pattern, mu within fp64 rounding of the sums --
+    over 300 sweeps, with transcripts decaying towards zero, and from start values spanning 10^+-150."""
+    p, _ = orc.synth_problem(R=20000, T=900, avg_hits=6, seed=5)
+    mu0, _ = orc.start_values(p)
+    a, b = orc.em(p, mu0), orc.em_seq(p, mu0)
+    assert a[1] == b[1] and abs(a[2] - b[2]) < 1e-6
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-12)
+    a = orc.em_x(p, mu0, max_iter=300, epsilon=-1e308)
+    b = orc.em_seq(p, mu0, max_iter=300, epsilon=-1e308)
+    assert a[3] == 0                                     # ordinary sweeps never need the measured-exponent repeat
+    live = b[0] > 0
+    assert np.array_equal(a[0] == 0, b[0] == 0) and b[0][live].min() < 1e-60
+    np.testing.assert_allclose(a[0][live], b[0][live], rtol=1e-11)
+    rng = np.random.default_rng(0)
+    k = rng.integers(1, 1000, size=p.m).astype(np.uint32)
+    pk = orc.Problem(p.row_ptr, p.col_idx, p.l * 10, k=k)
+    mu0, _ = orc.start_values(pk)
+    for scale in (1e-150, 1e-30, 1e150):
+        m0 = mu0.copy()
+        m0[::7] *= scale
+        m0[3] = 0.0
+        a = orc.em_x(pk, m0, max_iter=40, epsilon=-1e308)
+        b = orc.em_seq(pk, m0, max_iter=40, epsilon=-1e308)
+        live = b[0] > 0
+        assert a[3] >= 1 and np.array_equal(a[0] == 0, b[0] == 0)
+        np.testing.assert_allclose(a[0][live], b[0][live], rtol=1e-11)
+        assert abs(a[2] - b[2]) < 1e-4
