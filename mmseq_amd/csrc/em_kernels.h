@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void k_em_rows_global(const IdxT *__restrict__
 }
 
 // The rows pass on K1's 16-bit tile stream (same tiles, same window policy, same depth-2 prefetch).
-template <typename IdxT, bool HAS_K, int ELEMS, int WIN, int BS, int RC, bool MEASURE>
+template <typename IdxT, bool HAS_K, int ELEMS, int WIN, int BS, int RC, bool MEASURE, int ABL = 0>
 __global__ __launch_bounds__(BS) void k_em16(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
                                              const uint32_t *__restrict__ kmult, const S16Tile *__restrict__ tiles,
                                              const uint64_t *__restrict__ chunk_tile, const u32x4 *__restrict__ stream16, EmArgs a)
@@ -344,9 +344,11 @@ __global__ __launch_bounds__(BS) void k_em16(const IdxT *__restrict__ row_ptr, c
                         atomicMax((int32_t *)((char *)s_xe + (off >> 1)), xe);
                     } else {
                         uint64_t yh, yl;
+                        if (ABL == 3 && j == 0) continue;
                         if (em_term(x, xe, *(const uint32_t *)((const char *)s_w + (off >> 1)), acc, yh, yl)) {
+                            if (ABL == 2) { acc.lll ^= yh ^ yl; continue; }
                             atomicAdd((unsigned long long *)((char *)s_hi + off), (unsigned long long)yh);
-                            atomicAdd((unsigned long long *)((char *)s_lo + off), (unsigned long long)yl);
+                            if (ABL != 1) atomicAdd((unsigned long long *)((char *)s_lo + off), (unsigned long long)yl);
                         }
                     }
                 }

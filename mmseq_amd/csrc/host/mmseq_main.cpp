@@ -201,8 +201,23 @@ static void write_trace_lines(GzText &gz, int n_lines, size_t n_cols, const func
     }
 }
 
+// Stage timings on stderr when MMSEQ_TIMING is set (not part of the reference's output)
+struct StageTimer {
+    bool on = getenv("MMSEQ_TIMING") != nullptr;
+    double t0 = omp_get_wtime(), last = t0;
+    void mark(const char *what)
+    {
+        if (!on) return;
+        const double now = omp_get_wtime();
+        fprintf(stderr, "[timing] %-28s %8.3f s\n", what, now - last);
+        last = now;
+    }
+    void total() { if (on) fprintf(stderr, "[timing] %-28s %8.3f s\n", "total", omp_get_wtime() - t0); }
+};
+
 int main(int argc, char **argv)
 {
+    StageTimer stage;
     const int max_threads = omp_get_max_threads();
 
     // DEFAULT PARAMETER VALUES (src/mmseq.cpp:183-205)
@@ -407,6 +422,7 @@ int main(int argc, char **argv)
         return it == cache.end() ? -1 : it->second;
     };
 
+    stage.mark("read hits file + collapse");
     // ---- l[t] (src/mmseq.cpp:593-608)
     vector<double> l(n);
     for (uint32_t t = 0; t < n; t++) {
@@ -508,6 +524,7 @@ int main(int argc, char **argv)
         ofs.close(); ofs.clear();
     }
 
+    stage.mark("host tables (.k .M uh)");
     // ---- device problem: rows stably sorted by (leading transcript, length) -- the layout the sample
     //      kernel's LDS window wants; the row order is irrelevant to the model (rows are exchangeable)
     mmg_problem *prob = nullptr;
@@ -535,6 +552,7 @@ int main(int argc, char **argv)
         MMG_TRY(mmg_problem_create(&pd, device, &prob));
     }
 
+    stage.mark("device problem build");
     // ---- EM on the device (src/mmseq.cpp:741-811): mu stays there; this loop owns the stopping rule and the output
     GzText *gz_em = debug ? new GzText(output_base + ".trace_em.gz") : nullptr;
     if (gz_em) { for (uint32_t t = 0; t < n; t++) { gz_em->str(sid(t)); gz_em->str(" "); } gz_em->str("\n"); }
@@ -569,6 +587,7 @@ int main(int argc, char **argv)
     if (gz_em) { gz_em->close(); delete gz_em; }
     const vector<double> mu_em = mu;
 
+    stage.mark("EM");
     // ---- Gibbs on the device (src/mmseq.cpp:833-918)
     vector<double> mu_trace((size_t)n * trace_length);
     {
@@ -591,6 +610,7 @@ int main(int argc, char **argv)
     }
     mmg_problem_destroy(prob);
 
+    stage.mark("Gibbs + trace download");
     // ---- .trace_gibbs.gz (src/mmseq.cpp:823-831, :911-917), written after the loop
     {
         GzText gz(output_base + ".trace_gibbs.gz");
@@ -603,6 +623,7 @@ int main(int argc, char **argv)
 
     cout << "Amalgamating transcripts and calculating summary statistics..." << flush;
 
+    stage.mark("write .trace_gibbs.gz");
     // ---- trace aggregation (src/mmseq.cpp:927-1008)
     const size_t nI = identical_transcripts.size(), nG = gene2transcripts.size();
     vector<double> mu_trace_identical(nI * trace_length, 0.0), mu_trace_gene(nG * trace_length, 0.0);
@@ -685,6 +706,7 @@ int main(int argc, char **argv)
         gp.close();
     }
 
+    stage.mark("aggregate traces + write");
     // ---- percentiles (src/mmseq.cpp:1110-1192)
     const size_t nP = percentiles.size();
     vector<int> pind(nP);
@@ -801,6 +823,7 @@ int main(int argc, char **argv)
         for (size_t i = 0; i < nP; i++) { o << percentiles[i]; o << (i == nP - 1 ? term : ","); }
     };
 
+    stage.mark("summaries (pct, log, sokal)");
     // ---- .mmseq (src/mmseq.cpp:1469-1554)
     ofs.open((output_base + ".mmseq").c_str());
     ofs << "# Mapped fragments: " << numbermappedreads << endl;
@@ -917,5 +940,7 @@ int main(int argc, char **argv)
              << "  " << output_base << ".doublehits" << endl
              << "  " << output_base << ".dupIDs" << endl;
     }
+    stage.mark("write tables");
+    stage.total();
     return 0;
 }

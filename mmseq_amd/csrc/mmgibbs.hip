@@ -570,6 +570,15 @@ static const void *em16_kernel(const mmg_problem *p)
 {
     if (!p->use16 || p->variant != 0) return nullptr;
     const bool hk = p->d_k != nullptr;
+    if (!MEASURE && !hk && !p->idx64) {
+        if (const char *ab = getenv("MMG_EM_ABL")) { // timing ablations (wrong results by design)
+            switch (atoi(ab)) {
+            case 1: return (const void *)k_em16<uint32_t, false, 2560, 256, 128, 128, false, 1>;
+            case 2: return (const void *)k_em16<uint32_t, false, 2560, 256, 128, 128, false, 2>;
+            case 3: return (const void *)k_em16<uint32_t, false, 2560, 256, 128, 128, false, 3>;
+            }
+        }
+    }
     if (p->idx64) return hk ? (const void *)k_em16<uint64_t, true, 2560, 256, 128, 128, MEASURE> : (const void *)k_em16<uint64_t, false, 2560, 256, 128, 128, MEASURE>;
     return hk ? (const void *)k_em16<uint32_t, true, 2560, 256, 128, 128, MEASURE> : (const void *)k_em16<uint32_t, false, 2560, 256, 128, 128, MEASURE>;
 }

@@ -22,10 +22,11 @@ open(path, "wb").write(H.write_hits_binary(h))
 print("generated %d reads, %.1f MB binary hits file in %.1fs" % (R, os.path.getsize(path) / 1e6, time.time() - t0), flush=True)
 exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mmseq_amd", "csrc", "mmseq")
 t0 = time.time()
-r = subprocess.run([exe, "-gibbs_iter", "1024", path, "/tmp/scale_out"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+r = subprocess.run([exe, "-gibbs_iter", "1024", path, "/tmp/scale_out"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                   env=dict(os.environ, MMSEQ_TIMING="1"))
 print("mmseq rc=%d wall=%.1fs" % (r.returncode, time.time() - t0))
 print(r.stdout.decode().replace("\r", "\n")[-1500:])
-print(r.stderr.decode()[-500:])
+print(r.stderr.decode()[-1500:])
 tab = open("/tmp/scale_out.mmseq").read().split("\n")
 print(tab[0], "| rows", len(tab) - 3)
 uh = sum(int(l.split("\t")[7]) for l in tab[2:-1])
