@@ -188,7 +188,7 @@ def main():
                                                       "(int32 count all-reduce per iteration)" % world),
                        "trace": "every iteration kept (fp64 mu trace resident in HBM)", "generator_seed": args.seed},
             "reads_iters_per_sec": iters_per_s * reads_per_chain,
-            "roofline": {"bound": "hbm", "kernel": "k_sample (K1)", "achieved": ach, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_sample16 (K1)", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(args, C),
                          "algorithmic_bytes_per_launch": b_k1, "avg_launch_ms": k1_ms,
                          "traffic_frac_of_peak": (pmc_traffic(args, C) / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)

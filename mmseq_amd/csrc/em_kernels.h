@@ -41,10 +41,10 @@ __device__ __forceinline__ double block_sum_256(double v, double *red)
 }
 
 // N_t: hits per column
-__global__ __launch_bounds__(256) void k_em_colcount(const uint32_t *__restrict__ col_idx, uint64_t nnz, uint32_t *cnt)
+__global__ __launch_bounds__(256) void k_em_colcount(const uint32_t *__restrict__ col_idx, uint64_t nnz, uint64_t *cnt)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nnz; j += stride) atomicAdd(&cnt[col_idx[j]], 1u);
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nnz; j += stride) atomicAdd((unsigned long long *)&cnt[col_idx[j]], 1ull);
 }
 
 __global__ void k_fill_i32(int32_t *p, uint32_t n, int32_t v)
@@ -56,7 +56,7 @@ __global__ void k_fill_i32(int32_t *p, uint32_t n, int32_t v)
 // Before a rows pass: the scale word of every transcript (measured: from XE; carried: from the last sum),
 // cleared accumulators, and the penalty sum_t mu_t l_t as one partial per 256-block.
 __global__ __launch_bounds__(256) void k_em_prepare(uint32_t n, const double *__restrict__ mu, const double *__restrict__ l,
-                                                    const uint32_t *__restrict__ colcnt, const int32_t *__restrict__ ref,
+                                                    const uint64_t *__restrict__ colcnt, const int32_t *__restrict__ ref,
                                                     int measured, uint32_t *__restrict__ word, uint64_t *__restrict__ hi,
                                                     uint64_t *__restrict__ lo, double *__restrict__ partial, uint64_t *ll)
 {
@@ -65,8 +65,8 @@ __global__ __launch_bounds__(256) void k_em_prepare(uint32_t n, const double *__
     double pen = 0.0;
     if (t < n) {
         const double m = mu[t];
-        const uint32_t N = colcnt[t];
-        const int sl = 63 - (N ? 32 - __builtin_clz(N) : 0);
+        const uint64_t N = colcnt[t];
+        const int sl = 63 - (N ? 64 - __builtin_clzll(N) : 0);
         const int32_t r = ref[t];
         const bool alive = m > 0.0 && m < __builtin_huge_val();
         uint32_t w;

@@ -134,7 +134,7 @@ struct mmg_problem {
     int grid16 = 0;
     bool use16 = false;
     double s16_fast_fraction = 0.0;
-    uint32_t *d_colcnt = nullptr;   // hits per transcript, for the EM scale words (lazy)
+    uint64_t *d_colcnt = nullptr;   // hits per transcript, for the EM scale words (lazy)
     uint64_t *d_chunk_tile = nullptr;
     uint64_t n_chunks = 0;
     int grid_sample = 1;
@@ -648,14 +648,14 @@ extern "C" int mmg_em_create(const mmg_problem *cp, const double *mu0, mmg_em **
     mmg_problem *p = const_cast<mmg_problem *>(cp); // the lazily built column counts are a cache
     HIP_TRY(hipSetDevice(p->device));
     if (!p->d_colcnt) {
-        HIP_TRY(hipMalloc((void **)&p->d_colcnt, p->n * sizeof(uint32_t)));
-        HIP_TRY(hipMemset(p->d_colcnt, 0, p->n * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **)&p->d_colcnt, p->n * sizeof(uint64_t)));
+        HIP_TRY(hipMemset(p->d_colcnt, 0, p->n * sizeof(uint64_t)));
         if (p->nnz) {
             const unsigned g = (unsigned)std::min<uint64_t>((p->nnz + 255) / 256, (uint64_t)p->cu_count * 32);
             hipLaunchKernelGGL(k_em_colcount, dim3(g), dim3(256), 0, 0, p->d_col, p->nnz, p->d_colcnt);
             HIP_TRY(hipGetLastError());
         }
-        p->device_bytes += p->n * 4;
+        p->device_bytes += p->n * 8;
     }
     mmg_em *e = new mmg_em();
     e->p = p;
