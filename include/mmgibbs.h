@@ -77,6 +77,9 @@ typedef struct mmg_problem_info {
     uint64_t n_tiles;      /* LDS tiles the sample kernel walks                           */
     uint64_t device_bytes; /* HBM held by the problem                                     */
     int32_t index_bits;    /* 32 or 64: width of the device row_ptr                       */
+    int32_t sample_kernel; /* what mmg_sampler_sample launches: 0 k_sample (32-bit CSR tiles), 1 k_sample16
+                              (16-bit tile stream), 2 k_sample_sell (sliced-ELL 16-bit stream)   */
+    uint64_t stream_bytes; /* bytes of the tile stream that kernel reads per launch (0 for kernel 0) */
 } mmg_problem_info;
 
 /* Parameters of the Gibbs loop: alpha/beta are the Gamma prior (src/mmseq.cpp:184-185),

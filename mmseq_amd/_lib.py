@@ -31,7 +31,8 @@ class SynthDesc(C.Structure):
 class ProblemInfo(C.Structure):
     _fields_ = [("m", C.c_uint64), ("nnz", C.c_uint64), ("total_k", C.c_uint64), ("row_id_base", C.c_uint64),
                 ("n", C.c_uint32), ("max_row_len", C.c_uint32), ("n_tiles", C.c_uint64),
-                ("device_bytes", C.c_uint64), ("index_bits", C.c_int32)]
+                ("device_bytes", C.c_uint64), ("index_bits", C.c_int32), ("sample_kernel", C.c_int32),
+                ("stream_bytes", C.c_uint64)]
 
 
 class Config(C.Structure):

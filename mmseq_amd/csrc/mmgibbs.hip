@@ -3,6 +3,7 @@
 #include "../../include/mmgibbs.h"
 #include "gibbs_kernels.h"
 #include "em_kernels.h"
+#include "sell_kernels.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -135,6 +136,15 @@ struct mmg_problem {
     bool use16 = false;
     double s16_fast_fraction = 0.0;
     uint64_t *d_colcnt = nullptr;   // hits per transcript, for the EM scale words (lazy)
+    // SELL-64 stream of k_sample_sell (problems without multiplicities)
+    uint8_t *d_sell = nullptr;
+    uint64_t sell_bytes = 0, n_sell_tiles = 0;
+    SellTile *d_sell_tiles = nullptr;
+    uint64_t *d_sell_chunk = nullptr;
+    int grid_sell = 0;
+    bool use_sell = false;
+    double sell_fast_fraction = 0.0;
+    std::vector<uint8_t> h_sell_ng;   // per 64-row tile: groups of the longest row (0: empty, 255: too long); consumed by problem_build_desc
     uint64_t *d_chunk_tile = nullptr;
     uint64_t n_chunks = 0;
     int grid_sample = 1;
@@ -156,6 +166,9 @@ static void problem_free(mmg_problem *p)
     if (p->d_s16tiles) (void)hipFree(p->d_s16tiles);
     if (p->d_chunk_tile16) (void)hipFree(p->d_chunk_tile16);
     if (p->d_colcnt) (void)hipFree(p->d_colcnt);
+    if (p->d_sell) (void)hipFree(p->d_sell);
+    if (p->d_sell_tiles) (void)hipFree(p->d_sell_tiles);
+    if (p->d_sell_chunk) (void)hipFree(p->d_sell_chunk);
     if (p->d_chunk_tile) (void)hipFree(p->d_chunk_tile);
     delete p;
 }
@@ -210,6 +223,16 @@ static int problem_finish(mmg_problem *p, const uint64_t *h_row_ptr)
         p->device_bytes += (p->m + 1) * 4;
     }
     p->h_tile_row.swap(tiles);
+    if (!p->d_k && p->m) { // SELL-64 tiling: fixed 64-row slices, groups of the longest row
+        const uint64_t nt64 = (p->m + 63) / 64;
+        p->h_sell_ng.assign(nt64, 0);
+        for (uint64_t t = 0; t < nt64; ++t) {
+            uint64_t mx = 0;
+            const uint64_t r1 = std::min<uint64_t>(p->m, (t + 1) * 64);
+            for (uint64_t r = t * 64; r < r1; ++r) mx = std::max<uint64_t>(mx, h_row_ptr[r + 1] - h_row_ptr[r]);
+            p->h_sell_ng[t] = mx > 255 ? 255 : (uint8_t)((mx + 3) / 4);
+        }
+    }
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, p->device));
     p->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -236,6 +259,87 @@ static int problem_finish(mmg_problem *p, const uint64_t *h_row_ptr)
 }
 
 // per-tile descriptors, built on the device from the RESIDENT CSR (col_idx must be final)
+static const void *k1_sell_kernel(bool idx64)
+{
+    return idx64 ? (const void *)k_sample_sell<uint64_t, 8> : (const void *)k_sample_sell<uint32_t, 8>;
+}
+
+// SELL-64 stream for k_sample_sell: tiles of 64 rows, the window policy of the 16-bit stream, one block per tile.
+static int problem_build_sell(mmg_problem *p)
+{
+    std::vector<uint8_t> ngs;
+    ngs.swap(p->h_sell_ng);
+    const char *ev = getenv("MMG_K1_SELL");
+    if (ngs.empty() || p->d_k || (ev && atoi(ev) == 0)) return MMG_OK;
+    const uint64_t nt = ngs.size();
+    const uint32_t WIN = SELL_WIN;
+    std::vector<uint64_t> tile_row(nt + 1);
+    for (uint64_t t = 0; t <= nt; ++t) tile_row[t] = std::min<uint64_t>(p->m, t * 64);
+    uint64_t *d_tile_row = nullptr;
+    TileDesc *d_td = nullptr;
+    auto cleanup = [&]() { if (d_tile_row) (void)hipFree(d_tile_row); if (d_td) (void)hipFree(d_td); };
+#define SELL_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail(MMG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
+    SELL_TRY(hipMalloc((void **)&d_tile_row, tile_row.size() * sizeof(uint64_t)));
+    SELL_TRY(hipMemcpy(d_tile_row, tile_row.data(), tile_row.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    SELL_TRY(hipMalloc((void **)&d_td, nt * sizeof(TileDesc)));
+    if (p->idx64) hipLaunchKernelGGL(k_tile_desc<uint64_t>, dim3((unsigned)nt), dim3(64), 0, 0, (const uint64_t *)p->d_row_ptr, p->d_col, d_tile_row, nt, d_td);
+    else hipLaunchKernelGGL(k_tile_desc<uint32_t>, dim3((unsigned)nt), dim3(64), 0, 0, (const uint32_t *)p->d_row_ptr, p->d_col, d_tile_row, nt, d_td);
+    SELL_TRY(hipGetLastError());
+    std::vector<TileDesc> td(nt);
+    SELL_TRY(hipMemcpy(td.data(), d_td, nt * sizeof(TileDesc), hipMemcpyDeviceToHost));
+    cleanup();
+    d_tile_row = nullptr; d_td = nullptr;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k1_sell_kernel(p->idx64), 64, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 16; }
+    if (per_cu > 32) per_cu = 32;
+    if (const char *e2 = getenv("MMG_K1_SELL_WAVES_PER_CU")) { const int v = atoi(e2); if (v >= 1 && v <= 32) per_cu = v; }
+    const uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>(nt, (uint64_t)p->cu_count * per_cu));
+    std::vector<uint64_t> chunk(grid + 1);
+    for (uint64_t c = 0; c <= grid; ++c) chunk[c] = (uint64_t)(((unsigned __int128)nt * c) / grid);
+    std::vector<SellTile> st(nt);
+    uint64_t n_fast = 0, n_live = 0, pos = 0;
+    for (uint64_t c = 0; c < grid; ++c) {
+        bool have = false;
+        uint32_t cur = 0;
+        for (uint64_t t = chunk[c]; t < chunk[c + 1]; ++t) if (td[t].nnz) { cur = td[t].cmin & ~15u; break; }
+        for (uint64_t t = chunk[c]; t < chunk[c + 1]; ++t) {
+            const TileDesc &d = td[t];
+            SellTile &q = st[t];
+            q.off16 = 0; q.r0 = d.r0; q.meta = sell_meta(d.nrows, 0, 0);
+            if (d.nnz == 0) { q.meta = sell_meta(d.nrows, 0, S16_EMPTY); q.wbase = cur; continue; }
+            const bool keep = have && d.cmin >= cur && (uint64_t)d.clast + K1_WIN_MARGIN <= (uint64_t)cur + WIN;
+            if (!keep) { cur = d.cmin & ~15u; have = true; }
+            q.wbase = cur;
+            const bool inwin = d.call >= cur && (uint64_t)d.cmax < (uint64_t)cur + WIN;
+            if (inwin && ngs[t] >= 1 && ngs[t] <= 64) { // rows of at most 255 hits (the length byte), all columns inside the window
+                q.meta = sell_meta(d.nrows, ngs[t], S16_FAST);
+                q.off16 = pos;
+                pos += 4 + 16 * (uint64_t)ngs[t];
+                ++n_fast;
+            }
+            ++n_live;
+        }
+    }
+    p->sell_fast_fraction = n_live ? (double)n_fast / (double)n_live : 0.0;
+    p->use_sell = p->sell_fast_fraction >= 0.9 || (ev && atoi(ev) == 2);
+    if (!p->use_sell) return MMG_OK;
+    p->sell_bytes = pos * 16;
+    p->n_sell_tiles = nt;
+    HIP_TRY(hipMalloc((void **)&p->d_sell, p->sell_bytes + 64));
+    HIP_TRY(hipMalloc((void **)&p->d_sell_tiles, nt * sizeof(SellTile)));
+    HIP_TRY(hipMemcpy(p->d_sell_tiles, st.data(), nt * sizeof(SellTile), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void **)&p->d_sell_chunk, chunk.size() * sizeof(uint64_t)));
+    HIP_TRY(hipMemcpy(p->d_sell_chunk, chunk.data(), chunk.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    if (p->idx64) hipLaunchKernelGGL(k_encode_sell<uint64_t>, dim3((unsigned)nt), dim3(64), 0, 0, (const uint64_t *)p->d_row_ptr, p->d_col, p->d_sell_tiles, nt, p->d_sell);
+    else hipLaunchKernelGGL(k_encode_sell<uint32_t>, dim3((unsigned)nt), dim3(64), 0, 0, (const uint32_t *)p->d_row_ptr, p->d_col, p->d_sell_tiles, nt, p->d_sell);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    p->grid_sell = (int)grid;
+    p->device_bytes += p->sell_bytes + nt * sizeof(SellTile);
+#undef SELL_TRY
+    return MMG_OK;
+}
+
 static int problem_build_desc(mmg_problem *p)
 {
     std::vector<uint64_t> &tiles = p->h_tile_row;
@@ -318,7 +422,7 @@ static int problem_build_desc(mmg_problem *p)
             }
         }
         std::vector<uint64_t>().swap(tiles);
-    return MMG_OK;
+    return problem_build_sell(p);
 }
 
 extern "C" int mmg_problem_create(const mmg_problem_desc *d, int device, mmg_problem **out)
@@ -484,6 +588,8 @@ extern "C" int mmg_problem_info_get(const mmg_problem *p, mmg_problem_info *info
     info->m = p->m; info->nnz = p->nnz; info->total_k = p->total_k; info->row_id_base = p->row_id_base;
     info->n = p->n; info->max_row_len = p->max_row_len; info->n_tiles = p->n_tiles;
     info->device_bytes = p->device_bytes; info->index_bits = p->idx64 ? 64 : 32;
+    info->sample_kernel = p->use_sell ? 2 : (p->use16 ? 1 : 0);
+    info->stream_bytes = p->use_sell ? p->sell_bytes : (p->use16 ? p->stream16_bytes : 0);
     return MMG_OK;
 }
 
@@ -864,7 +970,7 @@ extern "C" int mmg_sampler_sample(mmg_sampler *s)
         for (int c = 0; c < s->cfg.n_chains;) {
             // chains are advanced in fused groups of 8 / 4 / 2 / 1 (the walk reads each hit's offset once per group)
             int fuse = 1;
-            if (p->use16) {
+            if (p->use16 && !p->use_sell) {
                 for (int f = 8; f > 1; f >>= 1)
                     if (f <= fuse_cap && c + f <= s->cfg.n_chains && k1_s16_kernel(p->variant, p->idx64, p->d_k != nullptr, f)) { fuse = f; break; }
             }
@@ -878,7 +984,13 @@ extern "C" int mmg_sampler_sample(mmg_sampler *s)
             const uint64_t *ct = p->d_chunk_tile;
             const double *mu = s->d_mu + (size_t)c * p->n;
             int32_t *cnt = s->d_cnt + (size_t)c * p->n;
-            if (p->use16) {
+            if (p->use_sell) {
+                const SellTile *ts = p->d_sell_tiles;
+                const uint64_t *cs = p->d_sell_chunk;
+                const uint8_t *ss = p->d_sell;
+                void *kargs[] = {(void *)&rp, (void *)&ci, (void *)&ts, (void *)&cs, (void *)&mu, (void *)&ss, (void *)&cnt, (void *)&a};
+                HIP_TRY(hipLaunchKernel(k1_sell_kernel(p->idx64), dim3(p->grid_sell), dim3(64), kargs, 0, s->cur));
+            } else if (p->use16) {
                 const S16Tile *t16 = p->d_s16tiles;
                 const uint64_t *c16 = p->d_chunk_tile16;
                 const void *s16 = p->d_stream16;

@@ -1,0 +1,265 @@
+// K1 on a sliced-ELL ("SELL-64") 8-bit stream: the sampler kernel for problems without multiplicities.
+//
+// k_sample16 stages every tile through LDS: the block is written there (ds_write_b128), the row extents and
+// the offsets are read back (ds_read_b128) before the mu gathers can start, and the two waves of a
+// workgroup meet at two barriers per tile.  LDS time is what bounds that kernel, and about half of it is
+// this staging, not the gathers.  Here a tile is 64 consecutive rows = one wave, stored column-major:
+// group g of the tile is 64 x (4 u8 window indices) = 256 contiguous bytes, lane r owns bytes [4r, 4r+4): one
+// byte per hit (the window holds 255 transcripts, index 255 is its 0.0 slot).  A lane loads its own row's
+// groups straight into registers with perfectly coalesced 4-byte loads; nothing but
+// the mu gathers and the count atomic touches LDS, and a workgroup is a single wave, so there is no barrier
+// on the tile path at all.  Rows are padded to the longest row of their tile (rows are sorted by leading
+// transcript and length, so slices are homogeneous) with the offset of the window's 0.0 slot: every lane
+// walks the same number of groups, a pad adds an exact 0.0 and can never be selected, so the draw equals
+// the oracle's plain sequential walk bit for bit -- same keyed stream, same additions in the same order.
+#pragma once
+
+namespace mmg {
+
+struct SellTile {
+    uint64_t off16;   // 16-byte-unit offset of the tile's block in the stream
+    uint64_t r0;      // first row
+    uint32_t wbase;   // LDS window base in force while this tile is walked
+    uint32_t meta;    // nrows (<= 64) | ng << 8 (groups of 4 hits stored for every lane: longest row of the tile) | flags << 16
+    __host__ __device__ uint32_t nrows() const { return meta & 0xffu; }
+    __host__ __device__ uint32_t ng() const { return (meta >> 8) & 0xffu; }
+    __host__ __device__ uint32_t flags() const { return meta >> 16; }
+};  // dwords only: the descriptors are fetched with scalar loads
+__host__ __device__ inline uint32_t sell_meta(uint32_t nrows, uint32_t ng, uint32_t flags) { return nrows | (ng << 8) | (flags << 16); }
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// Block of a fast tile: 64 length bytes, then ng groups of 64 lanes x 4 u8 window indices (col - wbase), 255 = pad.
+constexpr uint32_t SELL_WIN = 255;   // transcripts per window; slot 255 holds 0.0
+template <typename IdxT>
+__global__ __launch_bounds__(64) void k_encode_sell(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
+                                                    const SellTile *__restrict__ tiles, uint64_t n_tiles, uint8_t *stream)
+{
+    const uint64_t tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    const SellTile d = tiles[tile];
+    if (!(d.flags() & S16_FAST)) return;
+    uint8_t *blk = stream + d.off16 * 16;
+    const uint32_t lane = threadIdx.x;
+    uint64_t b = 0;
+    uint32_t L = 0;
+    if (lane < d.nrows()) {
+        b = row_ptr[d.r0 + lane];
+        L = (uint32_t)((uint64_t)row_ptr[d.r0 + lane + 1] - b);
+    }
+    blk[lane] = (uint8_t)L; // fast tiles hold rows of at most 255 hits
+    uint32_t *grp = (uint32_t *)(blk + 64) + lane;
+    for (uint32_t g = 0; g < d.ng(); ++g) {
+        uint32_t w = 0;
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t idx = 4 * g + j;
+            const uint32_t o = idx < L ? col_idx[b + idx] - d.wbase : SELL_WIN;
+            w |= o << (8 * j);
+        }
+        grp[(size_t)g * 64] = w;
+    }
+}
+
+template <typename IdxT, int NGC>
+__global__ __launch_bounds__(64) void k_sample_sell(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
+                                                    const SellTile *__restrict__ tiles, const uint64_t *__restrict__ chunk_tile,
+                                                    const double *__restrict__ gmu, const uint8_t *__restrict__ stream, int32_t *gcnt,
+                                                    SampleArgs a)
+{
+    constexpr int WIN = (int)SELL_WIN;
+    __shared__ __attribute__((aligned(16))) double s_mu[WIN + 1]; // [WIN] stays 0.0: what pad slots read
+    __shared__ int32_t s_cnt[WIN + 1];
+    const uint32_t lane = threadIdx.x;
+
+    const uint64_t t_begin = chunk_tile[blockIdx.x], t_end = chunk_tile[blockIdx.x + 1];
+    if (t_begin >= t_end) return;
+    const uint64_t nt = t_end - t_begin;
+    const SellTile *__restrict__ T = tiles + t_begin;
+
+    for (int i = lane; i < WIN + 1; i += 64) s_cnt[i] = 0;
+    if (lane == 0) s_mu[WIN] = 0.0;
+
+    auto flush_window = [&](uint32_t base) {
+        for (int i = lane; i < WIN; i += 64) {
+            const int32_t v = s_cnt[i];
+            if (v) { global_count_add(gcnt, base + (uint32_t)i, v); s_cnt[i] = 0; }
+        }
+    };
+    auto load_window = [&](uint32_t base) {
+        for (int i = lane; i < WIN; i += 64) {
+            const uint32_t c = base + (uint32_t)i;
+            s_mu[i] = c < a.n ? gmu[c] : 0.0;
+        }
+    };
+    auto wo = [&](uint32_t off) { return *(const double *)((const char *)s_mu + off); }; // off = window index * 8
+    // byte k of a group word as an LDS byte offset
+#define SELL_OFF0(v) (((v) << 3) & 0x7f8u)
+#define SELL_OFF1(v) (((v) >> 5) & 0x7f8u)
+#define SELL_OFF2(v) (((v) >> 13) & 0x7f8u)
+#define SELL_OFF3(v) (((v) >> 21) & 0x7f8u)
+
+    // The cached groups and the prefix sums are NAMED registers (macro-expanded), not arrays: a select chain over an
+    // array that a loop once indexed is turned back into a dynamic index by the optimiser, and the array lands in scratch.
+#define SELL_GROUPS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define SELL_GROUPS_REV(X) X(7) X(6) X(5) X(4) X(3) X(2) X(1) X(0)
+    static_assert(NGC == 8, "the group list above is written out for 8 cached groups");
+    struct Buf {
+        uint32_t g0, g1, g2, g3, g4, g5, g6, g7;
+        uint32_t len;
+    };
+    // request a tile's block: the lane's length byte and its first NGC groups (clamped, unconditional)
+    // UNCONDITIONAL: tiles without a block (empty, slow, past the end of the range) read the head of the stream instead.
+    // Loads retire in order and are waited for by count, so the number issued per tile must not depend on the path --
+    // otherwise the compiler has to assume the fewest, and every walk waits for the prefetch issued just before it.
+    auto issue = [&](const SellTile &d, Buf &bf) {
+        const bool fast = d.flags() & S16_FAST; // uniform
+        const uint8_t *__restrict__ blk = stream + (fast ? d.off16 * 16 : 0);
+        bf.len = blk[lane];
+        const uint32_t last = fast ? d.ng() - 1u : 0u;
+        // scalar base per group + one shared lane offset: the loads use the SGPR-base addressing form
+#define SELL_ISSUE(i) bf.g##i = __builtin_nontemporal_load((const uint32_t *)(blk + 64 + (size_t)min((uint32_t)i, last) * 256) + lane);
+        SELL_GROUPS(SELL_ISSUE)
+#undef SELL_ISSUE
+    };
+
+    auto walk = [&](const SellTile &d, const Buf &bf) {
+        const uint32_t ng = d.ng();                                    // uniform
+        const uint32_t *__restrict__ src = (const uint32_t *)(stream + d.off16 * 16 + 64) + lane; // groups beyond the cached ones
+        const uint32_t L = bf.len;
+        double t = 0.0;
+#define SELL_SUM(i)                                                                                          \
+        if ((uint32_t)i < ng) {                                                                              \
+            const uint32_t v = bf.g##i;                                                                      \
+            const double w0 = wo(SELL_OFF0(v)), w1 = wo(SELL_OFF1(v)), w2 = wo(SELL_OFF2(v)), w3 = wo(SELL_OFF3(v)); \
+            t += w0; t += w1; t += w2; t += w3;                                                              \
+        }                                                                                                    \
+        const double P##i = t;
+        SELL_GROUPS(SELL_SUM)
+#undef SELL_SUM
+#pragma unroll 1
+        for (uint32_t g = NGC; g < ng; ++g) { // rows of more than 4 * NGC hits: rare, keep it small
+            const uint32_t v = src[(size_t)g * 64];
+            const double w0 = wo(SELL_OFF0(v)), w1 = wo(SELL_OFF1(v)), w2 = wo(SELL_OFF2(v)), w3 = wo(SELL_OFF3(v));
+            t += w0; t += w1; t += w2; t += w3;
+        }
+        if (L == 0) return;
+        // offsets of group g of this lane's row
+        // 8-way selections: one compare-and-select per candidate with an empty asm between the steps (a visible chain or
+        // tree of selects is rewritten into a dynamically indexed stack table, i.e. scratch memory traffic per row)
+        auto group_of = [&](uint32_t g) -> uint32_t {
+            uint32_t r = bf.g0;
+            asm("" : "+v"(r));
+#define SELL_SEL(i) { r = (g == (uint32_t)i) ? bf.g##i : r; asm("" : "+v"(r)); }
+            SELL_GROUPS(SELL_SEL)
+#undef SELL_SEL
+            if (g >= (uint32_t)NGC) r = src[(size_t)g * 64];
+            return r;
+        };
+        auto off_of = [&](uint32_t j) -> uint32_t { return ((group_of(j >> 2) >> (8u * (j & 3u))) & 0xffu) << 3; };
+        uint32_t off;
+        if (L == 1) {
+            off = SELL_OFF0(bf.g0);
+        } else {
+            Stream2 s(a.seed, a.chain, TAG_ROW, a.row_id_base + d.r0 + lane, a.iter);
+            const double u = s.next();
+            const bool degenerate = !(t > 0.0) || !(t < __builtin_huge_val());
+            if (degenerate) {
+                uint32_t j = (uint32_t)(u * (double)L);
+                off = off_of(j < L ? j : L - 1);
+            } else {
+                const double target = u * t;
+                // first cached boundary the target falls below (prefix sums never decrease): one descending sweep of
+                // compares that carries the group's offsets and the prefix before it along
+                bool hit = false;
+                uint32_t v = 0;
+                double acc = 0.0;
+#define SELL_FIND(i, prev) { const bool c = target < P##i; hit = c ? true : hit; v = c ? bf.g##i : v; acc = c ? (prev) : acc; asm("" : "+v"(v), "+v"(acc)); }
+                SELL_FIND(7, P6) SELL_FIND(6, P5) SELL_FIND(5, P4) SELL_FIND(4, P3) SELL_FIND(3, P2) SELL_FIND(2, P1) SELL_FIND(1, P0) SELL_FIND(0, 0.0)
+#undef SELL_FIND
+                bool found = false;
+                off = 0;
+                if (hit) {
+                    const uint32_t o0 = SELL_OFF0(v), o1 = SELL_OFF1(v), o2 = SELL_OFF2(v), o3 = SELL_OFF3(v);
+                    const double p0 = acc + wo(o0), p1 = p0 + wo(o1), p2 = p1 + wo(o2);
+                    off = target < p0 ? o0 : (target < p1 ? o1 : (target < p2 ? o2 : o3));
+                    found = true;
+                } else {
+                    double acc = P7;
+#pragma unroll 1
+                    for (uint32_t g = NGC; g < ng && !found; ++g) {
+                        const uint32_t v = src[(size_t)g * 64];
+                        const uint32_t o0 = SELL_OFF0(v), o1 = SELL_OFF1(v), o2 = SELL_OFF2(v), o3 = SELL_OFF3(v);
+                        const double p0 = acc + wo(o0), p1 = p0 + wo(o1), p2 = p1 + wo(o2), p3 = p2 + wo(o3);
+                        if (target < p3) {
+                            off = target < p0 ? o0 : (target < p1 ? o1 : (target < p2 ? o2 : o3));
+                            found = true;
+                        }
+                        acc = p3;
+                    }
+                }
+                if (!found) off = off_of(L - 1); // rounding left target >= total: the last real hit
+            }
+        }
+        atomicAdd((int32_t *)((char *)s_cnt + (off >> 1)), 1);
+    };
+#undef SELL_GROUPS
+#undef SELL_GROUPS_REV
+#undef SELL_OFF0
+#undef SELL_OFF1
+#undef SELL_OFF2
+#undef SELL_OFF3
+
+    auto slow_tile = [&](const SellTile &d) {
+        // rows straight from the 32-bit CSR (window lookups / LDS counts where possible)
+        const uint32_t wbase = d.wbase;
+        if (lane < d.nrows()) {
+            const uint64_t st = (uint64_t)row_ptr[d.r0 + lane];
+            const uint32_t L = (uint32_t)((uint64_t)row_ptr[d.r0 + lane + 1] - st);
+            auto add = [&](uint32_t col, int32_t x) {
+                const uint32_t dd = col - wbase;
+                if (dd < (uint32_t)WIN) atomicAdd(&s_cnt[dd], x);
+                else global_count_add(gcnt, col, x);
+            };
+            RowViewGlobalWin<WIN> v{col_idx + st, L, wbase, s_mu, gmu};
+            allocate_row<false>(v, add, 1u, a, a.row_id_base + d.r0 + lane);
+        }
+    };
+
+    auto process = [&](const SellTile &d, uint32_t &cur_base, const SellTile &refill, Buf &bf) {
+        if (d.flags() & S16_EMPTY) { issue(refill, bf); return; }
+        if (d.wbase != cur_base) {
+            __syncthreads();
+            flush_window(cur_base);
+            load_window(d.wbase);
+            cur_base = d.wbase;
+            __syncthreads();
+        }
+        if (d.flags() & S16_FAST) walk(d, bf);
+        else slow_tile(d);
+        issue(refill, bf); // the registers are free again only now: tile i+2 travels while tile i+1 is walked
+    };
+
+    SellTile none;
+    none.off16 = 0; none.r0 = 0; none.wbase = 0; none.meta = sell_meta(0, 0, S16_EMPTY);
+    auto tile_at = [&](uint64_t i) { return i < nt ? T[i] : none; };
+
+    SellTile dA = tile_at(0), dB = tile_at(1);
+    Buf bufA, bufB; // A: even tiles of the range, B: odd tiles
+    // the window first: its loads are waited for to the last one, which must not include the two blocks requested below
+    // (the loop is entered with A's and B's loads in flight, A's older -- exactly the state its back edge arrives in)
+    load_window(dA.wbase);
+    uint32_t cur_base = dA.wbase;
+    __syncthreads();
+    issue(dA, bufA);
+    issue(dB, bufB);
+    for (uint64_t i = 0; i < nt; i += 2) {
+        const SellTile nA = tile_at(i + 2), nB = tile_at(i + 3); // scalar loads: in flight while A and B are walked
+        process(dA, cur_base, nA, bufA);
+        process(dB, cur_base, nB, bufB); // past the end of the range dB is the empty tile: same loads, no walk
+        dA = nA;
+        dB = nB;
+    }
+    __syncthreads();
+    flush_window(cur_base);
+}
+
+} // namespace mmg

@@ -2,7 +2,7 @@
 config 3/4 (50 M reads x 200 k transcripts, avg 20 hits).  At these sizes the oracle still finishes a few
 sweeps in seconds on the host cores, so the first iterations are compared BIT FOR BIT; beyond that the tests
 use size-independent properties: every read is assigned exactly once, reruns and alternative kernels
-(16-bit tile stream vs 32-bit CSR walk; EM stream kernel vs row-per-thread kernel) give identical bits, the
+(sliced-ELL stream vs 16-bit tile stream vs 32-bit CSR walk; EM stream kernel vs row-per-thread kernel) give identical bits, the
 EM log-likelihood never decreases."""
 import hashlib
 
@@ -68,15 +68,19 @@ def test_conservation_and_kernel_independence_at_full_size(full, gpu, monkeypatc
     s.run(n_it)
     assert _digest(s.trace(0), s.counts(0)) == d_stream    # rerun: same bits
     s.close()
-    # the same rows walked from the 32-bit CSR instead of the 16-bit tile stream: same bits
-    monkeypatch.setenv("MMG_K1_S16", "0")
-    prob2 = gpu.Problem.synthetic(R, T, avg, seed=1234, sort=True)
-    assert prob2.info.n_tiles == prob.info.n_tiles
-    s = gpu.Sampler(prob2, mu0, seed=77, gibbs_iter=n_it, trace_len=n_it)
-    s.run(n_it)
-    assert _digest(s.trace(0), s.counts(0)) == d_stream
-    s.close()
-    prob2.close()
+    # the same rows through the other two sample kernels (16-bit tile stream, 32-bit CSR tiles): same bits
+    assert prob.info.sample_kernel == 2
+    monkeypatch.setenv("MMG_K1_SELL", "0")
+    for want in (1, 0):
+        if want == 0:
+            monkeypatch.setenv("MMG_K1_S16", "0")
+        prob2 = gpu.Problem.synthetic(R, T, avg, seed=1234, sort=True)
+        assert prob2.info.sample_kernel == want
+        s = gpu.Sampler(prob2, mu0, seed=77, gibbs_iter=n_it, trace_len=n_it)
+        s.run(n_it)
+        assert _digest(s.trace(0), s.counts(0)) == d_stream
+        s.close()
+        prob2.close()
 
 
 def test_em_at_full_size(full, gpu, monkeypatch):

@@ -78,10 +78,19 @@ def test_sample_counts_bit_exact_single_sweep(gpu, orc):
     assert np.array_equal(mu1, orc.gamma_update(ref, p.l, 0.1, 0.1, 42, 0, 0))
 
 
-@pytest.mark.parametrize("R,T,avg", [(10000, 1000, 4), (30000, 500, 12), (2000, 4000, 2)])
-def test_full_chain_bit_exact(gpu, orc, R, T, avg):
-    p, mu0, _ = _mk(orc, R, T, avg)
+# the three sample kernels: sliced-ELL 8-bit stream (default without multiplicities), 16-bit tile stream, 32-bit CSR tiles
+KERNEL_ENVS = {2: {}, 1: {"MMG_K1_SELL": "0"}, 0: {"MMG_K1_SELL": "0", "MMG_K1_S16": "0"}}
+
+
+@pytest.mark.parametrize("kernel", [2, 1, 0])
+@pytest.mark.parametrize("R,T,avg", [(10000, 1000, 4), (30000, 500, 12), (2000, 4000, 2), (70000, 3000, 30)])
+def test_full_chain_bit_exact(gpu, orc, monkeypatch, R, T, avg, kernel):
+    for k, v in KERNEL_ENVS[kernel].items():
+        monkeypatch.setenv(k, v)
+    p, mu0, _ = _mk(orc, R, T, avg)                      # rows sorted by (leading transcript, length): the fast layout
     prob = gpu.Problem.from_csr(p.row_ptr, p.col_idx, p.l)
+    got = prob.info.sample_kernel                        # a stream kernel is only chosen when >= 90 % of its tiles qualify
+    assert got <= kernel and (got == kernel or (R, T, avg) not in [(10000, 1000, 4), (70000, 3000, 30)])
     s = gpu.Sampler(prob, mu0, seed=1234, gibbs_iter=128, trace_len=64)
     s.run(128)
     ref = orc.gibbs_keyed(p, mu0, seed=1234, n_iter=128, trace_len=64)
@@ -360,8 +369,9 @@ def test_64bit_row_offsets_path(gpu, orc, monkeypatch):
 
 
 @pytest.mark.parametrize("n_chains", [2, 4, 8, 11])
-def test_fused_chains_equal_independent_single_chains(gpu, orc, n_chains):
+def test_fused_chains_equal_independent_single_chains(gpu, orc, monkeypatch, n_chains):
     """Chains advanced together by the fused walk (groups of 8/4/2/1) are bit-identical to single-chain runs."""
+    monkeypatch.setenv("MMG_K1_SELL", "0")               # the fused walk lives in k_sample16
     p, mu0, _ = _mk(orc, 40000, 1500, 9)
     prob = gpu.Problem.from_csr(p.row_ptr, p.col_idx, p.l)
     s = gpu.Sampler(prob, mu0, seed=21, n_chains=n_chains, chain_base=3, gibbs_iter=16, trace_len=16)

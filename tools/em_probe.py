@@ -5,7 +5,7 @@ import numpy as np
 from mmseq_amd import Problem
 
 def probe(R, T, avg, sweeps=40):
-    prob = Problem.synthetic(R, T, avg, seed=1234, sort=True)
+    prob = Problem.synthetic(R, T, avg, seed=1234, sort=True, uniform=bool(int(os.environ.get('MMG_PROBE_UNIFORM', '0'))))
     inf = prob.info
     mu0, _ = prob.start_values()
     t0 = time.time()

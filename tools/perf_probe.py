@@ -32,7 +32,7 @@ def probe(R, T, avg, iters=20, chains=1, uniform=0, sort=True, tag="", check=Tru
     k1 = tm["sample_ms"] / tm["sample_launches"]
     k2 = tm["update_ms"] / tm["update_launches"]
     wall = (t4 - t3) / iters * 1e3
-    print(f"{tag} R={R} T={T} avg={avg} C={chains} sort={sort} tiles={inf.n_tiles} gen={t1-t0:.1f}s "
+    print(f"{tag} kernel={inf.sample_kernel} stream={inf.stream_bytes/1e9:.3f}GB R={R} T={T} avg={avg} C={chains} sort={sort} tiles={inf.n_tiles} gen={t1-t0:.1f}s "
           f"K1={k1:.3f}ms K2={k2:.3f}ms wall/iter={wall:.3f}ms K1 GB/s={(4*(inf.m+1)+4*inf.nnz)/k1/1e6:.0f} "
           f"iter/s={1e3/wall:.1f} chain-it/s={chains*1e3/wall:.1f} frac8TB={B/(wall*1e-3)/8e12:.3f}", flush=True)
     if check:
