@@ -136,7 +136,7 @@ struct mmg_problem {
     bool use16 = false;
     double s16_fast_fraction = 0.0;
     uint64_t *d_colcnt = nullptr;   // hits per transcript, for the EM scale words (lazy)
-    // SELL-64 stream of k_sample_sell (problems without multiplicities)
+    // SELL-64 stream of k_sample_sell
     uint8_t *d_sell = nullptr;
     uint64_t sell_bytes = 0, n_sell_tiles = 0;
     SellTile *d_sell_tiles = nullptr;
@@ -223,7 +223,7 @@ static int problem_finish(mmg_problem *p, const uint64_t *h_row_ptr)
         p->device_bytes += (p->m + 1) * 4;
     }
     p->h_tile_row.swap(tiles);
-    if (!p->d_k && p->m) { // SELL-64 tiling: fixed 64-row slices, groups of the longest row
+    if (p->m) { // SELL-64 tiling: fixed 64-row slices, groups of the longest row
         const uint64_t nt64 = (p->m + 63) / 64;
         p->h_sell_ng.assign(nt64, 0);
         for (uint64_t t = 0; t < nt64; ++t) {
@@ -259,9 +259,10 @@ static int problem_finish(mmg_problem *p, const uint64_t *h_row_ptr)
 }
 
 // per-tile descriptors, built on the device from the RESIDENT CSR (col_idx must be final)
-static const void *k1_sell_kernel(bool idx64)
+static const void *k1_sell_kernel(bool idx64, bool has_k)
 {
-    return idx64 ? (const void *)k_sample_sell<uint64_t, 8> : (const void *)k_sample_sell<uint32_t, 8>;
+    if (idx64) return has_k ? (const void *)k_sample_sell<uint64_t, true, 8> : (const void *)k_sample_sell<uint64_t, false, 8>;
+    return has_k ? (const void *)k_sample_sell<uint32_t, true, 8> : (const void *)k_sample_sell<uint32_t, false, 8>;
 }
 
 // SELL-64 stream for k_sample_sell: tiles of 64 rows, the window policy of the 16-bit stream, one block per tile.
@@ -270,7 +271,7 @@ static int problem_build_sell(mmg_problem *p)
     std::vector<uint8_t> ngs;
     ngs.swap(p->h_sell_ng);
     const char *ev = getenv("MMG_K1_SELL");
-    if (ngs.empty() || p->d_k || (ev && atoi(ev) == 0)) return MMG_OK;
+    if (ngs.empty() || (ev && atoi(ev) == 0)) return MMG_OK;
     const uint64_t nt = ngs.size();
     const uint32_t WIN = SELL_WIN;
     std::vector<uint64_t> tile_row(nt + 1);
@@ -290,7 +291,7 @@ static int problem_build_sell(mmg_problem *p)
     cleanup();
     d_tile_row = nullptr; d_td = nullptr;
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k1_sell_kernel(p->idx64), 64, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 16; }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k1_sell_kernel(p->idx64, p->d_k != nullptr), 64, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 16; }
     if (per_cu > 32) per_cu = 32;
     if (const char *e2 = getenv("MMG_K1_SELL_WAVES_PER_CU")) { const int v = atoi(e2); if (v >= 1 && v <= 32) per_cu = v; }
     const uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>(nt, (uint64_t)p->cu_count * per_cu));
@@ -988,8 +989,8 @@ extern "C" int mmg_sampler_sample(mmg_sampler *s)
                 const SellTile *ts = p->d_sell_tiles;
                 const uint64_t *cs = p->d_sell_chunk;
                 const uint8_t *ss = p->d_sell;
-                void *kargs[] = {(void *)&rp, (void *)&ci, (void *)&ts, (void *)&cs, (void *)&mu, (void *)&ss, (void *)&cnt, (void *)&a};
-                HIP_TRY(hipLaunchKernel(k1_sell_kernel(p->idx64), dim3(p->grid_sell), dim3(64), kargs, 0, s->cur));
+                void *kargs[] = {(void *)&rp, (void *)&ci, (void *)&kk, (void *)&ts, (void *)&cs, (void *)&mu, (void *)&ss, (void *)&cnt, (void *)&a};
+                HIP_TRY(hipLaunchKernel(k1_sell_kernel(p->idx64, p->d_k != nullptr), dim3(p->grid_sell), dim3(64), kargs, 0, s->cur));
             } else if (p->use16) {
                 const S16Tile *t16 = p->d_s16tiles;
                 const uint64_t *c16 = p->d_chunk_tile16;

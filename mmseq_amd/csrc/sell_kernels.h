@@ -1,4 +1,4 @@
-// K1 on a sliced-ELL ("SELL-64") 8-bit stream: the sampler kernel for problems without multiplicities.
+// K1 on a sliced-ELL ("SELL-64") 8-bit stream: the default sampler kernel.
 //
 // k_sample16 stages every tile through LDS: the block is written there (ds_write_b128), the row extents and
 // the offsets are read back (ds_read_b128) before the mu gathers can start, and the two waves of a
@@ -59,9 +59,9 @@ __global__ __launch_bounds__(64) void k_encode_sell(const IdxT *__restrict__ row
     }
 }
 
-template <typename IdxT, int NGC>
+template <typename IdxT, bool HAS_K, int NGC>
 __global__ __launch_bounds__(64) void k_sample_sell(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
-                                                    const SellTile *__restrict__ tiles, const uint64_t *__restrict__ chunk_tile,
+                                                    const uint32_t *__restrict__ kmult, const SellTile *__restrict__ tiles, const uint64_t *__restrict__ chunk_tile,
                                                     const double *__restrict__ gmu, const uint8_t *__restrict__ stream, int32_t *gcnt,
                                                     SampleArgs a)
 {
@@ -105,6 +105,7 @@ __global__ __launch_bounds__(64) void k_sample_sell(const IdxT *__restrict__ row
     struct Buf {
         uint32_t g0, g1, g2, g3, g4, g5, g6, g7;
         uint32_t len;
+        uint32_t kk; // multiplicity of the lane's row (HAS_K)
     };
     // request a tile's block: the lane's length byte and its first NGC groups (clamped, unconditional)
     // UNCONDITIONAL: tiles without a block (empty, slow, past the end of the range) read the head of the stream instead.
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(64) void k_sample_sell(const IdxT *__restrict__ row
         const bool fast = d.flags() & S16_FAST; // uniform
         const uint8_t *__restrict__ blk = stream + (fast ? d.off16 * 16 : 0);
         bf.len = blk[lane];
+        if (HAS_K) bf.kk = kmult[(fast ? d.r0 : 0) + min(lane, (fast ? d.nrows() : 1u) - 1u)];
         const uint32_t last = fast ? d.ng() - 1u : 0u;
         // scalar base per group + one shared lane offset: the loads use the SGPR-base addressing form
 #define SELL_ISSUE(i) bf.g##i = __builtin_nontemporal_load((const uint32_t *)(blk + 64 + (size_t)min((uint32_t)i, last) * 256) + lane);
@@ -155,51 +157,69 @@ __global__ __launch_bounds__(64) void k_sample_sell(const IdxT *__restrict__ row
             return r;
         };
         auto off_of = [&](uint32_t j) -> uint32_t { return ((group_of(j >> 2) >> (8u * (j & 3u))) & 0xffu) << 3; };
-        uint32_t off;
-        if (L == 1) {
-            off = SELL_OFF0(bf.g0);
-        } else {
-            Stream2 s(a.seed, a.chain, TAG_ROW, a.row_id_base + d.r0 + lane, a.iter);
-            const double u = s.next();
-            const bool degenerate = !(t > 0.0) || !(t < __builtin_huge_val());
+        auto add = [&](uint32_t off, int32_t x) { atomicAdd((int32_t *)((char *)s_cnt + (off >> 1)), x); };
+        const uint32_t kk = HAS_K ? bf.kk : 1u;
+        if (HAS_K && kk == 0) return;
+        if (L == 1) { add(SELL_OFF0(bf.g0), (int32_t)kk); return; }
+        const bool degenerate = !(t > 0.0) || !(t < __builtin_huge_val());
+        const uint64_t row_id = a.row_id_base + d.r0 + lane;
+        // one categorical draw: the window byte offset of the selected hit (allocate_row's pick + col)
+        auto draw = [&](double u) -> uint32_t {
             if (degenerate) {
-                uint32_t j = (uint32_t)(u * (double)L);
-                off = off_of(j < L ? j : L - 1);
-            } else {
-                const double target = u * t;
-                // first cached boundary the target falls below (prefix sums never decrease): one descending sweep of
-                // compares that carries the group's offsets and the prefix before it along
-                bool hit = false;
-                uint32_t v = 0;
-                double acc = 0.0;
-#define SELL_FIND(i, prev) { const bool c = target < P##i; hit = c ? true : hit; v = c ? bf.g##i : v; acc = c ? (prev) : acc; asm("" : "+v"(v), "+v"(acc)); }
-                SELL_FIND(7, P6) SELL_FIND(6, P5) SELL_FIND(5, P4) SELL_FIND(4, P3) SELL_FIND(3, P2) SELL_FIND(2, P1) SELL_FIND(1, P0) SELL_FIND(0, 0.0)
-#undef SELL_FIND
-                bool found = false;
-                off = 0;
-                if (hit) {
-                    const uint32_t o0 = SELL_OFF0(v), o1 = SELL_OFF1(v), o2 = SELL_OFF2(v), o3 = SELL_OFF3(v);
-                    const double p0 = acc + wo(o0), p1 = p0 + wo(o1), p2 = p1 + wo(o2);
-                    off = target < p0 ? o0 : (target < p1 ? o1 : (target < p2 ? o2 : o3));
-                    found = true;
-                } else {
-                    double acc = P7;
-#pragma unroll 1
-                    for (uint32_t g = NGC; g < ng && !found; ++g) {
-                        const uint32_t v = src[(size_t)g * 64];
-                        const uint32_t o0 = SELL_OFF0(v), o1 = SELL_OFF1(v), o2 = SELL_OFF2(v), o3 = SELL_OFF3(v);
-                        const double p0 = acc + wo(o0), p1 = p0 + wo(o1), p2 = p1 + wo(o2), p3 = p2 + wo(o3);
-                        if (target < p3) {
-                            off = target < p0 ? o0 : (target < p1 ? o1 : (target < p2 ? o2 : o3));
-                            found = true;
-                        }
-                        acc = p3;
-                    }
-                }
-                if (!found) off = off_of(L - 1); // rounding left target >= total: the last real hit
+                const uint32_t j = (uint32_t)(u * (double)L);
+                return off_of(j < L ? j : L - 1);
             }
+            const double target = u * t;
+            // first cached boundary the target falls below (prefix sums never decrease): one descending sweep of
+            // compares that carries the group's offsets and the prefix before it along
+            bool hit = false;
+            uint32_t v = 0;
+            double acc = 0.0;
+#define SELL_FIND(i, prev) { const bool c = target < P##i; hit = c ? true : hit; v = c ? bf.g##i : v; acc = c ? (prev) : acc; asm("" : "+v"(v), "+v"(acc)); }
+            SELL_FIND(7, P6) SELL_FIND(6, P5) SELL_FIND(5, P4) SELL_FIND(4, P3) SELL_FIND(3, P2) SELL_FIND(2, P1) SELL_FIND(1, P0) SELL_FIND(0, 0.0)
+#undef SELL_FIND
+            if (hit) {
+                const uint32_t o0 = SELL_OFF0(v), o1 = SELL_OFF1(v), o2 = SELL_OFF2(v), o3 = SELL_OFF3(v);
+                const double p0 = acc + wo(o0), p1 = p0 + wo(o1), p2 = p1 + wo(o2);
+                return target < p0 ? o0 : (target < p1 ? o1 : (target < p2 ? o2 : o3));
+            }
+            double accl = P7;
+#pragma unroll 1
+            for (uint32_t g = NGC; g < ng; ++g) {
+                const uint32_t vv = src[(size_t)g * 64];
+                const uint32_t o0 = SELL_OFF0(vv), o1 = SELL_OFF1(vv), o2 = SELL_OFF2(vv), o3 = SELL_OFF3(vv);
+                const double p0 = accl + wo(o0), p1 = p0 + wo(o1), p2 = p1 + wo(o2), p3 = p2 + wo(o3);
+                if (target < p3) return target < p0 ? o0 : (target < p1 ? o1 : (target < p2 ? o2 : o3));
+                accl = p3;
+            }
+            return off_of(L - 1); // rounding left target >= total: the last real hit
+        };
+        if (!HAS_K || kk <= K_SMALL) {
+            Stream2 s(a.seed, a.chain, TAG_ROW, row_id, a.iter);
+            if (!HAS_K) {
+                add(draw(s.next()), 1);
+            } else {
+#pragma unroll 1
+                for (uint32_t dd = 0; dd < kk; ++dd) add(draw(s.next()), 1);
+            }
+            return;
         }
-        atomicAdd((int32_t *)((char *)s_cnt + (off >> 1)), 1);
+        // conditional-binomial chain, as allocate_row (the published gsl_ran_multinomial scheme, src/mmseq.cpp:880)
+        Stream2 q(a.seed, a.chain, TAG_ROW, row_id, a.iter);
+        uint32_t remaining = kk;
+        double rem_w = t;
+#pragma unroll 1
+        for (uint32_t j = 0; j + 1 < L && remaining > 0; ++j) {
+            const uint32_t off = off_of(j);
+            const double w = wo(off);
+            double pr = degenerate ? 1.0 / (double)(L - j) : (rem_w > 0.0 ? w / rem_w : 1.0);
+            if (pr > 1.0) pr = 1.0;
+            const uint32_t x = binomial(q, remaining, pr);
+            if (x) add(off, (int32_t)x);
+            remaining -= x;
+            rem_w -= w;
+        }
+        if (remaining > 0) add(off_of(L - 1), (int32_t)remaining);
     };
 #undef SELL_GROUPS
 #undef SELL_GROUPS_REV
@@ -220,7 +240,7 @@ __global__ __launch_bounds__(64) void k_sample_sell(const IdxT *__restrict__ row
                 else global_count_add(gcnt, col, x);
             };
             RowViewGlobalWin<WIN> v{col_idx + st, L, wbase, s_mu, gmu};
-            allocate_row<false>(v, add, 1u, a, a.row_id_base + d.r0 + lane);
+            allocate_row<HAS_K>(v, add, HAS_K ? kmult[d.r0 + lane] : 1u, a, a.row_id_base + d.r0 + lane);
         }
     };
 

@@ -309,9 +309,19 @@ def test_golden_tiny_chain_on_device(gpu):
 def test_torch_view_of_device_buffers_and_single_rank_collectives(gpu, orc):
     """dist glue on one GPU: zero-copy torch views of the library's buffers, kernels on torch's stream,
     a 1-rank RCCL process group around the shard-mode step."""
+    import time
+    t0 = time.time()
+    def stamp(what):  # phase timings: stdout (-s / on failure) and, when present, the scratch directory of the GPU run
+        line = "[torch_view] %-36s %.2fs" % (what, time.time() - t0)
+        print(line, flush=True)
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        if os.path.isdir(d):
+            with open(os.path.join(d, "torch_view_timing.log"), "a") as f:
+                f.write(line + "\n")
     import torch
     import torch.distributed as dist
     from mmseq_amd import dist as mdist
+    stamp("imports")
     p, aux = orc.synth_problem(R=20000, T=900, avg_hits=6, seed=5)
     mu0, _ = orc.start_values(p)
     prob = gpu.Problem.from_csr(p.row_ptr, p.col_idx, p.l)
@@ -323,18 +333,24 @@ def test_torch_view_of_device_buffers_and_single_rank_collectives(gpu, orc):
     if own:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        stamp("before init_process_group")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        stamp("init_process_group")
     try:
         for _ in range(8):
             s.sample()
             dist.all_reduce(counts)            # world size 1: identity, but exercises RCCL on the same stream
             s.update()
+        stamp("8 x sample/all_reduce/update issued")
         torch.cuda.synchronize()
+        stamp("synchronize")
         mom = mdist.moments_tensor(s)
         mdist.pool_moments(mom)
+        stamp("pool_moments")
     finally:
         if own:
             dist.destroy_process_group()
+            stamp("destroy_process_group")
     ref = orc.gibbs_keyed(p, mu0, seed=3, n_iter=8, trace_len=8)
     assert np.array_equal(s.trace(0), ref["trace"])
     assert np.array_equal(mom.cpu().numpy()[:900], ref["sum_log"])
