@@ -100,7 +100,6 @@ __global__ __launch_bounds__(64) void k_sample_sell(const IdxT *__restrict__ row
     // The cached groups and the prefix sums are NAMED registers (macro-expanded), not arrays: a select chain over an
     // array that a loop once indexed is turned back into a dynamic index by the optimiser, and the array lands in scratch.
 #define SELL_GROUPS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
-#define SELL_GROUPS_REV(X) X(7) X(6) X(5) X(4) X(3) X(2) X(1) X(0)
     static_assert(NGC == 8, "the group list above is written out for 8 cached groups");
     struct Buf {
         uint32_t g0, g1, g2, g3, g4, g5, g6, g7;
@@ -222,7 +221,6 @@ __global__ __launch_bounds__(64) void k_sample_sell(const IdxT *__restrict__ row
         if (remaining > 0) add(off_of(L - 1), (int32_t)remaining);
     };
 #undef SELL_GROUPS
-#undef SELL_GROUPS_REV
 #undef SELL_OFF0
 #undef SELL_OFF1
 #undef SELL_OFF2

@@ -142,6 +142,47 @@ def test_edge_rows(gpu, orc):
     assert int(s.counts(0).sum()) == int(k[[1, 2, 3, 4, 6, 7, 8]].sum())
 
 
+@pytest.mark.parametrize("with_k", [False, True])
+def test_sliced_ell_kernel_edge_rows(gpu, orc, monkeypatch, with_k):
+    """The sliced-ELL kernel (forced even though few tiles qualify) on the row shapes its format singles out: rows of
+    exactly 32 / 33 hits (the register cache holds 8 groups), 255 and 256+ hits (the length byte; longer rows make their
+    tile a slow tile), single-hit and empty rows, a window slide inside a workgroup's range, a ragged last tile,
+    degenerate weights (all mu of a row zero / infinite) -- bit-exact against the oracle, with and without multiplicities."""
+    monkeypatch.setenv("MMG_K1_SELL", "2")
+    monkeypatch.setenv("MMG_K1_SELL_WAVES_PER_CU", "1")       # few workgroups: long tile ranges, several window slides each
+    rng = np.random.default_rng(9)
+    T = 40000
+    rows = []
+    for lead in range(0, T - 300, 37):                         # leading transcripts ascend: the layout the window wants
+        for L in (1, 2, 3, 4, 5, 31, 32, 33, 34, 40, 0, 7):
+            rows.append(sorted(rng.choice(np.arange(lead, lead + 120), size=L, replace=False).tolist()) if L else [])
+    rows[500] = list(range(18500, 18500 + 254))               # fits the 255-wide window
+    rows[501] = list(range(18500, 18500 + 255))               # 255 hits: still a fast row
+    rows[900] = list(range(33300, 33300 + 300))               # too long for the length byte: slow tile
+    rows[1200] = [5, 39000]                                    # far outside any window: slow tile
+    rows = rows[:-13]                                          # ragged last tile
+    rp = np.cumsum([0] + [len(r) for r in rows]).astype(np.uint64)
+    ci = np.concatenate([np.asarray(r, np.uint32) for r in rows if r])
+    l = np.linspace(0.5, 2.0, T)
+    k = rng.choice([1, 1, 2, 8, 9, 500], size=len(rows)).astype(np.uint32) if with_k else None
+    p = orc.Problem(rp, ci, l, k=k)
+    mu0 = rng.gamma(0.3, 1.0, size=T)
+    mu0[::5] = 1e-300
+    mu0[2000:2200] = 0.0                                       # rows whose every weight is zero: uniform pick
+    mu0[3000:3100] = np.inf                                    # total not finite: uniform pick as well
+    prob = gpu.Problem.from_csr(rp, ci, l, k=k)
+    assert prob.info.sample_kernel == 2
+    s = gpu.Sampler(prob, mu0, seed=17, gibbs_iter=12, trace_len=12)
+    s.sample()
+    ref1 = orc.sample_counts(p, mu0, seed=17, chain=0, it=0)
+    assert np.array_equal(s.counts(0), ref1)
+    s.update()
+    s.run(11)
+    ref = orc.gibbs_keyed(p, mu0, seed=17, n_iter=12, trace_len=12)
+    assert np.array_equal(s.counts(0), ref["cnt"])
+    assert np.array_equal(s.trace(0), ref["trace"])
+
+
 def test_chains_and_shards_reproduce_single_chain(gpu, orc):
     """(a) chain c of a multi-chain sampler == a single-chain sampler with chain_base=c;
     (b) read-sharding: two shards' counts summed (the all-reduce) == the unsharded chain."""
