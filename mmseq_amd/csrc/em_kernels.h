@@ -212,11 +212,12 @@ __global__ __launch_bounds__(256) void k_em_rows_global(const IdxT *__restrict__
 }
 
 // The rows pass on K1's 16-bit tile stream (same tiles, same window policy, same depth-2 prefetch).
-template <typename IdxT, bool HAS_K, int ELEMS, int WIN, int BS, int RC, bool MEASURE, int ABL = 0>
+template <typename IdxT, bool HAS_K, int ELEMS, int WIN, int BS, int RC, bool MEASURE, int ABL = 0, int REP = 2>
 __global__ __launch_bounds__(BS) void k_em16(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
                                              const uint32_t *__restrict__ kmult, const S16Tile *__restrict__ tiles,
                                              const uint64_t *__restrict__ chunk_tile, const u32x4 *__restrict__ stream16, EmArgs a)
 {
+    const int tid = threadIdx.x;
     constexpr int ROWS_CAP = RC;
     constexpr int RPCH = (ROWS_CAP + 8) / 8;
     constexpr int NC = (RPCH + ELEMS / 8 + BS - 1) / BS;
@@ -226,10 +227,13 @@ __global__ __launch_bounds__(BS) void k_em16(const IdxT *__restrict__ row_ptr, c
     __shared__ __attribute__((aligned(16))) double s_mu[WIN + 2];          // [WIN] stays 0.0: what pad slots read
     __shared__ uint32_t s_k[HAS_K ? ROWS_CAP : 1];
     __shared__ uint32_t s_w[MEASURE ? 1 : WIN + 2];                        // scale words; [WIN] dead
-    __shared__ uint64_t s_hi[MEASURE ? 1 : WIN + 2], s_lo[MEASURE ? 1 : WIN + 2];
+    // REP replicas of the accumulators, lane l adds to replica l % REP: LDS atomics to one address retire one per two
+    // clocks (tools/lds_atomic_bench.hip), and the abundance skew inside a window sends many lanes to the same transcript
+    constexpr int AST = WIN + 2;                                           // entries per replica
+    __shared__ uint64_t s_hi[MEASURE ? 1 : REP * AST], s_lo[MEASURE ? 1 : REP * AST];
+    const uint32_t rep_off = MEASURE ? 0u : (uint32_t)(tid % REP) * (uint32_t)(AST * 8);
     __shared__ int32_t s_xe[MEASURE ? WIN + 2 : 1];
     __shared__ uint64_t s_ll[3];
-    const int tid = threadIdx.x;
 
     const uint64_t t_begin = chunk_tile[blockIdx.x], t_end = chunk_tile[blockIdx.x + 1];
     if (t_begin >= t_end) return;
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(BS) void k_em16(const IdxT *__restrict__ row_ptr, c
     if (tid < 3) s_ll[tid] = 0;
     for (int i = tid; i < WIN + 2; i += BS) {
         if (MEASURE) s_xe[i] = INT32_MIN;
-        else { s_hi[i] = 0; s_lo[i] = 0; }
+        else { for (int r = 0; r < REP; ++r) { s_hi[r * AST + i] = 0; s_lo[r * AST + i] = 0; } }
     }
     if (tid < 2) { s_mu[WIN + tid] = 0.0; if (!MEASURE) s_w[WIN + tid] = EM_WORD_DEAD; }
 
@@ -249,9 +253,10 @@ __global__ __launch_bounds__(BS) void k_em16(const IdxT *__restrict__ row_ptr, c
                 const int32_t v = s_xe[i];
                 if (v != INT32_MIN) { atomicMax(&a.xe[base + (uint32_t)i], v); s_xe[i] = INT32_MIN; }
             } else {
-                const uint64_t h = s_hi[i], l = s_lo[i];
-                if (h) { atomicAdd((unsigned long long *)&a.hi[base + (uint32_t)i], (unsigned long long)h); s_hi[i] = 0; }
-                if (l) { atomicAdd((unsigned long long *)&a.lo[base + (uint32_t)i], (unsigned long long)l); s_lo[i] = 0; }
+                uint64_t h = 0, l = 0;
+                for (int r = 0; r < REP; ++r) { h += s_hi[r * AST + i]; l += s_lo[r * AST + i]; s_hi[r * AST + i] = 0; s_lo[r * AST + i] = 0; }
+                if (h) atomicAdd((unsigned long long *)&a.hi[base + (uint32_t)i], (unsigned long long)h);
+                if (l) atomicAdd((unsigned long long *)&a.lo[base + (uint32_t)i], (unsigned long long)l);
             }
         }
     };
@@ -347,8 +352,8 @@ __global__ __launch_bounds__(BS) void k_em16(const IdxT *__restrict__ row_ptr, c
                         if (ABL == 3 && j == 0) continue;
                         if (em_term(x, xe, *(const uint32_t *)((const char *)s_w + (off >> 1)), acc, yh, yl)) {
                             if (ABL == 2) { acc.lll ^= yh ^ yl; continue; }
-                            atomicAdd((unsigned long long *)((char *)s_hi + off), (unsigned long long)yh);
-                            if (ABL != 1) atomicAdd((unsigned long long *)((char *)s_lo + off), (unsigned long long)yl);
+                            atomicAdd((unsigned long long *)((char *)s_hi + rep_off + off), (unsigned long long)yh);
+                            if (ABL != 1) atomicAdd((unsigned long long *)((char *)s_lo + rep_off + off), (unsigned long long)yl);
                         }
                     }
                 }

@@ -678,6 +678,13 @@ static const void *em16_kernel(const mmg_problem *p)
     if (!p->use16 || p->variant != 0) return nullptr;
     const bool hk = p->d_k != nullptr;
     if (!MEASURE && !hk && !p->idx64) {
+        if (const char *rp = getenv("MMG_EM_REP")) { // accumulator replicas (experiments)
+            switch (atoi(rp)) {
+            case 1: return (const void *)k_em16<uint32_t, false, 2560, 256, 128, 128, false, 0, 1>;
+            case 4: return (const void *)k_em16<uint32_t, false, 2560, 256, 128, 128, false, 0, 4>;
+            case 8: return (const void *)k_em16<uint32_t, false, 2560, 256, 128, 128, false, 0, 8>;
+            }
+        }
         if (const char *ab = getenv("MMG_EM_ABL")) { // timing ablations (wrong results by design)
             switch (atoi(ab)) {
             case 1: return (const void *)k_em16<uint32_t, false, 2560, 256, 128, 128, false, 1>;
