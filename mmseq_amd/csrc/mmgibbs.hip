@@ -261,6 +261,15 @@ static int problem_finish(mmg_problem *p, const uint64_t *h_row_ptr)
 // per-tile descriptors, built on the device from the RESIDENT CSR (col_idx must be final)
 static const void *k1_sell_kernel(bool idx64, bool has_k)
 {
+    if (!idx64 && !has_k) {
+        if (const char *rp = getenv("MMG_K1_SELL_REP")) { // count replicas (experiments)
+            switch (atoi(rp)) {
+            case 4: return (const void *)k_sample_sell<uint32_t, false, 8, 4>;
+            case 2: return (const void *)k_sample_sell<uint32_t, false, 8, 2>;
+            case 8: return (const void *)k_sample_sell<uint32_t, false, 8, 8>;
+            }
+        }
+    }
     if (idx64) return has_k ? (const void *)k_sample_sell<uint64_t, true, 8> : (const void *)k_sample_sell<uint64_t, false, 8>;
     return has_k ? (const void *)k_sample_sell<uint32_t, true, 8> : (const void *)k_sample_sell<uint32_t, false, 8>;
 }

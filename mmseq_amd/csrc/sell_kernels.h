@@ -59,7 +59,7 @@ __global__ __launch_bounds__(64) void k_encode_sell(const IdxT *__restrict__ row
     }
 }
 
-template <typename IdxT, bool HAS_K, int NGC>
+template <typename IdxT, bool HAS_K, int NGC, int REP = 1>
 __global__ __launch_bounds__(64) void k_sample_sell(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
                                                     const uint32_t *__restrict__ kmult, const SellTile *__restrict__ tiles, const uint64_t *__restrict__ chunk_tile,
                                                     const double *__restrict__ gmu, const uint8_t *__restrict__ stream, int32_t *gcnt,
@@ -67,7 +67,9 @@ __global__ __launch_bounds__(64) void k_sample_sell(const IdxT *__restrict__ row
 {
     constexpr int WIN = (int)SELL_WIN;
     __shared__ __attribute__((aligned(16))) double s_mu[WIN + 1]; // [WIN] stays 0.0: what pad slots read
-    __shared__ int32_t s_cnt[WIN + 1];
+    // REP replicas of the counts (lane l adds to replica l % REP) were tried against same-address serialisation of the LDS
+    // atomics: with one atomic per ROW they only cost (0.433 ms with 1, 0.445 / 0.455 / 0.473 with 2 / 4 / 8 at cfg 3)
+    __shared__ int32_t s_cnt[REP * (WIN + 1)];
     const uint32_t lane = threadIdx.x;
 
     const uint64_t t_begin = chunk_tile[blockIdx.x], t_end = chunk_tile[blockIdx.x + 1];
@@ -75,13 +77,16 @@ __global__ __launch_bounds__(64) void k_sample_sell(const IdxT *__restrict__ row
     const uint64_t nt = t_end - t_begin;
     const SellTile *__restrict__ T = tiles + t_begin;
 
-    for (int i = lane; i < WIN + 1; i += 64) s_cnt[i] = 0;
+    for (int i = lane; i < REP * (WIN + 1); i += 64) s_cnt[i] = 0;
+    const uint32_t rep_off = (lane % REP) * (uint32_t)((WIN + 1) * 4);
     if (lane == 0) s_mu[WIN] = 0.0;
 
     auto flush_window = [&](uint32_t base) {
         for (int i = lane; i < WIN; i += 64) {
-            const int32_t v = s_cnt[i];
-            if (v) { global_count_add(gcnt, base + (uint32_t)i, v); s_cnt[i] = 0; }
+            int32_t v = 0;
+#pragma unroll
+            for (int r = 0; r < REP; ++r) { v += s_cnt[r * (WIN + 1) + i]; s_cnt[r * (WIN + 1) + i] = 0; }
+            if (v) global_count_add(gcnt, base + (uint32_t)i, v);
         }
     };
     auto load_window = [&](uint32_t base) {
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(64) void k_sample_sell(const IdxT *__restrict__ row
             return r;
         };
         auto off_of = [&](uint32_t j) -> uint32_t { return ((group_of(j >> 2) >> (8u * (j & 3u))) & 0xffu) << 3; };
-        auto add = [&](uint32_t off, int32_t x) { atomicAdd((int32_t *)((char *)s_cnt + (off >> 1)), x); };
+        auto add = [&](uint32_t off, int32_t x) { atomicAdd((int32_t *)((char *)s_cnt + rep_off + (off >> 1)), x); };
         const uint32_t kk = HAS_K ? bf.kk : 1u;
         if (HAS_K && kk == 0) return;
         if (L == 1) { add(SELL_OFF0(bf.g0), (int32_t)kk); return; }
