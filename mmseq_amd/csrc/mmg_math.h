@@ -55,7 +55,14 @@ MMG_HD void philox2x32_10(uint32_t &c0, uint32_t &c1, uint32_t k)
 {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // one v_mad_u64_u32 yields both halves: 32-bit multiplies are quarter-rate, and this is the hot integer path
+        uint64_t pr;
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(pr) : "v"(c0), "s"(0xD256D193u) : "vcc");
+        const uint32_t hi = (uint32_t)(pr >> 32), lo = (uint32_t)pr;
+#else
         const uint32_t hi = mulhi32(0xD256D193u, c0), lo = 0xD256D193u * c0;
+#endif
         c0 = hi ^ k ^ c1;
         c1 = lo;
         k += 0x9E3779B9u;
