@@ -70,10 +70,17 @@ MMG_HD void philox2x32_10(uint32_t &c0, uint32_t &c1, uint32_t k)
 }
 
 // 52 random bits -> uniform strictly inside (0,1); every step exact
+MMG_HD double double_of(uint64_t u);
 MMG_HD double u52(uint32_t a, uint32_t b)
 {
     const uint64_t v = ((uint64_t)(a >> 6) << 26) | (uint64_t)(b >> 6);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // same value without the 64-bit integer -> double conversion: v as the mantissa of a double in [1,2) is 1 + v 2^-52;
+    // subtracting 1 is exact, and v 2^-52 + 2^-53 = (2v+1) 2^-53 is representable, so both additions are exact
+    return (double_of(0x3ff0000000000000ull | v) - 1.0) + 0x1p-53;
+#else
     return ((double)v + 0.5) * 0x1p-52;
+#endif
 }
 
 enum : uint32_t { TAG_ROW = 1, TAG_GAMMA = 2, TAG_SYNTH_ROW = 3, TAG_SYNTH_TX = 4, TAG_SIMU = 5 };
