@@ -132,7 +132,8 @@ typedef struct mmg_em mmg_em;
 int mmg_em_create(const mmg_problem *p, const double *mu0, mmg_em **out, double *loglik0);
 int mmg_em_step(mmg_em *e, double *loglik);
 int mmg_em_get_mu(mmg_em *e, double *mu);
-/* sweeps done, rows passes repeated on measured scale exponents, 1 if the tile-stream kernel runs */
+/* sweeps done, rows passes repeated on measured scale exponents, rows-pass kernel (2 sliced-ELL stream,
+ * 1 16-bit tile stream, 0 row per thread from the CSR) */
 int mmg_em_stats(const mmg_em *e, int *sweeps, int *repeated_passes, int *stream_kernel);
 void mmg_em_destroy(mmg_em *e);
 void mmg_problem_destroy(mmg_problem *p);

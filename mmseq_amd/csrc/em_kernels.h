@@ -422,4 +422,200 @@ __global__ __launch_bounds__(BS) void k_em16(const IdxT *__restrict__ row_ptr, c
     if (!MEASURE) em_acc_commit(acc, s_ll, a.ll);
 }
 
+
+// The rows pass on the sliced-ELL 8-bit stream of k_sample_sell: a tile is one wave, every lane holds its row's window
+// indices in registers, nothing is staged through LDS and there are no barriers on the tile path -- which leaves LDS for
+// REP replicas of the accumulators (lane l adds to replica l % REP; same-address LDS atomics retire one per two clocks).
+template <typename IdxT, bool HAS_K, bool MEASURE, int REP>
+__global__ __launch_bounds__(64) void k_em_sell(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
+                                                const uint32_t *__restrict__ kmult, const SellTile *__restrict__ tiles,
+                                                const uint64_t *__restrict__ chunk_tile, const uint8_t *__restrict__ stream, EmArgs a)
+{
+    constexpr int WIN = (int)SELL_WIN;
+    constexpr int AST = WIN + 1;                                            // entries per replica; [WIN] is the pad slot
+    __shared__ __attribute__((aligned(16))) double s_mu[AST];              // [WIN] stays 0.0: what pad slots read
+    __shared__ uint32_t s_w[MEASURE ? 1 : AST];                            // scale words; [WIN] dead
+    __shared__ uint64_t s_hi[MEASURE ? 1 : REP * AST], s_lo[MEASURE ? 1 : REP * AST];
+    __shared__ int32_t s_xe[MEASURE ? AST : 1];
+    __shared__ uint64_t s_ll[3];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t rep_off = MEASURE ? 0u : (lane % REP) * (uint32_t)(AST * 8);
+
+    const uint64_t t_begin = chunk_tile[blockIdx.x], t_end = chunk_tile[blockIdx.x + 1];
+    if (t_begin >= t_end) return;
+    const uint64_t nt = t_end - t_begin;
+    const SellTile *__restrict__ T = tiles + t_begin;
+
+    if (lane < 3) s_ll[lane] = 0;
+    for (int i = lane; i < AST; i += 64) {
+        if (MEASURE) s_xe[i] = INT32_MIN;
+        else { for (int r = 0; r < REP; ++r) { s_hi[r * AST + i] = 0; s_lo[r * AST + i] = 0; } }
+    }
+    if (lane == 0) { s_mu[WIN] = 0.0; if (!MEASURE) s_w[WIN] = EM_WORD_DEAD; }
+
+    auto flush_window = [&](uint32_t base) {
+        for (int i = lane; i < WIN; i += 64) {
+            if (MEASURE) {
+                const int32_t v = s_xe[i];
+                if (v != INT32_MIN) { atomicMax(&a.xe[base + (uint32_t)i], v); s_xe[i] = INT32_MIN; }
+            } else {
+                uint64_t h = 0, l = 0;
+                for (int r = 0; r < REP; ++r) { h += s_hi[r * AST + i]; l += s_lo[r * AST + i]; s_hi[r * AST + i] = 0; s_lo[r * AST + i] = 0; }
+                if (h) atomicAdd((unsigned long long *)&a.hi[base + (uint32_t)i], (unsigned long long)h);
+                if (l) atomicAdd((unsigned long long *)&a.lo[base + (uint32_t)i], (unsigned long long)l);
+            }
+        }
+    };
+    auto load_window = [&](uint32_t base) {
+        for (int i = lane; i < WIN; i += 64) {
+            const uint32_t c = base + (uint32_t)i;
+            s_mu[i] = c < a.n ? a.mu[c] : 0.0;
+            if (!MEASURE) s_w[i] = c < a.n ? a.word[c] : EM_WORD_DEAD;
+        }
+    };
+    auto wo = [&](uint32_t off) { return *(const double *)((const char *)s_mu + off); }; // off = window index * 8
+#define EMS_OFF0(v) (((v) << 3) & 0x7f8u)
+#define EMS_OFF1(v) (((v) >> 5) & 0x7f8u)
+#define EMS_OFF2(v) (((v) >> 13) & 0x7f8u)
+#define EMS_OFF3(v) (((v) >> 21) & 0x7f8u)
+#define EMS_GROUPS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+    struct Buf {
+        uint32_t g0, g1, g2, g3, g4, g5, g6, g7;
+        uint32_t len, kk;
+    };
+    // unconditional, like k_sample_sell::issue (the number of loads per tile must not depend on the path)
+    auto issue = [&](const SellTile &d, Buf &bf) {
+        const bool fast = d.flags() & S16_FAST; // uniform
+        const uint8_t *__restrict__ blk = stream + (fast ? d.off16 * 16 : 0);
+        bf.len = blk[lane];
+        if (HAS_K) bf.kk = kmult[(fast ? d.r0 : 0) + min(lane, (fast ? d.nrows() : 1u) - 1u)];
+        const uint32_t last = fast ? d.ng() - 1u : 0u;
+#define EMS_ISSUE(i) bf.g##i = __builtin_nontemporal_load((const uint32_t *)(blk + 64 + (size_t)min((uint32_t)i, last) * 256) + lane);
+        EMS_GROUPS(EMS_ISSUE)
+#undef EMS_ISSUE
+    };
+
+    EmAcc acc;
+    auto walk = [&](const SellTile &d, const Buf &bf) {
+        const uint32_t ng = d.ng();                                    // uniform
+        const uint32_t *__restrict__ src = (const uint32_t *)(stream + d.off16 * 16 + 64) + lane; // groups beyond the cached ones
+        double t = 0.0;
+#define EMS_SUM(i)                                                                                          \
+        if ((uint32_t)i < ng) {                                                                              \
+            const uint32_t v = bf.g##i;                                                                      \
+            const double w0 = wo(EMS_OFF0(v)), w1 = wo(EMS_OFF1(v)), w2 = wo(EMS_OFF2(v)), w3 = wo(EMS_OFF3(v)); \
+            t += w0; t += w1; t += w2; t += w3;                                                              \
+        }
+        EMS_GROUPS(EMS_SUM)
+#undef EMS_SUM
+#pragma unroll 1
+        for (uint32_t g = 8; g < ng; ++g) {
+            const uint32_t v = src[(size_t)g * 64];
+            const double w0 = wo(EMS_OFF0(v)), w1 = wo(EMS_OFF1(v)), w2 = wo(EMS_OFF2(v)), w3 = wo(EMS_OFF3(v));
+            t += w0; t += w1; t += w2; t += w3;
+        }
+        if (bf.len == 0) return;
+        double x;
+        int xe;
+        if (!em_row_head<MEASURE>(t, HAS_K ? bf.kk : 1u, acc, x, xe)) return;
+        // second half: every hit of the row receives x (pads point at the dead slot and add nothing)
+        auto give = [&](uint32_t off) {
+            if (MEASURE) {
+                atomicMax((int32_t *)((char *)s_xe + (off >> 1)), xe);
+            } else {
+                uint64_t yh, yl;
+                if (em_term(x, xe, *(const uint32_t *)((const char *)s_w + (off >> 1)), acc, yh, yl)) {
+                    atomicAdd((unsigned long long *)((char *)s_hi + rep_off + off), (unsigned long long)yh);
+                    atomicAdd((unsigned long long *)((char *)s_lo + rep_off + off), (unsigned long long)yl);
+                }
+            }
+        };
+#define EMS_GIVE(i)                                                                                          \
+        if ((uint32_t)i < ng) { const uint32_t v = bf.g##i; give(EMS_OFF0(v)); give(EMS_OFF1(v)); give(EMS_OFF2(v)); give(EMS_OFF3(v)); }
+        EMS_GROUPS(EMS_GIVE)
+#undef EMS_GIVE
+#pragma unroll 1
+        for (uint32_t g = 8; g < ng; ++g) {
+            const uint32_t v = src[(size_t)g * 64];
+            give(EMS_OFF0(v)); give(EMS_OFF1(v)); give(EMS_OFF2(v)); give(EMS_OFF3(v));
+        }
+    };
+#undef EMS_GROUPS
+#undef EMS_OFF0
+#undef EMS_OFF1
+#undef EMS_OFF2
+#undef EMS_OFF3
+
+    auto slow_tile = [&](const SellTile &d) {
+        const uint32_t wbase = d.wbase;
+        if (lane >= d.nrows()) return;
+        const uint64_t st = (uint64_t)row_ptr[d.r0 + lane];
+        const uint32_t L = (uint32_t)((uint64_t)row_ptr[d.r0 + lane + 1] - st);
+        if (L == 0) return;
+        const uint32_t *cl = col_idx + st;
+        double dsum = 0.0;
+        for (uint32_t j = 0; j < L; ++j) {
+            const uint32_t c = cl[j], dd = c - wbase;
+            dsum += dd < (uint32_t)WIN ? s_mu[dd] : a.mu[c];
+        }
+        double x;
+        int xe;
+        if (!em_row_head<MEASURE>(dsum, HAS_K ? kmult[d.r0 + lane] : 1u, acc, x, xe)) return;
+        for (uint32_t j = 0; j < L; ++j) {
+            const uint32_t c = cl[j], dd = c - wbase;
+            const bool in = dd < (uint32_t)WIN;
+            if (MEASURE) {
+                if (in) atomicMax(&s_xe[dd], xe);
+                else atomicMax(&a.xe[c], xe);
+            } else {
+                uint64_t yh, yl;
+                if (em_term(x, xe, in ? s_w[dd] : a.word[c], acc, yh, yl)) {
+                    if (in) {
+                        atomicAdd((unsigned long long *)&s_hi[dd], (unsigned long long)yh);
+                        atomicAdd((unsigned long long *)&s_lo[dd], (unsigned long long)yl);
+                    } else {
+                        if (yh) atomicAdd((unsigned long long *)&a.hi[c], (unsigned long long)yh);
+                        if (yl) atomicAdd((unsigned long long *)&a.lo[c], (unsigned long long)yl);
+                    }
+                }
+            }
+        }
+    };
+
+    auto process = [&](const SellTile &d, uint32_t &cur_base, const SellTile &refill, Buf &bf) {
+        if (d.flags() & S16_EMPTY) { issue(refill, bf); return; }
+        if (d.wbase != cur_base) {
+            __syncthreads();
+            flush_window(cur_base);
+            load_window(d.wbase);
+            cur_base = d.wbase;
+            __syncthreads();
+        }
+        if (d.flags() & S16_FAST) walk(d, bf);
+        else slow_tile(d);
+        issue(refill, bf);
+    };
+
+    SellTile none;
+    none.off16 = 0; none.r0 = 0; none.wbase = 0; none.meta = sell_meta(0, 0, S16_EMPTY);
+    auto tile_at = [&](uint64_t i) { return i < nt ? T[i] : none; };
+    SellTile dA = tile_at(0), dB = tile_at(1);
+    Buf bufA, bufB;
+    load_window(dA.wbase);
+    uint32_t cur_base = dA.wbase;
+    __syncthreads();
+    issue(dA, bufA);
+    issue(dB, bufB);
+    for (uint64_t i = 0; i < nt; i += 2) {
+        const SellTile nA = tile_at(i + 2), nB = tile_at(i + 3);
+        process(dA, cur_base, nA, bufA);
+        process(dB, cur_base, nB, bufB);
+        dA = nA;
+        dB = nB;
+    }
+    __syncthreads();
+    flush_window(cur_base);
+    if (!MEASURE) em_acc_commit(acc, s_ll, a.ll);
+}
+
 } // namespace mmg

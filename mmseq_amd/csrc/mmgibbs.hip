@@ -2,8 +2,8 @@
 // Host side of the device boundary that replaces src/mmseq.cpp:833-925 of the reference.
 #include "../../include/mmgibbs.h"
 #include "gibbs_kernels.h"
-#include "em_kernels.h"
 #include "sell_kernels.h"
+#include "em_kernels.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -665,6 +665,7 @@ struct mmg_em {
     uint64_t *d_chunk[2] = {nullptr, nullptr}; // tile ranges of the accumulate / measure kernels
     int grid[2] = {0, 0};
     bool fast = false;
+    int path = 0;   // rows-pass kernel: 2 sliced-ELL stream, 1 16-bit tile stream, 0 row per thread from the CSR
     bool first = true;
     int sweeps = 0, repeats = 0;
     double loglik = 0.0;
@@ -706,12 +707,39 @@ static const void *em16_kernel(const mmg_problem *p)
     return hk ? (const void *)k_em16<uint32_t, true, 2560, 256, 128, 128, MEASURE> : (const void *)k_em16<uint32_t, false, 2560, 256, 128, 128, MEASURE>;
 }
 
+template <bool MEASURE>
+static const void *em_sell_kernel(const mmg_problem *p)
+{
+    if (!p->use_sell) return nullptr;
+    const bool hk = p->d_k != nullptr;
+    int rep = 2;
+    if (const char *rp = getenv("MMG_EM_REP")) rep = atoi(rp);
+#define EMS_PICK(IDX, HK) \
+    (MEASURE ? (const void *)k_em_sell<IDX, HK, true, 1> : rep == 1 ? (const void *)k_em_sell<IDX, HK, MEASURE, 1> \
+     : rep == 4 ? (const void *)k_em_sell<IDX, HK, MEASURE, 4> : (const void *)k_em_sell<IDX, HK, MEASURE, 2>)
+    if (p->idx64) return hk ? EMS_PICK(uint64_t, true) : EMS_PICK(uint64_t, false);
+    return hk ? EMS_PICK(uint32_t, true) : EMS_PICK(uint32_t, false);
+#undef EMS_PICK
+}
+
 static int em_launch_rows(mmg_em *e, bool measure)
 {
     mmg_problem *p = e->p;
     EmArgs a;
     a.n = p->n; a.mu = e->d_mu; a.word = e->d_word; a.hi = e->d_hi; a.lo = e->d_lo; a.xe = e->d_xe; a.ll = e->d_ll;
     if (p->m == 0) return MMG_OK;
+    if (e->path == 2) {
+        const int w = measure ? 1 : 0;
+        const void *fn = measure ? em_sell_kernel<true>(p) : em_sell_kernel<false>(p);
+        const void *rp = p->d_row_ptr;
+        const uint32_t *col = p->d_col, *kk = p->d_k;
+        const SellTile *tiles = p->d_sell_tiles;
+        const uint64_t *chunk = e->d_chunk[w];
+        const uint8_t *stream = p->d_sell;
+        void *args[] = {(void *)&rp, (void *)&col, (void *)&kk, (void *)&tiles, (void *)&chunk, (void *)&stream, (void *)&a};
+        HIP_TRY(hipLaunchKernel(fn, dim3((unsigned)e->grid[w]), dim3(64), args, 0, 0));
+        return MMG_OK;
+    }
     if (e->fast) {
         const int w = measure ? 1 : 0;
         const void *fn = measure ? em16_kernel<true>(p) : em16_kernel<false>(p);
@@ -795,17 +823,24 @@ extern "C" int mmg_em_create(const mmg_problem *cp, const double *mu0, mmg_em **
     EM_TRY(hipMalloc((void **)&e->d_out, sizeof(EmOut)));
     EM_TRY(hipMemcpy(e->d_mu, mu0, p->n * sizeof(double), hipMemcpyHostToDevice));
     e->fast = em16_kernel<false>(p) != nullptr && p->n_tiles > 0;
-    if (const char *ev = getenv("MMG_EM_STREAM")) { if (atoi(ev) == 0) e->fast = false; }
-    if (e->fast) {
+    e->path = (em_sell_kernel<false>(p) != nullptr && p->n_sell_tiles > 0) ? 2 : (e->fast ? 1 : 0);
+    if (const char *ev = getenv("MMG_EM_STREAM")) { // 0: row-per-thread kernel, 1: 16-bit tile stream (if the problem has one)
+        if (atoi(ev) == 0) e->path = 0;
+        if (atoi(ev) == 1) e->path = e->fast ? 1 : 0;
+    }
+    e->fast = e->path == 1;
+    if (e->path) {
+        const uint64_t n_tiles = e->path == 2 ? p->n_sell_tiles : p->n_tiles;
+        const unsigned bs = e->path == 2 ? 64 : 128;
         for (int w = 0; w < 2; ++w) {
-            const void *fn = w ? em16_kernel<true>(p) : em16_kernel<false>(p);
+            const void *fn = e->path == 2 ? (w ? em_sell_kernel<true>(p) : em_sell_kernel<false>(p)) : (w ? em16_kernel<true>(p) : em16_kernel<false>(p));
             int per_cu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 128, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 4; }
-            if (per_cu > 16) per_cu = 16;
-            uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>(p->n_tiles, (uint64_t)p->cu_count * per_cu));
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, bs, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 4; }
+            if (per_cu > 32) per_cu = 32;
+            uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, (uint64_t)p->cu_count * per_cu));
             if (const char *eg = getenv("MMG_EM_GRID")) { const long v = atol(eg); if (v >= 1 && (uint64_t)v < grid) grid = (uint64_t)v; } // tests: long tile ranges on small problems
             std::vector<uint64_t> chunk(grid + 1);
-            for (uint64_t c = 0; c <= grid; ++c) chunk[c] = (uint64_t)(((unsigned __int128)p->n_tiles * c) / grid);
+            for (uint64_t c = 0; c <= grid; ++c) chunk[c] = (uint64_t)(((unsigned __int128)n_tiles * c) / grid);
             EM_TRY(hipMalloc((void **)&e->d_chunk[w], chunk.size() * sizeof(uint64_t)));
             EM_TRY(hipMemcpy(e->d_chunk[w], chunk.data(), chunk.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
             e->grid[w] = (int)grid;
@@ -846,7 +881,7 @@ extern "C" int mmg_em_stats(const mmg_em *e, int *sweeps, int *repeated_passes, 
     if (!e) return fail(MMG_ERR_ARG, "NULL argument");
     if (sweeps) *sweeps = e->sweeps;
     if (repeated_passes) *repeated_passes = e->repeats;
-    if (stream_kernel) *stream_kernel = e->fast ? 1 : 0;
+    if (stream_kernel) *stream_kernel = e->path;
     return MMG_OK;
 }
 

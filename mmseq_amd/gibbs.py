@@ -130,10 +130,16 @@ class Em:
         check(self._lib.mmg_em_get_mu(self._h, _ptr(out)))
         return out
 
-    def stats(self):
+    def stats_raw(self):
+        """sweeps, repeated passes, rows-pass kernel id (2 sliced-ELL stream, 1 16-bit tile stream, 0 row per thread)."""
         a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
         check(self._lib.mmg_em_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
-        return {"sweeps": a.value, "repeated_passes": b.value, "stream_kernel": bool(c.value)}
+        return {"sweeps": a.value, "repeated_passes": b.value, "stream_kernel": c.value}
+
+    def stats(self):
+        d = self.stats_raw()
+        d["stream_kernel"] = bool(d["stream_kernel"])
+        return d
 
     def close(self):
         if self._h:

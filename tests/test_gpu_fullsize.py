@@ -86,7 +86,7 @@ def test_conservation_and_kernel_independence_at_full_size(full, gpu, monkeypatc
 def test_em_at_full_size(full, gpu, monkeypatch):
     name, prob, mu0, uh = full
     em = prob.em_stepper(mu0)
-    assert em.stats()["stream_kernel"]
+    assert em.stats_raw()["stream_kernel"] == 2
     lls = [em.loglik]
     for _ in range(8):
         lls.append(em.step())
@@ -94,12 +94,13 @@ def test_em_at_full_size(full, gpu, monkeypatch):
     assert em.stats()["repeated_passes"] == 0
     mu_stream = em.mu()
     em.close()
-    monkeypatch.setenv("MMG_EM_STREAM", "0")                # row-per-thread kernel, global atomics: another order
-    em = prob.em_stepper(mu0)
-    assert not em.stats()["stream_kernel"]
-    lls2 = [em.loglik] + [em.step() for _ in range(8)]
-    assert lls2 == lls and np.array_equal(em.mu(), mu_stream)
-    em.close()
+    for env, want in (("1", 1), ("0", 0)):                  # 16-bit tile stream kernel; row-per-thread kernel, global atomics
+        monkeypatch.setenv("MMG_EM_STREAM", env)
+        em = prob.em_stepper(mu0)
+        assert em.stats_raw()["stream_kernel"] == want
+        lls2 = [em.loglik] + [em.step() for _ in range(8)]
+        assert lls2 == lls and np.array_equal(em.mu(), mu_stream)
+        em.close()
     # at the EM fixed point sum_t mu_t l_t = number of reads; 8 sweeps from the start value are already close
     tot = float(np.sum(mu_stream * prob.l()))
     assert abs(tot / prob.info.total_k - 1.0) < 1e-9

@@ -247,7 +247,8 @@ def test_start_values_and_em_match_oracle(gpu, orc):
     np.testing.assert_allclose(mu, orc.em(p, mu0, max_iter=3, epsilon=-1e308)[0], rtol=1e-13)
 
 
-@pytest.mark.parametrize("sort,stream_env,grid", [(True, None, None), (True, None, "7"), (True, "0", None), (False, None, None)])
+@pytest.mark.parametrize("sort,stream_env,grid", [(True, None, None), (True, None, "7"), (True, "1", None), (True, "1", "7"),
+                                                  (True, "0", None), (False, None, None)])
 def test_em_stepper_paths_match_oracle(gpu, orc, monkeypatch, sort, stream_env, grid):
     """Tile-stream kernel (sorted rows), row-per-thread kernel (forced / unsorted rows): same bits as the oracle,
     with multiplicities, dead transcripts and an empty row; the oracle in turn tracks the reference's summation order."""
@@ -266,7 +267,8 @@ def test_em_stepper_paths_match_oracle(gpu, orc, monkeypatch, sort, stream_env, 
     prob = gpu.Problem.from_csr(pk.row_ptr, pk.col_idx, pk.l, k=pk.k)
     em = prob.em_stepper(mu0)
     st = em.stats()
-    assert st["stream_kernel"] == (sort and stream_env is None)
+    want = 0 if (not sort or stream_env == "0") else (1 if stream_env == "1" else 2)
+    assert em.stats_raw()["stream_kernel"] == want
     lls = [em.loglik]
     for _ in range(12):
         lls.append(em.step())
