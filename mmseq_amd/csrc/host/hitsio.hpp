@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <unordered_map>
 #include <memory>
 #include <string>
 #include <vector>
@@ -80,7 +81,7 @@ private:
                            std::map<std::string, std::vector<std::string>> *, std::vector<std::vector<std::string>> *);
     std::unique_ptr<hitsio_detail::ByteSource> src;
     std::vector<std::string> headerTranscriptName;
-    std::map<std::string, uint32_t> headerIndex; // text schema: name -> header index
+    std::unordered_map<std::string, uint32_t> headerIndex; // text schema: name -> header index
     int hitsfileSchema;
     uint32_t countReadMapRecord;
     std::string deltaBuffer;

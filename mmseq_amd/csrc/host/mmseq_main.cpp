@@ -11,6 +11,7 @@
 // are written after the loop from the device-resident trace, VLAs are heap vectors (:1308-1348).
 // There is no CPU sampler here: without a HIP device the program stops with an error.
 #include <omp.h>
+#include <charconv>
 #include <zlib.h>
 
 #include <algorithm>
@@ -375,10 +376,29 @@ int main(int argc, char **argv)
     vector<uint32_t> k;                   // multiplicity per hit set
     vector<uint64_t> row_ptr(1, 0);       // hit sets in first-seen order
     vector<uint32_t> col_idx;
-    unordered_map<string, uint32_t> indexComb;
     long long numbermappedreads = 0;
     {
-        string rid, key;
+        // hit set -> row: open-addressing table of row ids keyed by a 64-bit hash of the sorted set; a candidate is
+        // confirmed against the stored row itself, so there is no per-set key allocation (src/mmseq.cpp:395-441 keeps a
+        // map<vector<int>,int> and regrows M)
+        vector<uint32_t> table(1u << 16, 0xffffffffu);
+        vector<uint64_t> row_hash;
+        auto hash_of = [](const vector<uint32_t> &c) {
+            uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)c.size();
+            for (uint32_t v : c) { h ^= v; h *= 0xff51afd7ed558ccdull; h ^= h >> 32; }
+            return h;
+        };
+        auto grow = [&]() {
+            vector<uint32_t> bigger(table.size() * 2, 0xffffffffu);
+            const size_t mask = bigger.size() - 1;
+            for (uint32_t r = 0; r < (uint32_t)row_hash.size(); ++r) {
+                size_t s = (size_t)row_hash[r] & mask;
+                while (bigger[s] != 0xffffffffu) s = (s + 1) & mask;
+                bigger[s] = r;
+            }
+            table.swap(bigger);
+        };
+        string rid;
         vector<uint32_t> comb;
         uint32_t hidx = 0;
         while (hitsfileReader.readReadMapRecordReadID(rid)) {
@@ -395,19 +415,28 @@ int main(int argc, char **argv)
                 else doublehits[o]++;
             }
             sort(comb.begin(), comb.end());
-            key.assign((const char *)comb.data(), comb.size() * sizeof(uint32_t));
-            auto it = indexComb.find(key);
-            if (it == indexComb.end()) {
-                const uint32_t row = (uint32_t)k.size();
+            const uint64_t h = hash_of(comb);
+            const size_t mask = table.size() - 1;
+            size_t s = (size_t)h & mask;
+            uint32_t row = 0xffffffffu;
+            for (;; s = (s + 1) & mask) {
+                const uint32_t r = table[s];
+                if (r == 0xffffffffu) break;
+                if (row_hash[r] == h && row_ptr[r + 1] - row_ptr[r] == comb.size() &&
+                    equal(comb.begin(), comb.end(), col_idx.begin() + (ptrdiff_t)row_ptr[r])) { row = r; break; }
+            }
+            if (row == 0xffffffffu) {
+                row = (uint32_t)k.size();
                 if ((row & 0xfff) == 0)
                     cout << "Found " << obs2hdr.size() << " transcripts in " << row << " transcript combinations.\r" << flush;
-                indexComb.emplace(key, row);
+                table[s] = row;
+                row_hash.push_back(h);
                 k.push_back(0);
                 col_idx.insert(col_idx.end(), comb.begin(), comb.end());
                 row_ptr.push_back(col_idx.size());
-                it = indexComb.find(key);
+                if ((uint64_t)k.size() * 2 > table.size()) grow();
             }
-            k[it->second]++;
+            k[row]++;
         }
         cout << "Found " << obs2hdr.size() << " transcripts in " << k.size() << " transcript combinations." << endl;
     }
@@ -444,6 +473,7 @@ int main(int argc, char **argv)
     }
     for (uint32_t t = 0; t < n; ++t) mu[t] /= l[t];
 
+    stage.mark("l, start values, histogram");
     // ---- unique hits to identical sets and genes: O(nnz) form of src/uh.cpp:3-26
     vector<int> identical_unique_hits(identical_transcripts.size(), 0), gene_unique_hits(gene2transcripts.size(), 0);
     {
@@ -486,18 +516,43 @@ int main(int argc, char **argv)
         cerr << "done." << endl;
     }
 
+    stage.mark("unique hits (sets, genes)");
     // ---- .k and .M (src/mmseq.cpp:682-695)
     ofstream ofs;
-    ofs.open((output_base + ".k").c_str());
-    for (uint64_t i = 0; i < m; i++) ofs << k[i] << "\n";
-    ofs.close(); ofs.clear();
-    ofs.open((output_base + ".M").c_str());
-    ofs << "#";
-    for (uint32_t t = 0; t < n; t++) ofs << "\t" << sid(t);
-    ofs << "\n";
-    for (uint64_t i = 0; i < m; ++i)
-        for (uint64_t j = row_ptr[i]; j < row_ptr[i + 1]; ++j) ofs << i << "\t" << col_idx[j] << "\n";
-    ofs.close(); ofs.clear();
+    {   // integer tables: chunks of rows formatted in parallel (to_chars), written in order
+        auto write_rows = [&](ofstream &o, const function<void(uint64_t, string &)> &fmt) {
+            const uint64_t chunk = 1u << 16;
+            const int64_t nchunks = (int64_t)((m + chunk - 1) / chunk);
+            const int64_t batch = max<int64_t>(1, omp_get_max_threads() * 2);
+            for (int64_t c0 = 0; c0 < nchunks; c0 += batch) {
+                const int64_t nb = min(batch, nchunks - c0);
+                vector<string> out(nb);
+#pragma omp parallel for schedule(dynamic, 1)
+                for (int64_t c = 0; c < nb; ++c) {
+                    const uint64_t r0 = (uint64_t)(c0 + c) * chunk, r1 = min<uint64_t>(m, r0 + chunk);
+                    for (uint64_t i = r0; i < r1; ++i) fmt(i, out[c]);
+                }
+                for (auto &x : out) o.write(x.data(), (streamsize)x.size());
+            }
+        };
+        auto put = [](string &o, uint64_t v, char sep) {
+            char tmp[24];
+            auto r = to_chars(tmp, tmp + sizeof tmp, v);
+            o.append(tmp, r.ptr - tmp);
+            o.push_back(sep);
+        };
+        ofs.open((output_base + ".k").c_str());
+        write_rows(ofs, [&](uint64_t i, string &o) { put(o, k[i], '\n'); });
+        ofs.close(); ofs.clear();
+        ofs.open((output_base + ".M").c_str());
+        ofs << "#";
+        for (uint32_t t = 0; t < n; t++) ofs << "\t" << sid(t);
+        ofs << "\n";
+        write_rows(ofs, [&](uint64_t i, string &o) {
+            for (uint64_t j = row_ptr[i]; j < row_ptr[i + 1]; ++j) { put(o, i, '\t'); put(o, col_idx[j], '\n'); }
+        });
+        ofs.close(); ofs.clear();
+    }
 
     if (debug) { // src/mmseq.cpp:697-731
         ofs.open((output_base + ".sharedcounts").c_str());
@@ -524,7 +579,7 @@ int main(int argc, char **argv)
         ofs.close(); ofs.clear();
     }
 
-    stage.mark("host tables (.k .M uh)");
+    stage.mark("write .k .M");
     // ---- device problem: rows stably sorted by (leading transcript, length) -- the layout the sample
     //      kernel's LDS window wants; the row order is irrelevant to the model (rows are exchangeable)
     mmg_problem *prob = nullptr;
