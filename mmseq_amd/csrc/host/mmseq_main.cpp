@@ -11,6 +11,7 @@
 // are written after the loop from the device-resident trace, VLAs are heap vectors (:1308-1348).
 // There is no CPU sampler here: without a HIP device the program stops with an error.
 #include <omp.h>
+#include <parallel/algorithm>
 #include <charconv>
 #include <zlib.h>
 
@@ -95,6 +96,15 @@ static int powerof2(unsigned int x)
 // no dictionary carried over), so the concatenation is a valid deflate stream; the CRCs are merged with
 // crc32_combine.  Any gzip reader (zlib, Boost gzip_decompressor of mmcollapse, R) reads it unchanged.
 // Numbers are formatted with "%g" == default ostream formatting (6 significant digits).
+// "%g" (6 significant digits, what the reference's default ostream formatting prints) without going through printf:
+// to_chars(general, 6) is specified to produce exactly the %.6g digits; nan/inf keep printf's spelling.
+static inline int fmt_g(char *tmp, double v)
+{
+    if (!(v - v == 0.0)) return snprintf(tmp, 40, "%g", v);
+    auto r = to_chars(tmp, tmp + 39, v, chars_format::general, 6);
+    return (int)(r.ptr - tmp);
+}
+
 struct GzText {
     FILE *f = nullptr;
     uLong crc = 0;
@@ -157,8 +167,7 @@ struct GzText {
     void num(double v)
     {
         char tmp[40];
-        int n = snprintf(tmp, sizeof tmp, "%g", v);
-        pending.append(tmp, n);
+        pending.append(tmp, fmt_g(tmp, v));
     }
     void close()
     {
@@ -192,7 +201,8 @@ static void write_trace_lines(GzText &gz, int n_lines, size_t n_cols, const func
             for (int i = lb; i < le; ++i) {
                 for (size_t col = 0; col < n_cols; ++col) {
                     if (!keep(col)) continue;
-                    int len = snprintf(tmp, sizeof tmp, "%g ", at(i, col));
+                    int len = fmt_g(tmp, at(i, col));
+                    tmp[len++] = ' ';
                     s.append(tmp, len);
                 }
                 s += "\n";
@@ -584,14 +594,20 @@ int main(int argc, char **argv)
     //      kernel's LDS window wants; the row order is irrelevant to the model (rows are exchangeable)
     mmg_problem *prob = nullptr;
     {
+        // key = (leading transcript + 1 | 0 for an empty row, length), ties by original position: a plain parallel sort of
+        // (key, row) pairs is the stable order
+        vector<pair<uint64_t, uint32_t>> keyed(m);
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < (int64_t)m; ++i) {
+            const uint64_t L = row_ptr[i + 1] - row_ptr[i];
+            const uint64_t lead = L ? (uint64_t)col_idx[row_ptr[i]] + 1 : 0;
+            keyed[i] = {(lead << 32) | min<uint64_t>(L, 0xffffffffull), (uint32_t)i};
+        }
+        __gnu_parallel::sort(keyed.begin(), keyed.end());
         vector<uint32_t> order(m);
-        for (uint64_t i = 0; i < m; ++i) order[i] = (uint32_t)i;
-        stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-            const uint64_t la = row_ptr[a + 1] - row_ptr[a], lb = row_ptr[b + 1] - row_ptr[b];
-            const int64_t fa = la ? (int64_t)col_idx[row_ptr[a]] : -1, fb = lb ? (int64_t)col_idx[row_ptr[b]] : -1;
-            if (fa != fb) return fa < fb;
-            return la < lb;
-        });
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < (int64_t)m; ++i) order[i] = keyed[i].second;
+        vector<pair<uint64_t, uint32_t>>().swap(keyed);
         vector<uint64_t> d_rp(m + 1, 0);
         vector<uint32_t> d_ci(col_idx.size()), d_k(m);
         for (uint64_t i = 0; i < m; ++i) {
