@@ -104,3 +104,39 @@ def test_em_at_full_size(full, gpu, monkeypatch):
     # at the EM fixed point sum_t mu_t l_t = number of reads; 8 sweeps from the start value are already close
     tot = float(np.sum(mu_stream * prob.l()))
     assert abs(tot / prob.info.total_k - 1.0) < 1e-9
+
+
+def test_multiplicities_at_config2_size(gpu, orc, monkeypatch):
+    """Config-2 shape with collapsed-hit-set multiplicities (Zipf: half the rows k = 1, 15 % k > 8, up to 10^5): every
+    path of the allocation (k categorical draws, conditional-binomial chain) at 5 M rows, bit-exact against the oracle
+    and identical across the three sample kernels."""
+    R, T, avg = CONFIGS["cfg2"]
+    base = gpu.Problem.synthetic(R, T, avg, seed=1234, sort=True)
+    rp, ci = base.download()
+    l = base.l()
+    base.close()
+    rng = np.random.default_rng(1)
+    k = np.minimum(rng.zipf(1.7, size=R), 100000).astype(np.uint32)
+    p = orc.Problem(rp, ci, l, k=k)
+    digests = {}
+    for want, env in ((2, {}), (1, {"MMG_K1_SELL": "0"}), (0, {"MMG_K1_SELL": "0", "MMG_K1_S16": "0"})):
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        prob = gpu.Problem.from_csr(rp, ci, l, k=k)
+        assert prob.info.sample_kernel == want and prob.info.total_k == int(k.astype(np.int64).sum())
+        mu0, uh = prob.start_values()
+        if want == 2:
+            mu_start = mu0
+        s = gpu.Sampler(prob, mu_start, seed=9, gibbs_iter=2, trace_len=2)
+        s.run(2)
+        digests[want] = _digest(s.trace(0), s.counts(0))
+        if want == 2:
+            ref = orc.gibbs_keyed(p, mu_start, seed=9, n_iter=2, trace_len=2)
+            assert np.array_equal(s.counts(0), ref["cnt"]) and np.array_equal(s.trace(0), ref["trace"])
+            assert int(s.counts(0).astype(np.int64).sum()) == prob.info.total_k
+            mu_g, _, ll_g = prob.em(mu_start, max_iter=2, epsilon=-1e308)
+            mu_o, _, ll_o = orc.em(p, mu_start, max_iter=2, epsilon=-1e308)
+            assert np.array_equal(mu_g, mu_o) and ll_g == ll_o
+        s.close()
+        prob.close()
+    assert digests[2] == digests[1] == digests[0]
