@@ -11,6 +11,9 @@
 // are written after the loop from the device-resident trace, VLAs are heap vectors (:1308-1348).
 // There is no CPU sampler here: without a HIP device the program stops with an error.
 #include <omp.h>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
 #include <parallel/algorithm>
 #include <charconv>
 #include <zlib.h>
@@ -408,13 +411,41 @@ int main(int argc, char **argv)
             }
             table.swap(bigger);
         };
-        string rid;
+        // The reader (inflate + record decode, strictly sequential: src/hitsio.hpp:77-79) runs in its own thread and hands
+        // over blocks of decoded reads; this thread collapses them.  Two blocks in flight.
+        struct Block { vector<uint32_t> len, idx; };
+        Block blocks[2];
+        int ready[2] = {0, 0}; // 0: free for the reader, 1: filled, 2: filled and last
+        mutex mtx;
+        condition_variable cv;
+        thread producer([&]() {
+            string rid;
+            uint32_t h = 0;
+            bool more = true;
+            for (int b = 0; more; b ^= 1) {
+                { unique_lock<mutex> lk(mtx); cv.wait(lk, [&] { return ready[b] == 0; }); }
+                Block &B = blocks[b];
+                B.len.clear(); B.idx.clear();
+                while (B.len.size() < 65536 && (more = hitsfileReader.readReadMapRecordReadID(rid))) {
+                    uint32_t c = 0;
+                    while (hitsfileReader.readReadMapRecordTranscriptIndex(h)) { B.idx.push_back(h); ++c; }
+                    B.len.push_back(c);
+                }
+                { lock_guard<mutex> lk(mtx); ready[b] = more ? 1 : 2; }
+                cv.notify_all();
+            }
+        });
         vector<uint32_t> comb;
-        uint32_t hidx = 0;
-        while (hitsfileReader.readReadMapRecordReadID(rid)) {
+        bool last = false;
+        for (int b = 0; !last; b ^= 1) {
+            { unique_lock<mutex> lk(mtx); cv.wait(lk, [&] { return ready[b] != 0; }); last = ready[b] == 2; }
+            const Block &B = blocks[b];
+            size_t at = 0;
+            for (size_t r = 0; r < B.len.size(); ++r) {
             numbermappedreads++;
             comb.clear();
-            while (hitsfileReader.readReadMapRecordTranscriptIndex(hidx)) {
+            for (uint32_t q = 0; q < B.len[r]; ++q) {
+                const uint32_t hidx = B.idx[at++];
                 if (hidx >= nHeader) {
                     cerr << "Error: a read maps to a transcript that has no @TranscriptMetaData entry (no length).\n";
                     exit(1);
@@ -447,7 +478,11 @@ int main(int argc, char **argv)
                 if ((uint64_t)k.size() * 2 > table.size()) grow();
             }
             k[row]++;
+            }
+            { lock_guard<mutex> lk(mtx); ready[b] = 0; }
+            cv.notify_all();
         }
+        producer.join();
         cout << "Found " << obs2hdr.size() << " transcripts in " << k.size() << " transcript combinations." << endl;
     }
     const uint32_t n = (uint32_t)obs2hdr.size();
