@@ -153,7 +153,7 @@ __device__ __forceinline__ bool em_term(double x, int xe, uint32_t w, EmAcc &acc
 {
     const int E = (int)(int16_t)(w & 0xffffu), sl = (int)((w >> 16) & 63u), cap = (int)((w >> 22) & 63u);
     if (E == EM_DEAD) return false;
-    if (xe + E >= cap) { acc.viol = 1; return false; }
+    acc.viol |= (uint32_t)(xe + E >= cap); // no branch: a failed check repeats the whole pass, whatever is added here is discarded
     const double Y = __builtin_ldexp(x, E);
     const double tr = __builtin_trunc(Y);
     yh = (uint64_t)tr;
