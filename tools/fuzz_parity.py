@@ -39,7 +39,8 @@ def one_case(seed, gpu, orc, verbose=True):
         mu0, uh = orc.start_values(pk)
         if rng.integers(0, 3) == 0: mu0[rng.integers(0, T, size=max(1, T // 20))] = 0.0
         if rng.integers(0, 4) == 0: mu0 *= 10.0 ** rng.uniform(-120, 120, size=T)
-        prob = gpu.Problem.from_csr(pk.row_ptr, pk.col_idx, pk.l, k=pk.k)
+        rid0 = int(rng.choice([0, 0, 12345, (1 << 32) - 100, (1 << 40) + 7]))    # shard offset: crosses 2^32 in the middle of a problem
+        prob = gpu.Problem.from_csr(pk.row_ptr, pk.col_idx, pk.l, k=pk.k, row_id_base=rid0)
         g_mu0, g_uh = prob.start_values()
         assert np.array_equal(g_uh, uh), "unique hits"
         n_it = int(rng.integers(1, 6))
@@ -48,7 +49,7 @@ def one_case(seed, gpu, orc, verbose=True):
         s = gpu.Sampler(prob, mu0, alpha=alpha, beta=beta, seed=seed, n_chains=chains, chain_base=2, gibbs_iter=n_it, trace_len=n_it)
         s.run(n_it)
         for c in range(chains):
-            ref = orc.gibbs_keyed(pk, mu0, alpha=alpha, beta=beta, seed=seed, n_iter=n_it, trace_len=n_it, chain=2 + c)
+            ref = orc.gibbs_keyed(pk, mu0, alpha=alpha, beta=beta, seed=seed, n_iter=n_it, trace_len=n_it, chain=2 + c, row_id_base=rid0)
             assert np.array_equal(s.counts(c), ref["cnt"]), "counts chain %d" % c
             assert np.array_equal(s.trace(c), ref["trace"]), "trace chain %d" % c
         s.close()
