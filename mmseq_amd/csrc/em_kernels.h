@@ -426,8 +426,8 @@ __global__ __launch_bounds__(BS) void k_em16(const IdxT *__restrict__ row_ptr, c
 // The rows pass on the sliced-ELL 8-bit stream of k_sample_sell: a tile is one wave, every lane holds its row's window
 // indices in registers, nothing is staged through LDS and there are no barriers on the tile path -- which leaves LDS for
 // REP replicas of the accumulators (lane l adds to replica l % REP; same-address LDS atomics retire one per two clocks).
-template <typename IdxT, bool HAS_K, bool MEASURE, int REP>
-__global__ __launch_bounds__(64) void k_em_sell(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
+template <typename IdxT, bool HAS_K, bool MEASURE, int REP, int W = 1>
+__global__ __launch_bounds__(64 * W) void k_em_sell(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
                                                 const uint32_t *__restrict__ kmult, const SellTile *__restrict__ tiles,
                                                 const uint64_t *__restrict__ chunk_tile, const uint8_t *__restrict__ stream, EmArgs a)
 {
@@ -438,7 +438,11 @@ __global__ __launch_bounds__(64) void k_em_sell(const IdxT *__restrict__ row_ptr
     __shared__ uint64_t s_hi[MEASURE ? 1 : REP * AST], s_lo[MEASURE ? 1 : REP * AST];
     __shared__ int32_t s_xe[MEASURE ? AST : 1];
     __shared__ uint64_t s_ll[3];
-    const uint32_t lane = threadIdx.x;
+    // W waves per workgroup share one window (mu, scale words, accumulators): the LDS per wave drops W-fold, more waves are
+    // resident, and the walk of one wave overlaps the scatter of another.  Wave w owns tiles w, w+W, ... of the range; every
+    // wave steps through EVERY window slide of the range in tile order (two barriers each), so the barrier counts match.
+    constexpr int BS = 64 * W;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t rep_off = MEASURE ? 0u : (lane % REP) * (uint32_t)(AST * 8);
 
     const uint64_t t_begin = chunk_tile[blockIdx.x], t_end = chunk_tile[blockIdx.x + 1];
@@ -446,15 +450,15 @@ __global__ __launch_bounds__(64) void k_em_sell(const IdxT *__restrict__ row_ptr
     const uint64_t nt = t_end - t_begin;
     const SellTile *__restrict__ T = tiles + t_begin;
 
-    if (lane < 3) s_ll[lane] = 0;
-    for (int i = lane; i < AST; i += 64) {
+    if (tid < 3) s_ll[tid] = 0;
+    for (int i = tid; i < AST; i += BS) {
         if (MEASURE) s_xe[i] = INT32_MIN;
         else { for (int r = 0; r < REP; ++r) { s_hi[r * AST + i] = 0; s_lo[r * AST + i] = 0; } }
     }
-    if (lane == 0) { s_mu[WIN] = 0.0; if (!MEASURE) s_w[WIN] = EM_WORD_DEAD; }
+    if (tid == 0) { s_mu[WIN] = 0.0; if (!MEASURE) s_w[WIN] = EM_WORD_DEAD; }
 
     auto flush_window = [&](uint32_t base) {
-        for (int i = lane; i < WIN; i += 64) {
+        for (int i = tid; i < WIN; i += BS) {
             if (MEASURE) {
                 const int32_t v = s_xe[i];
                 if (v != INT32_MIN) { atomicMax(&a.xe[base + (uint32_t)i], v); s_xe[i] = INT32_MIN; }
@@ -467,7 +471,7 @@ __global__ __launch_bounds__(64) void k_em_sell(const IdxT *__restrict__ row_ptr
         }
     };
     auto load_window = [&](uint32_t base) {
-        for (int i = lane; i < WIN; i += 64) {
+        for (int i = tid; i < WIN; i += BS) {
             const uint32_t c = base + (uint32_t)i;
             s_mu[i] = c < a.n ? a.mu[c] : 0.0;
             if (!MEASURE) s_w[i] = c < a.n ? a.word[c] : EM_WORD_DEAD;
@@ -582,36 +586,48 @@ __global__ __launch_bounds__(64) void k_em_sell(const IdxT *__restrict__ row_ptr
         }
     };
 
-    auto process = [&](const SellTile &d, uint32_t &cur_base, const SellTile &refill, Buf &bf) {
-        if (d.flags() & S16_EMPTY) { issue(refill, bf); return; }
-        if (d.wbase != cur_base) {
-            __syncthreads();
-            flush_window(cur_base);
-            load_window(d.wbase);
-            cur_base = d.wbase;
-            __syncthreads();
+    SellTile none;
+    none.off16 = 0; none.r0 = 0; none.wbase = 0; none.meta = sell_meta(0, 0, S16_EMPTY);
+    auto tile_at = [&](uint64_t i) { return i < nt ? T[i] : none; };
+    uint32_t cur_base = tile_at(0).wbase;
+    uint64_t scan = 0; // tiles of the range already examined for a window slide (by this wave; same sequence in every wave)
+    auto slide_to = [&](uint32_t base) {
+        __syncthreads();           // every wave has finished the tiles of the old window
+        flush_window(cur_base);
+        load_window(base);
+        cur_base = base;
+        __syncthreads();
+    };
+    // g: index of the tile in the range (own tiles: wave, wave + W, ...)
+    auto process = [&](const SellTile &d, uint64_t g, const SellTile &refill, Buf &bf) {
+        if (g < nt) {
+            for (; scan <= g; ++scan) {
+                const SellTile q = scan == g ? d : T[scan];
+                if (!(q.flags() & S16_EMPTY) && q.wbase != cur_base) slide_to(q.wbase);
+            }
         }
+        if (d.flags() & S16_EMPTY) { issue(refill, bf); return; }
         if (d.flags() & S16_FAST) walk(d, bf);
         else slow_tile(d);
         issue(refill, bf);
     };
 
-    SellTile none;
-    none.off16 = 0; none.r0 = 0; none.wbase = 0; none.meta = sell_meta(0, 0, S16_EMPTY);
-    auto tile_at = [&](uint64_t i) { return i < nt ? T[i] : none; };
-    SellTile dA = tile_at(0), dB = tile_at(1);
+    SellTile dA = tile_at(wave), dB = tile_at(wave + W);
     Buf bufA, bufB;
-    load_window(dA.wbase);
-    uint32_t cur_base = dA.wbase;
+    load_window(cur_base);
     __syncthreads();
     issue(dA, bufA);
     issue(dB, bufB);
-    for (uint64_t i = 0; i < nt; i += 2) {
-        const SellTile nA = tile_at(i + 2), nB = tile_at(i + 3);
-        process(dA, cur_base, nA, bufA);
-        process(dB, cur_base, nB, bufB);
+    for (uint64_t g = wave; g < nt; g += 2 * W) {
+        const SellTile nA = tile_at(g + 2 * W), nB = tile_at(g + 3 * W);
+        process(dA, g, nA, bufA);
+        process(dB, g + W, nB, bufB);
         dA = nA;
         dB = nB;
+    }
+    for (; scan < nt; ++scan) { // slides after this wave's last tile: the other waves still need them
+        const SellTile q = T[scan];
+        if (!(q.flags() & S16_EMPTY) && q.wbase != cur_base) slide_to(q.wbase);
     }
     __syncthreads();
     flush_window(cur_base);

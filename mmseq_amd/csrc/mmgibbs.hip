@@ -707,16 +707,22 @@ static const void *em16_kernel(const mmg_problem *p)
     return hk ? (const void *)k_em16<uint32_t, true, 2560, 256, 128, 128, MEASURE> : (const void *)k_em16<uint32_t, false, 2560, 256, 128, 128, MEASURE>;
 }
 
+// k_em_sell runs as 2 waves per workgroup with 4 accumulator replicas (1.93 ms per sweep at cfg 3; 1 wave x 2 replicas: 2.12,
+// 2 x 2: 2.01, 4 x 4: 1.99, 2 x 1: 2.34); MMG_EM_WAVES=1 selects the single-wave form for comparison.
+static int em_sell_waves()
+{
+    const char *ev = getenv("MMG_EM_WAVES");
+    return ev && atoi(ev) == 1 ? 1 : 2;
+}
+
 template <bool MEASURE>
 static const void *em_sell_kernel(const mmg_problem *p)
 {
     if (!p->use_sell) return nullptr;
     const bool hk = p->d_k != nullptr;
-    int rep = 2;
-    if (const char *rp = getenv("MMG_EM_REP")) rep = atoi(rp);
-#define EMS_PICK(IDX, HK) \
-    (MEASURE ? (const void *)k_em_sell<IDX, HK, true, 1> : rep == 1 ? (const void *)k_em_sell<IDX, HK, MEASURE, 1> \
-     : rep == 4 ? (const void *)k_em_sell<IDX, HK, MEASURE, 4> : (const void *)k_em_sell<IDX, HK, MEASURE, 2>)
+    const bool one = em_sell_waves() == 1;
+#define EMS_PICK(IDX, HK) (MEASURE ? (one ? (const void *)k_em_sell<IDX, HK, true, 1, 1> : (const void *)k_em_sell<IDX, HK, true, 1, 2>) \
+                                   : (one ? (const void *)k_em_sell<IDX, HK, MEASURE, 2, 1> : (const void *)k_em_sell<IDX, HK, MEASURE, 4, 2>))
     if (p->idx64) return hk ? EMS_PICK(uint64_t, true) : EMS_PICK(uint64_t, false);
     return hk ? EMS_PICK(uint32_t, true) : EMS_PICK(uint32_t, false);
 #undef EMS_PICK
@@ -737,7 +743,7 @@ static int em_launch_rows(mmg_em *e, bool measure)
         const uint64_t *chunk = e->d_chunk[w];
         const uint8_t *stream = p->d_sell;
         void *args[] = {(void *)&rp, (void *)&col, (void *)&kk, (void *)&tiles, (void *)&chunk, (void *)&stream, (void *)&a};
-        HIP_TRY(hipLaunchKernel(fn, dim3((unsigned)e->grid[w]), dim3(64), args, 0, 0));
+        HIP_TRY(hipLaunchKernel(fn, dim3((unsigned)e->grid[w]), dim3(64 * em_sell_waves()), args, 0, 0));
         return MMG_OK;
     }
     if (e->fast) {
@@ -831,7 +837,7 @@ extern "C" int mmg_em_create(const mmg_problem *cp, const double *mu0, mmg_em **
     e->fast = e->path == 1;
     if (e->path) {
         const uint64_t n_tiles = e->path == 2 ? p->n_sell_tiles : p->n_tiles;
-        const unsigned bs = e->path == 2 ? 64 : 128;
+        const unsigned bs = e->path == 2 ? 64 * em_sell_waves() : 128;
         for (int w = 0; w < 2; ++w) {
             const void *fn = e->path == 2 ? (w ? em_sell_kernel<true>(p) : em_sell_kernel<false>(p)) : (w ? em16_kernel<true>(p) : em16_kernel<false>(p));
             int per_cu = 0;

@@ -30,9 +30,10 @@ def one_case(seed, gpu, orc, verbose=True):
     if kern == 0: env["MMG_K1_S16"] = "0"
     if rng.integers(0, 3) == 0: env["MMG_K1_SELL_WAVES_PER_CU"] = "1"
     if rng.integers(0, 3) == 0: env["MMG_EM_GRID"] = str(int(rng.integers(1, 9)))
+    if rng.integers(0, 3) == 0: env["MMG_EM_WAVES"] = "1"
     em_stream = rng.choice(["", "1", "0"])
     if em_stream: env["MMG_EM_STREAM"] = str(em_stream)
-    keys = ["MMG_FORCE_IDX64", "MMG_K1_SELL", "MMG_K1_S16", "MMG_K1_SELL_WAVES_PER_CU", "MMG_EM_GRID", "MMG_EM_STREAM"]
+    keys = ["MMG_FORCE_IDX64", "MMG_K1_SELL", "MMG_K1_S16", "MMG_K1_SELL_WAVES_PER_CU", "MMG_EM_GRID", "MMG_EM_STREAM", "MMG_EM_WAVES"]
     for key in keys: os.environ.pop(key, None)
     os.environ.update(env)
     try:
