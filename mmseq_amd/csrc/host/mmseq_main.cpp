@@ -625,17 +625,34 @@ int main(int argc, char **argv)
     }
 
     stage.mark("write .k .M");
-    // ---- device problem: rows stably sorted by (leading transcript, length) -- the layout the sample
-    //      kernel's LDS window wants; the row order is irrelevant to the model (rows are exchangeable)
+    // ---- device problem.  Transcripts are numbered in HEADER order on the device (observed indices are first-seen order,
+    //      src/mmseq.cpp:399-408, which scatters the isoforms of a gene; the sample kernel keeps a window of consecutive
+    //      transcripts in LDS and wants a read's hits close together), rows stably sorted by (leading transcript, length).
+    //      Both orders are irrelevant to the model; every output stays in the reference's order.
     mmg_problem *prob = nullptr;
+    vector<uint32_t> dev_of_obs(n), obs_of_dev(n);
     {
+        for (uint32_t t = 0; t < n; ++t) obs_of_dev[t] = t;
+        sort(obs_of_dev.begin(), obs_of_dev.end(), [&](uint32_t a, uint32_t b) { return obs2hdr[a] < obs2hdr[b]; });
+        for (uint32_t d = 0; d < n; ++d) dev_of_obs[obs_of_dev[d]] = d;
+    }
+    auto to_dev = [&](const vector<double> &v) { vector<double> o(n); for (uint32_t d = 0; d < n; ++d) o[d] = v[obs_of_dev[d]]; return o; };
+    auto to_obs = [&](const vector<double> &v) { vector<double> o(n); for (uint32_t t = 0; t < n; ++t) o[t] = v[dev_of_obs[t]]; return o; };
+    {
+        // rows in device transcript numbering, each sorted ascending
+        vector<uint32_t> dcol(col_idx.size());
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < (int64_t)m; ++i) {
+            for (uint64_t j = row_ptr[i]; j < row_ptr[i + 1]; ++j) dcol[j] = dev_of_obs[col_idx[j]];
+            sort(dcol.begin() + (ptrdiff_t)row_ptr[i], dcol.begin() + (ptrdiff_t)row_ptr[i + 1]);
+        }
         // key = (leading transcript + 1 | 0 for an empty row, length), ties by original position: a plain parallel sort of
         // (key, row) pairs is the stable order
         vector<pair<uint64_t, uint32_t>> keyed(m);
 #pragma omp parallel for schedule(static)
         for (int64_t i = 0; i < (int64_t)m; ++i) {
             const uint64_t L = row_ptr[i + 1] - row_ptr[i];
-            const uint64_t lead = L ? (uint64_t)col_idx[row_ptr[i]] + 1 : 0;
+            const uint64_t lead = L ? (uint64_t)dcol[row_ptr[i]] + 1 : 0;
             keyed[i] = {(lead << 32) | min<uint64_t>(L, 0xffffffffull), (uint32_t)i};
         }
         __gnu_parallel::sort(keyed.begin(), keyed.end());
@@ -648,12 +665,13 @@ int main(int argc, char **argv)
         for (uint64_t i = 0; i < m; ++i) {
             const uint32_t r = order[i];
             const uint64_t L = row_ptr[r + 1] - row_ptr[r];
-            copy(col_idx.begin() + row_ptr[r], col_idx.begin() + row_ptr[r + 1], d_ci.begin() + d_rp[i]);
+            copy(dcol.begin() + (ptrdiff_t)row_ptr[r], dcol.begin() + (ptrdiff_t)row_ptr[r + 1], d_ci.begin() + (ptrdiff_t)d_rp[i]);
             d_rp[i + 1] = d_rp[i] + L;
             d_k[i] = k[r];
         }
+        const vector<double> l_dev = to_dev(l);
         mmg_problem_desc pd;
-        pd.m = m; pd.n = n; pd.row_ptr = d_rp.data(); pd.col_idx = d_ci.data(); pd.k = d_k.data(); pd.l = l.data();
+        pd.m = m; pd.n = n; pd.row_ptr = d_rp.data(); pd.col_idx = d_ci.data(); pd.k = d_k.data(); pd.l = l_dev.data();
         pd.row_id_base = 0;
         MMG_TRY(mmg_problem_create(&pd, device, &prob));
     }
@@ -665,7 +683,9 @@ int main(int argc, char **argv)
     {
         double loglik = 0.0;
         mmg_em *em = nullptr;
-        MMG_TRY(mmg_em_create(prob, mu.data(), &em, &loglik));
+        vector<double> mu_dev = to_dev(mu);
+        MMG_TRY(mmg_em_create(prob, mu_dev.data(), &em, &loglik));
+        stage.mark("EM set-up + first pass");
         double llr = epsilon + 1;
         int iter = 0;
         cout.precision(5);
@@ -673,7 +693,7 @@ int main(int argc, char **argv)
         while (iter < max_em_iter && llr > epsilon) {
             cout << "EM iteration " << iter << flush;
             if (gz_em) {
-                if (iter) MMG_TRY(mmg_em_get_mu(em, mu.data()));
+                if (iter) { MMG_TRY(mmg_em_get_mu(em, mu_dev.data())); mu = to_obs(mu_dev); }
                 for (uint32_t t = 0; t < n; t++) { gz_em->num(mu[t]); gz_em->str(" "); }
                 gz_em->str("\n");
             }
@@ -684,7 +704,8 @@ int main(int argc, char **argv)
             cout << ", log likelihood ratio: " << llr << "            \r";
             iter++;
         }
-        MMG_TRY(mmg_em_get_mu(em, mu.data()));
+        MMG_TRY(mmg_em_get_mu(em, mu_dev.data()));
+        mu = to_obs(mu_dev);
         mmg_em_destroy(em);
         cout << endl;
         cout.unsetf(ios::floatfield);
@@ -703,7 +724,8 @@ int main(int argc, char **argv)
         cfg.n_chains = 1; cfg.chain_base = 0; cfg.gibbs_iter = gibbs_iter; cfg.trace_len = trace_length;
         cfg.keep_trace = 1; cfg.timing = 0;
         mmg_sampler *smp = nullptr;
-        MMG_TRY(mmg_sampler_create(prob, &cfg, mu_em.data(), &smp));
+        const vector<double> mu_em_dev = to_dev(mu_em);
+        MMG_TRY(mmg_sampler_create(prob, &cfg, mu_em_dev.data(), &smp));
         const int chunk = max(1, gibbs_iter / 16);
         for (int done = 0; done < gibbs_iter; done += chunk) {
             cout << "Gibbs iteration " << done << "       \r" << flush;
@@ -711,7 +733,13 @@ int main(int argc, char **argv)
             MMG_TRY(mmg_sampler_sync(smp));
         }
         cout << "Gibbs iteration " << gibbs_iter - 1 << "       \r" << endl;
-        MMG_TRY(mmg_sampler_get_trace(smp, 0, mu_trace.data()));
+        {
+            vector<double> tr_dev((size_t)n * trace_length);
+            MMG_TRY(mmg_sampler_get_trace(smp, 0, tr_dev.data()));
+#pragma omp parallel for schedule(static)
+            for (int64_t t = 0; t < (int64_t)n; ++t)
+                memcpy(&mu_trace[(size_t)t * trace_length], &tr_dev[(size_t)dev_of_obs[t] * trace_length], (size_t)trace_length * sizeof(double));
+        }
         mmg_sampler_destroy(smp);
     }
     mmg_problem_destroy(prob);

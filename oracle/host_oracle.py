@@ -250,11 +250,17 @@ def expected_run(h, alpha=0.1, beta=0.1, seed=1234, gibbs_iter=1024, max_em_iter
     N = g["mapped"]
     sid = g["index_sid"]
     l = np.array([h.efflen[s] * float(N) / 1e9 for s in sid])
-    order = device_row_order(rows)
-    d_rows = [rows[i] for i in order]
+    # device numbering of the transcripts: header order of the observed ones (the CLI's choice, for window locality)
+    hdr_pos = {name: i for i, name in enumerate(h.names)}
+    obs_of_dev = np.argsort(np.array([hdr_pos[s] for s in sid], np.int64), kind="stable")
+    dev_of_obs = np.empty(n, np.int64)
+    dev_of_obs[obs_of_dev] = np.arange(n)
+    dev_rows = [sorted(int(dev_of_obs[c]) for c in r) for r in rows]
+    order = device_row_order(dev_rows)
+    d_rows = [dev_rows[i] for i in order]
     rp = np.cumsum([0] + [len(r) for r in d_rows]).astype(np.uint64)
     ci = np.array([c for r in d_rows for c in r], np.uint32)
-    p = B.Problem(rp, ci, l, k=k[order].astype(np.uint32))
+    p = B.Problem(rp, ci, l[obs_of_dev], k=k[order].astype(np.uint32))
     # start values in FIRST-SEEN row order on the host (deterministic), src/mmseq.cpp:617-638
     mu0 = np.zeros(n)
     uh = np.zeros(n, np.int64)
@@ -264,9 +270,10 @@ def expected_run(h, alpha=0.1, beta=0.1, seed=1234, gibbs_iter=1024, max_em_iter
         if len(r) == 1:
             uh[r[0]] += kk
     mu0 /= l
-    mu_em, em_iters, ll = B.em(p, mu0, max_iter=max_em_iter, epsilon=epsilon)
-    chain = B.gibbs_keyed(p, mu_em, alpha=alpha, beta=beta, seed=seed, n_iter=gibbs_iter, trace_len=trace_len)
-    trace = chain["trace"]                                   # [n, trace_len], real scale
+    mu_em_dev, em_iters, ll = B.em(p, mu0[obs_of_dev], max_iter=max_em_iter, epsilon=epsilon)
+    chain = B.gibbs_keyed(p, mu_em_dev, alpha=alpha, beta=beta, seed=seed, n_iter=gibbs_iter, trace_len=trace_len)
+    mu_em = mu_em_dev[dev_of_obs]                            # back to the observed (first-seen) order of the outputs
+    trace = chain["trace"][dev_of_obs]                       # [n, trace_len], real scale
     hdr_index = {name: i for i, name in enumerate(h.names)}
     genes = list(h.genes.items())
     # identical / gene sums, simulated traces for isoforms without hits (:927-1008)

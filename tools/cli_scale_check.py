@@ -25,7 +25,9 @@ t0 = time.time()
 r = subprocess.run([exe, "-gibbs_iter", "1024", path, "/tmp/scale_out"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                    env=dict(os.environ, MMSEQ_TIMING="1"))
 print("mmseq rc=%d wall=%.1fs" % (r.returncode, time.time() - t0))
-print(r.stdout.decode().replace("\r", "\n")[-1500:])
+out = r.stdout.decode().replace("\r", "\n")
+print("EM iterations:", out.count("EM iteration"), " Gibbs lines:", out.count("Gibbs iteration"))
+print(out[-1500:])
 print(r.stderr.decode()[-1500:])
 tab = open("/tmp/scale_out.mmseq").read().split("\n")
 print(tab[0], "| rows", len(tab) - 3)

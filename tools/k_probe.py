@@ -18,3 +18,13 @@ for env in ({}, {"MMG_K1_SELL": "0"}):
     tm = s.timing()
     print("kernel", prob.info.sample_kernel, "K1 %.3f ms" % (tm["sample_ms"] / tm["sample_launches"]), "digest", int(s.counts(0).astype(np.int64).sum()), hash(s.counts(0).tobytes()) & 0xffffffff)
     s.close(); prob.close()
+    if not env:
+        import time
+        prob = Problem.from_csr(rp, ci, l, k=k)
+        mu0, _ = prob.start_values()
+        em = prob.em_stepper(mu0)
+        for _ in range(3): em.step()
+        t0 = time.time()
+        for _ in range(40): em.step()
+        print("EM with multiplicities: %.3f ms per sweep" % ((time.time() - t0) / 40 * 1e3), em.stats_raw())
+        em.close(); prob.close()
