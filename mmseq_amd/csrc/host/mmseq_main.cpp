@@ -674,6 +674,12 @@ int main(int argc, char **argv)
         pd.m = m; pd.n = n; pd.row_ptr = d_rp.data(); pd.col_idx = d_ci.data(); pd.k = d_k.data(); pd.l = l_dev.data();
         pd.row_id_base = 0;
         MMG_TRY(mmg_problem_create(&pd, device, &prob));
+        if (stage.on) {
+            mmg_problem_info inf;
+            MMG_TRY(mmg_problem_info_get(prob, &inf));
+            fprintf(stderr, "[timing] sample kernel %d (2 sliced-ELL stream, 1 16-bit tile stream, 0 CSR tiles), %.1f MB on the device\n",
+                    inf.sample_kernel, inf.device_bytes / 1e6);
+        }
     }
 
     stage.mark("device problem build");

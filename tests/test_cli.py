@@ -249,8 +249,10 @@ def test_config1_plumbing_text_and_binary_agree(tmp_path, gpu, orc):
     outs = {}
     for f in ("t", "b"):
         out = str(tmp_path / ("out_" + f))
-        r = run(["-gibbs_iter", "1024", str(tmp_path / (f + ".hits")), out], timeout=300)
+        r = run(["-gibbs_iter", "1024", str(tmp_path / (f + ".hits")), out], timeout=300, env=dict(os.environ, MMSEQ_TIMING="1"))
         assert r.returncode == 0, r.stderr.decode()
+        # the CLI's device layout (header-order transcripts, rows by leading transcript) must qualify for the stream kernel
+        assert b"[timing] sample kernel 2 " in r.stderr, r.stderr.decode()
         outs[f] = {ext: open(out + ext, "rb").read() for ext in (".mmseq", ".gene.mmseq", ".identical.mmseq", ".k", ".M")}
         outs[f]["trace"] = gzip.open(out + ".trace_gibbs.gz", "rb").read()
     assert outs["t"] == outs["b"]
