@@ -23,6 +23,10 @@ extern "C" {
 #endif
 
 #define MMG_ABI_VERSION 2
+/* Layout hint (speed only, never correctness): the stream kernels keep a window of consecutive transcripts in LDS.  Rows
+ * sorted by (leading transcript, length) whose hits all lie within MMG_ROW_SPAN_HINT ids of their first hit always
+ * qualify; a caller that has rows with wider spans does best to sort those behind all the others. */
+#define MMG_ROW_SPAN_HINT 160
 
 enum {
     MMG_OK = 0,

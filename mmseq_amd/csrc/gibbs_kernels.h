@@ -12,12 +12,13 @@
 // sequentially (total, one Philox uniform, prefix walk) and issues one atomic.  The
 // sequential fp64 walk is what makes the draw bit-reproducible against the CPU oracle.
 #pragma once
+#include "../../include/mmgibbs.h"
 #include "mmg_math.h"
 
 namespace mmg {
 
 constexpr int K1_BLOCK = 256;
-constexpr uint32_t K1_WIN_MARGIN = 160;       // hits are expected within this many ids above a row's first hit
+constexpr uint32_t K1_WIN_MARGIN = MMG_ROW_SPAN_HINT;       // hits are expected within this many ids above a row's first hit
 constexpr uint32_t K_SMALL = 8u;              // == MMG_K_SMALL
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));

@@ -627,7 +627,8 @@ int main(int argc, char **argv)
     stage.mark("write .k .M");
     // ---- device problem.  Transcripts are numbered in HEADER order on the device (observed indices are first-seen order,
     //      src/mmseq.cpp:399-408, which scatters the isoforms of a gene; the sample kernel keeps a window of consecutive
-    //      transcripts in LDS and wants a read's hits close together), rows stably sorted by (leading transcript, length).
+    //      transcripts in LDS and wants a read's hits close together), rows stably sorted by (wide span last, leading
+    //      transcript, length).
     //      Both orders are irrelevant to the model; every output stays in the reference's order.
     mmg_problem *prob = nullptr;
     vector<uint32_t> dev_of_obs(n), obs_of_dev(n);
@@ -653,7 +654,10 @@ int main(int argc, char **argv)
         for (int64_t i = 0; i < (int64_t)m; ++i) {
             const uint64_t L = row_ptr[i + 1] - row_ptr[i];
             const uint64_t lead = L ? (uint64_t)dcol[row_ptr[i]] + 1 : 0;
-            keyed[i] = {(lead << 32) | min<uint64_t>(L, 0xffffffffull), (uint32_t)i};
+            // rows spanning more transcripts than the LDS window is guaranteed to cover go behind all others, so that
+            // they cannot disqualify the 64-row tiles of their neighbours
+            const uint64_t far = L && dcol[row_ptr[i + 1] - 1] - dcol[row_ptr[i]] >= MMG_ROW_SPAN_HINT ? 1 : 0;
+            keyed[i] = {(far << 63) | (lead << 32) | min<uint64_t>(L, 0xffffffffull), (uint32_t)i};
         }
         __gnu_parallel::sort(keyed.begin(), keyed.end());
         vector<uint32_t> order(m);

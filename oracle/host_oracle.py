@@ -207,11 +207,15 @@ def ingest(h):
                 doublehits=doublehits, mapped=mapped)
 
 
+ROW_SPAN_HINT = 160   # include/mmgibbs.h: MMG_ROW_SPAN_HINT
+
+
 def device_row_order(rows):
-    """The CLI's device layout: rows stably sorted by (leading transcript, length); empty rows first."""
+    """The CLI's device layout: rows stably sorted by (wide span last, leading transcript, length); empty rows first."""
     first = np.array([r[0] if len(r) else -1 for r in rows], np.int64)
     lens = np.array([len(r) for r in rows], np.int64)
-    return np.lexsort((lens, first))
+    far = np.array([1 if len(r) and r[-1] - r[0] >= ROW_SPAN_HINT else 0 for r in rows], np.int64)
+    return np.lexsort((lens, first, far))
 
 
 # ------------------------------------------------------------------------------------ summaries
