@@ -625,7 +625,7 @@ int main(int argc, char **argv)
     }
 
     stage.mark("write .k .M");
-    // ---- device problem.  Transcripts are numbered in HEADER order on the device (observed indices are first-seen order,
+    // ---- device problem.  Transcripts are numbered in HEADER order, gene by gene, on the device (observed indices are first-seen order,
     //      src/mmseq.cpp:399-408, which scatters the isoforms of a gene; the sample kernel keeps a window of consecutive
     //      transcripts in LDS and wants a read's hits close together), rows stably sorted by (wide span last, leading
     //      transcript, length).
@@ -633,8 +633,25 @@ int main(int argc, char **argv)
     mmg_problem *prob = nullptr;
     vector<uint32_t> dev_of_obs(n), obs_of_dev(n);
     {
-        for (uint32_t t = 0; t < n; ++t) obs_of_dev[t] = t;
-        sort(obs_of_dev.begin(), obs_of_dev.end(), [&](uint32_t a, uint32_t b) { return obs2hdr[a] < obs2hdr[b]; });
+        // key: (smallest header index of the transcript's gene, own header index) -- header order, with the isoforms of a
+        // gene pulled together wherever the header lists them
+        unordered_map<string, uint32_t> hdr_of_name;
+        hdr_of_name.reserve(nHeader * 2);
+        for (size_t i = 0; i < nHeader; ++i) hdr_of_name.emplace(transcriptList[i], (uint32_t)i);
+        map<string, uint32_t> gene_first;
+        for (auto &gt : gene2transcripts) {
+            uint32_t f = 0xffffffffu;
+            for (auto &name : gt.second) { auto it = hdr_of_name.find(name); if (it != hdr_of_name.end()) f = min(f, it->second); }
+            gene_first[gt.first] = f;
+        }
+        vector<pair<uint64_t, uint32_t>> tkey(n);
+        for (uint32_t t = 0; t < n; ++t) {
+            auto tg = transcript2gene.find(sid(t));
+            const uint32_t gf = tg == transcript2gene.end() ? obs2hdr[t] : min(gene_first[tg->second], obs2hdr[t]);
+            tkey[t] = {((uint64_t)gf << 32) | obs2hdr[t], t};
+        }
+        sort(tkey.begin(), tkey.end());
+        for (uint32_t d = 0; d < n; ++d) obs_of_dev[d] = tkey[d].second;
         for (uint32_t d = 0; d < n; ++d) dev_of_obs[obs_of_dev[d]] = d;
     }
     auto to_dev = [&](const vector<double> &v) { vector<double> o(n); for (uint32_t d = 0; d < n; ++d) o[d] = v[obs_of_dev[d]]; return o; };

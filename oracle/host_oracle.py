@@ -254,9 +254,15 @@ def expected_run(h, alpha=0.1, beta=0.1, seed=1234, gibbs_iter=1024, max_em_iter
     N = g["mapped"]
     sid = g["index_sid"]
     l = np.array([h.efflen[s] * float(N) / 1e9 for s in sid])
-    # device numbering of the transcripts: header order of the observed ones (the CLI's choice, for window locality)
+    # device numbering of the transcripts: header order, gene by gene (the CLI's choice, for window locality)
     hdr_pos = {name: i for i, name in enumerate(h.names)}
-    obs_of_dev = np.argsort(np.array([hdr_pos[s] for s in sid], np.int64), kind="stable")
+    gene_first, gene_of_t = {}, {}
+    for gid, ts in h.genes.items():
+        gene_first[gid] = min([hdr_pos[t] for t in ts if t in hdr_pos] or [0xffffffff])
+        for t in ts:
+            gene_of_t[t] = gid
+    tkey = [((min(gene_first[gene_of_t[s]], hdr_pos[s]) if s in gene_of_t else hdr_pos[s]) << 32) | hdr_pos[s] for s in sid]
+    obs_of_dev = np.argsort(np.array(tkey, np.uint64), kind="stable")
     dev_of_obs = np.empty(n, np.int64)
     dev_of_obs[obs_of_dev] = np.arange(n)
     dev_rows = [sorted(int(dev_of_obs[c]) for c in r) for r in rows]
