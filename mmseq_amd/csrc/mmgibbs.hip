@@ -331,7 +331,9 @@ static int problem_build_sell(mmg_problem *p)
         }
     }
     p->sell_fast_fraction = n_live ? (double)n_fast / (double)n_live : 0.0;
-    p->use_sell = p->sell_fast_fraction >= 0.9 || (ev && atoi(ev) == 2);
+    // tiles that do not qualify are walked from the CSR inside the same kernel; half the tiles on the register path already
+    // beats the fallback kernels (callers sort wide rows last, so the slow tiles are a contiguous tail)
+    p->use_sell = p->sell_fast_fraction >= 0.5 || (ev && atoi(ev) == 2);
     if (!p->use_sell) return MMG_OK;
     p->sell_bytes = pos * 16;
     p->n_sell_tiles = nt;
