@@ -144,6 +144,7 @@ struct mmg_problem {
     int grid_sell = 0;
     bool use_sell = false;
     double sell_fast_fraction = 0.0;
+    std::vector<uint64_t> h_sell_cum; // cumulative tile cost (weighted_chunks), kept for the EM kernels' own ranges
     std::vector<uint8_t> h_sell_ng;   // per 64-row tile: groups of the longest row (0: empty, 255: too long); consumed by problem_build_desc
     uint64_t *d_chunk_tile = nullptr;
     uint64_t n_chunks = 0;
@@ -259,6 +260,23 @@ static int problem_finish(mmg_problem *p, const uint64_t *h_row_ptr)
 }
 
 // per-tile descriptors, built on the device from the RESIDENT CSR (col_idx must be final)
+// Contiguous tile ranges of (nearly) equal COST: cum[t] = cost of tiles [0, t).  A tile that cannot run on the register path
+// is walked from the CSR and costs many times more; with equal tile counts a tail of such tiles (wide rows are sorted
+// last) lands on a few workgroups that finish long after the rest.
+static void weighted_chunks(const std::vector<uint64_t> &cum, uint64_t grid, std::vector<uint64_t> &chunk)
+{
+    const uint64_t nt = cum.size() - 1, total = cum[nt];
+    chunk.assign(grid + 1, 0);
+    uint64_t t = 0;
+    for (uint64_t c = 1; c < grid; ++c) {
+        const uint64_t target = (uint64_t)(((unsigned __int128)total * c) / grid);
+        while (t < nt && cum[t] < target) ++t;
+        chunk[c] = t;
+    }
+    chunk[grid] = nt;
+}
+constexpr uint64_t SELL_SLOW_TILE_COST = 24; // measured: a CSR-walked tile against a register-path tile
+
 static const void *k1_sell_kernel(bool idx64, bool has_k)
 {
     if (!idx64 && !has_k) {
@@ -304,8 +322,14 @@ static int problem_build_sell(mmg_problem *p)
     if (per_cu > 32) per_cu = 32;
     if (const char *e2 = getenv("MMG_K1_SELL_WAVES_PER_CU")) { const int v = atoi(e2); if (v >= 1 && v <= 32) per_cu = v; }
     const uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>(nt, (uint64_t)p->cu_count * per_cu));
-    std::vector<uint64_t> chunk(grid + 1);
-    for (uint64_t c = 0; c <= grid; ++c) chunk[c] = (uint64_t)(((unsigned __int128)nt * c) / grid);
+    // cost estimate before the window policy runs: a tile whose columns span more than the window cannot qualify
+    p->h_sell_cum.assign(nt + 1, 0);
+    for (uint64_t t = 0; t < nt; ++t) {
+        const bool slow = td[t].nnz && ((uint64_t)td[t].cmax - td[t].call >= WIN || ngs[t] > 64 || ngs[t] == 0);
+        p->h_sell_cum[t + 1] = p->h_sell_cum[t] + (td[t].nnz == 0 ? 0 : slow ? SELL_SLOW_TILE_COST : 1);
+    }
+    std::vector<uint64_t> chunk;
+    weighted_chunks(p->h_sell_cum, grid, chunk);
     std::vector<SellTile> st(nt);
     uint64_t n_fast = 0, n_live = 0, pos = 0;
     for (uint64_t c = 0; c < grid; ++c) {
@@ -848,7 +872,8 @@ extern "C" int mmg_em_create(const mmg_problem *cp, const double *mu0, mmg_em **
             uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, (uint64_t)p->cu_count * per_cu));
             if (const char *eg = getenv("MMG_EM_GRID")) { const long v = atol(eg); if (v >= 1 && (uint64_t)v < grid) grid = (uint64_t)v; } // tests: long tile ranges on small problems
             std::vector<uint64_t> chunk(grid + 1);
-            for (uint64_t c = 0; c <= grid; ++c) chunk[c] = (uint64_t)(((unsigned __int128)n_tiles * c) / grid);
+            if (e->path == 2 && p->h_sell_cum.size() == n_tiles + 1) weighted_chunks(p->h_sell_cum, grid, chunk);
+            else for (uint64_t c = 0; c <= grid; ++c) chunk[c] = (uint64_t)(((unsigned __int128)n_tiles * c) / grid);
             EM_TRY(hipMalloc((void **)&e->d_chunk[w], chunk.size() * sizeof(uint64_t)));
             EM_TRY(hipMemcpy(e->d_chunk[w], chunk.data(), chunk.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
             e->grid[w] = (int)grid;
