@@ -1,6 +1,7 @@
 """GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same
 seeded inputs.  Integer outputs and -- because both sides implement the same keyed-stream spec
 with once-rounded fp64 arithmetic -- fp64 traces are required to be BIT-IDENTICAL."""
+import json
 import os
 
 import numpy as np
@@ -347,6 +348,23 @@ def test_golden_tiny_chain_on_device(gpu):
     assert np.array_equal(s.trace(0).ravel(), f(g["trace"]))
     assert s.counts(0).tolist() == g["cnt_last"]
     assert np.array_equal(s.mu(0), f(g["mu_last"]))
+
+
+def test_golden_em_on_device(gpu):
+    """tests/golden/em_fixed_tiny.json on the device: mu, log-likelihood and the repeat count, bit for bit."""
+    gd = os.path.join(os.path.dirname(__file__), "golden")
+    g = json.load(open(os.path.join(gd, "keyed_chain_tiny.json")))
+    e = json.load(open(os.path.join(gd, "em_fixed_tiny.json")))
+    fh = lambda xs: np.array([float.fromhex(x) for x in xs])
+    prob = gpu.Problem.from_csr(np.asarray(g["row_ptr"], np.uint64), np.asarray(g["col_idx"], np.uint32), fh(g["l"]),
+                                k=np.asarray(g["k"], np.uint32))
+    for r in e["runs"]:
+        em = prob.em_stepper(fh(r["mu_start"]))
+        for _ in range(r["sweeps"]):
+            em.step()
+        assert [float(x).hex() for x in em.mu()] == r["mu"] and float(em.loglik).hex() == r["loglik"]
+        assert em.stats()["repeated_passes"] == r["repeated_passes"]
+        em.close()
 
 
 def test_torch_view_of_device_buffers_and_single_rank_collectives(gpu, orc):

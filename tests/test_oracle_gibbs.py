@@ -209,3 +209,22 @@ def test_em_fixed_point_spec_tracks_reference_order(orc):
         assert a[3] >= 1 and np.array_equal(a[0] == 0, b[0] == 0)
         np.testing.assert_allclose(a[0][live], b[0][live], rtol=1e-11)
         assert abs(a[2] - b[2]) < 1e-4
+
+
+def _em_golden():
+    import json
+    gd = os.path.join(os.path.dirname(__file__), "golden")
+    g = json.load(open(os.path.join(gd, "keyed_chain_tiny.json")))
+    e = json.load(open(os.path.join(gd, "em_fixed_tiny.json")))
+    fh = lambda xs: np.array([float.fromhex(x) for x in xs])
+    return g, e, fh
+
+
+def test_em_golden_vectors(orc):
+    """tests/golden/em_fixed_tiny.json (tools/gen_golden.py): the exact-sum EM reproduces its committed bits."""
+    g, e, fh = _em_golden()
+    p = orc.Problem(np.asarray(g["row_ptr"], np.uint64), np.asarray(g["col_idx"], np.uint32), fh(g["l"]), k=np.asarray(g["k"], np.uint32))
+    assert any(r["repeated_passes"] > 0 for r in e["runs"])
+    for r in e["runs"]:
+        mu, it, ll, redo = orc.em_x(p, fh(r["mu_start"]), max_iter=r["sweeps"], epsilon=-1e308)
+        assert [float(x).hex() for x in mu] == r["mu"] and float(ll).hex() == r["loglik"] and redo == r["repeated_passes"]

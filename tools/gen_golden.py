@@ -4,6 +4,7 @@ compiled reference sokal.cc in oracle/_ref; `make -C oracle` builds it).
   sokal_reference.json   inputs -> (rc, var, tau, m) produced by the REFERENCE's own sokal()
                          (src/sokal.cc, compiled unmodified)
   keyed_chain_tiny.json  a tiny problem and the keyed-stream Gibbs trace/counts it must produce
+  em_fixed_tiny.json     the same problem through the exact-sum EM: mu and log-likelihood after 0/1/2/8 sweeps
                          (produced by the CPU oracle; guards oracle and kernels against co-drift)
 """
 import json
@@ -74,8 +75,27 @@ def gen_tiny_chain():
               open(os.path.join(OUT, "keyed_chain_tiny.json"), "w"), indent=0)
 
 
+def gen_tiny_em():
+    """The tiny problem of keyed_chain_tiny.json through the exact-sum EM (orc_em): log-likelihoods and mu after 1, 2, 8
+    sweeps, plus a start with one dead and one wildly scaled transcript (takes the measured-exponent repeat path)."""
+    g = json.load(open(os.path.join(OUT, "keyed_chain_tiny.json")))
+    p = B.Problem(np.asarray(g["row_ptr"], np.uint64), np.asarray(g["col_idx"], np.uint32),
+                  np.array([float.fromhex(x) for x in g["l"]]), k=np.asarray(g["k"], np.uint32))
+    mu0 = np.array([float.fromhex(x) for x in g["mu0"]])
+    out = {"source": "oracle/mmseq_oracle.c orc_em (exact fixed-point sums) on the problem of keyed_chain_tiny.json", "runs": []}
+    wild = mu0.copy()
+    wild[2] = 0.0
+    wild[5] *= 1e-120
+    for name, start in (("start_values", mu0), ("dead_and_wild", wild)):
+        for sweeps in (0, 1, 2, 8):
+            mu, it, ll, redo = B.em_x(p, start, max_iter=sweeps, epsilon=-1e308)
+            out["runs"].append(dict(start=name, mu_start=hexf(start), sweeps=sweeps, mu=hexf(mu), loglik=float(ll).hex(), repeated_passes=int(redo)))
+    json.dump(out, open(os.path.join(OUT, "em_fixed_tiny.json"), "w"), indent=0)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gen_sokal()
     gen_tiny_chain()
+    gen_tiny_em()
     print("wrote", os.listdir(OUT))
