@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
 """bench.py -- Gibbs iterations/sec of the mmseq hot path on MI355X (contract: see the task prompt).
 
+HIP events bracket K1 and K2 on every --time-every-th step INSIDE the timed region (default 4: an event pair costs about 9 us of
+stream time, ten per cent of a step if every launch carries one); roofline.avg_launch_ms is the mean over those launches.
+
 A "step" is one Gibbs sweep: K1 (per-row multinomial allocation + count scatter, the CSR stream)
 + K2 (Gamma redraw + trace capture) over the whole synthetic hit matrix, for every chain on the GPU.
 Default workload = BASELINE.json's 50M-read / 200k-transcript shape (configs[2]/[3]): 1 chain per GPU.
 
-  python bench.py --gpus 1 --steps 64 --warmup 8
+  python bench.py --gpus 1 --steps 256 --warmup 16
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W            (one rank per GPU, RCCL)
 """
@@ -72,14 +75,16 @@ def cpu_baseline(args, total_reads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--rows", type=int, default=50_000_000, help="reads per GPU")
     ap.add_argument("--transcripts", type=int, default=200_000)
     ap.add_argument("--avg-hits", type=float, default=20.0)
     ap.add_argument("--chains", type=int, default=1, help="chains per GPU")
     ap.add_argument("--mode", choices=["chains", "shard"], default="chains")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--time-every", type=int, default=4, help="HIP-event pairs around K1/K2 on every N-th step of the timed region "
+                    "(a pair costs about 9 us of stream time; 1 = every step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
     ap.add_argument("--cpu-iters", type=int, default=24)
@@ -123,7 +128,8 @@ def main():
     gibbs_iter = 1024                                      # every iteration is a kept sample (BASELINE.md B formula)
     chain_base = 0 if args.mode == "shard" else rank * args.chains
     smp = Sampler(prob, mu0, seed=args.seed, n_chains=args.chains, chain_base=chain_base, gibbs_iter=gibbs_iter,
-                  trace_len=trace_len, keep_trace=True, timing=True)
+                  trace_len=trace_len, keep_trace=True,
+                  timing=args.time_every if args.steps >= 4 * args.time_every else 1)   # short runs: every step
     mdist.use_current_stream(smp)
     counts = mdist.counts_tensor(smp) if args.mode == "shard" else None
     moments = mdist.moments_tensor(smp)
@@ -192,7 +198,7 @@ def main():
             "reads_iters_per_sec": iters_per_s * reads_per_chain,
             "roofline": {"bound": "hbm", "kernel": kname + " (K1)", "stream_bytes_per_launch": inf.stream_bytes, "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(args, C, kname),
-                         "algorithmic_bytes_per_launch": b_k1, "avg_launch_ms": k1_ms,
+                         "algorithmic_bytes_per_launch": b_k1, "avg_launch_ms": k1_ms, "timed_launches": tm["sample_launches"],
                          "traffic_frac_of_peak": (pmc_traffic(args, C, kname) / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
                          if pmc_traffic(args, C, kname) else None,
                          "note": "achieved = algorithmic bytes of the u32 CSR (SURVEY 8d) / K1 time; the kernel streams a compact "

@@ -96,7 +96,7 @@ typedef struct mmg_config {
     int32_t gibbs_iter; /* planned chain length; sample s kept when iter % (gibbs_iter/trace_len) == 0 (:911) */
     int32_t trace_len;  /* samples per chain: 1024 in the reference (:191)                */
     int32_t keep_trace; /* !=0: store the samples (n*trace_len doubles per chain); 0: moments only */
-    int32_t timing;     /* !=0: bracket every kernel launch with HIP events               */
+    int32_t timing;     /* N > 0: bracket the kernel launches of every N-th iteration with HIP events; 0: none */
 } mmg_config;
 
 typedef struct mmg_timing {

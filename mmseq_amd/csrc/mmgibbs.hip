@@ -1044,7 +1044,8 @@ extern "C" int mmg_sampler_sample(mmg_sampler *s)
     const mmg_problem *p = s->p;
     HIP_TRY(hipSetDevice(p->device));
     int e0 = -1, e1 = -1;
-    if (s->cfg.timing) {
+    const bool timed = s->cfg.timing > 0 && s->iter % s->cfg.timing == 0; // every timing-th iteration: an event pair costs ~9 us of stream time
+    if (timed) {
         int rc = ev_get(s, e0); if (rc) return rc;
         rc = ev_get(s, e1); if (rc) return rc;
         HIP_TRY(hipEventRecord(s->ev_pool[e0], s->cur));
@@ -1090,7 +1091,7 @@ extern "C" int mmg_sampler_sample(mmg_sampler *s)
         }
         HIP_TRY(hipGetLastError());
     }
-    if (s->cfg.timing) {
+    if (timed) {
         HIP_TRY(hipEventRecord(s->ev_pool[e1], s->cur));
         s->ev_sample.push_back({e0, e1});
     }
@@ -1115,7 +1116,8 @@ extern "C" int mmg_sampler_update(mmg_sampler *s)
     a.chain_base = (uint32_t)s->cfg.chain_base; a.iter = (uint32_t)s->iter; a.sample_idx = sample_idx;
     a.trace_len = (uint32_t)s->cfg.trace_len;
     int e0 = -1, e1 = -1;
-    if (s->cfg.timing) {
+    const bool timed = s->cfg.timing > 0 && s->iter % s->cfg.timing == 0;
+    if (timed) {
         int rc = ev_get(s, e0); if (rc) return rc;
         rc = ev_get(s, e1); if (rc) return rc;
         HIP_TRY(hipEventRecord(s->ev_pool[e0], s->cur));
@@ -1123,7 +1125,7 @@ extern "C" int mmg_sampler_update(mmg_sampler *s)
     const unsigned gb = (unsigned)((C * n + 255) / 256);
     hipLaunchKernelGGL(k_update, dim3(gb), dim3(256), 0, s->cur, a);
     HIP_TRY(hipGetLastError());
-    if (s->cfg.timing) {
+    if (timed) {
         HIP_TRY(hipEventRecord(s->ev_pool[e1], s->cur));
         s->ev_update.push_back({e0, e1});
     }
