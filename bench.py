@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--time-every", type=int, default=4, help="HIP-event pairs around K1/K2 on every N-th step of the timed region "
                     "(a pair costs about 9 us of stream time; 1 = every step)")
+    ap.add_argument("--settle-iters", type=int, default=256, help="iterations of a scratch chain before the warm-up steps (GPU clock ramp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
     ap.add_argument("--cpu-iters", type=int, default=24)
@@ -142,6 +143,16 @@ def main():
 
     if args.warmup + args.steps > gibbs_iter:
         raise SystemExit("warmup + steps must be <= %d" % gibbs_iter)
+    if args.settle_iters > 0:
+        # The GPU raises its clocks over the first ~100 ms of load: 64 steps right after start-up average 0.39 ms, steps 200+
+        # 0.35 ms.  A scratch chain (different key, nothing kept) brings the clocks up before the W warm-up steps, so that short
+        # timed regions measure the steady state a 1024-iteration run lives in.  Not part of W or K; reported in config.
+        scratch = Sampler(prob, mu0, seed=args.seed + 1, n_chains=1, chain_base=1 << 20, gibbs_iter=1 << 20, trace_len=1,
+                          keep_trace=False, timing=0)
+        mdist.use_current_stream(scratch)
+        scratch.run(args.settle_iters)
+        torch.cuda.synchronize()
+        scratch.close()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -194,7 +205,8 @@ def main():
                        "parallelism": ("%d independent chains (1 all-reduce of posterior moments)" % chains_total)
                        if args.mode == "chains" else ("read-sharded single chain over %d GPUs "
                                                       "(int32 count all-reduce per iteration)" % world),
-                       "trace": "every iteration kept (fp64 mu trace resident in HBM)", "generator_seed": args.seed},
+                       "trace": "every iteration kept (fp64 mu trace resident in HBM)", "generator_seed": args.seed,
+                       "clock_settle_iters_before_warmup": args.settle_iters},
             "reads_iters_per_sec": iters_per_s * reads_per_chain,
             "roofline": {"bound": "hbm", "kernel": kname + " (K1)", "stream_bytes_per_launch": inf.stream_bytes, "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(args, C, kname),
