@@ -22,11 +22,16 @@
 extern "C" {
 #endif
 
-#define MMG_ABI_VERSION 2
-/* Layout hint (speed only, never correctness): the stream kernels keep a window of consecutive transcripts in LDS.  Rows
- * sorted by (leading transcript, length) whose hits all lie within MMG_ROW_SPAN_HINT ids of their first hit always
- * qualify; a caller that has rows with wider spans does best to sort those behind all the others. */
-#define MMG_ROW_SPAN_HINT 160
+#define MMG_ABI_VERSION 3
+/* Layout.  The model does not care about the order of rows or the numbering of transcripts (src/mmseq.cpp:399-418 uses
+ * first-seen order for both); the kernels do: they keep a window of consecutive transcripts in LDS and want the 64 rows of a
+ * wave to have equal lengths.  mmg_problem_create therefore stores the rows in a CANONICAL order of its own (sorted on the
+ * device by leading-transcript band, multiplicity class, length and a content hash -- a pure function of the set of rows, so
+ * the chain does not depend on the order the caller happened to read them in) and, given tx_order, renumbers the transcripts
+ * internally.  Every per-transcript array crossing this ABI stays in the CALLER's numbering; rows never cross it. */
+#define MMG_LAYOUT_CANONICAL 0u /* default: rows re-ordered by the library                                      */
+#define MMG_LAYOUT_KEEP_ROWS 1u /* rows kept as given (row i of the upload draws from random stream row_id_base + i):
+                                   shards cut from an already canonical problem, tests of specific row orders    */
 
 enum {
     MMG_OK = 0,
@@ -54,9 +59,14 @@ typedef struct mmg_problem_desc {
     const uint32_t *col_idx; /* row_ptr[m] column indices                                */
     const uint32_t *k;       /* m multiplicities, or NULL for all ones                   */
     const double *l;         /* n: effective_length * mapped_reads / 1e9  (:603), > 0    */
-    uint64_t row_id_base;    /* global index of row 0 (read-shard mode: the shard offset;
-                                keys the per-row random stream so shards reproduce the
-                                single-device chain bit for bit)                         */
+    uint64_t row_id_base;    /* global index of stored row 0 (read-shard mode: the shard offset):
+                                stored row i draws from random stream row_id_base + i      */
+    uint32_t layout;         /* MMG_LAYOUT_*                                              */
+    const uint64_t *tx_order;/* optional, n keys: transcripts are laid out on the device by ascending
+                                (key, index).  A caller that knows which transcripts share reads (the
+                                isoforms of a gene, src/mmseq.cpp:358) passes gene_ordinal << 32 | ordinal
+                                within the gene, so that a read's hits are neighbours.  NULL: the caller's
+                                numbering is the device numbering                         */
 } mmg_problem_desc;
 
 /* Synthetic problem generated directly into device CSR (no reference counterpart; the
@@ -68,22 +78,27 @@ typedef struct mmg_synth_desc {
     uint32_t n;           /* transcripts                                                  */
     double avg_hits;      /* row length = min(100, 1 + Poisson(avg_hits - 1))             */
     int32_t uniform;      /* 0: hits inside a +-64 index window; 1: uniform over n        */
-    int32_t sorted;       /* 1: rows stably ordered by leading transcript (the order hit-set
-                             collapse yields; what the sample kernel's LDS window wants);
-                             0: generator order (a name-sorted BAM's order)               */
+    int32_t sorted;       /* 1: canonical layout (MMG_LAYOUT_CANONICAL); 0: generator order kept
+                             (a name-sorted BAM's order; MMG_LAYOUT_KEEP_ROWS)            */
     uint64_t mapped_reads;/* N in l = efflen * N / 1e9; 0 => rows                         */
+    double far_fraction;  /* fraction of the rows (>= 2 hits) whose last drawn hit is replaced by a
+                             transcript anywhere in [0, n): reads that also hit a paralogue */
 } mmg_synth_desc;
 
 typedef struct mmg_problem_info {
     uint64_t m, nnz, total_k, row_id_base;
     uint32_t n;
     uint32_t max_row_len;
-    uint64_t n_tiles;      /* LDS tiles the sample kernel walks                           */
+    uint64_t n_tiles;      /* tiles the sample kernel walks                               */
     uint64_t device_bytes; /* HBM held by the problem                                     */
     int32_t index_bits;    /* 32 or 64: width of the device row_ptr                       */
-    int32_t sample_kernel; /* what mmg_sampler_sample launches: 0 k_sample (32-bit CSR tiles), 1 k_sample16
-                              (16-bit tile stream), 2 k_sample_sell (sliced-ELL 16-bit stream)   */
+    int32_t sample_kernel; /* what mmg_sampler_sample launches: 2 k_sample_sell (sliced-ELL 8-bit stream; the default),
+                              0 k_sample (32-bit CSR tiles: problems whose rows mostly span more than an LDS window) */
     uint64_t stream_bytes; /* bytes of the tile stream that kernel reads per launch (0 for kernel 0) */
+    uint64_t fast_tiles;   /* sliced-ELL tiles walked from the register stream (the rest: from the CSR) */
+    uint64_t padded_slots; /* hit slots of the sliced-ELL stream incl. padding (>= nnz of the fast tiles) */
+    int32_t layout;        /* MMG_LAYOUT_* in force                                       */
+    int32_t tx_renumbered; /* 1: tx_order was given                                       */
 } mmg_problem_info;
 
 /* Parameters of the Gibbs loop: alpha/beta are the Gamma prior (src/mmseq.cpp:184-185),
@@ -114,12 +129,15 @@ int mmg_device_count(int *count);
 int mmg_problem_create(const mmg_problem_desc *desc, int device, mmg_problem **out);
 int mmg_problem_create_synthetic(const mmg_synth_desc *desc, int device, mmg_problem **out);
 int mmg_problem_info_get(const mmg_problem *p, mmg_problem_info *info);
-/* Copies the device CSR back (row_ptr m+1 u64, col_idx nnz u32; either may be NULL). */
-int mmg_problem_download(const mmg_problem *p, uint64_t *row_ptr, uint32_t *col_idx);
+/* Copies the device CSR back in STORED order (row_ptr m+1 u64, col_idx nnz u32 in the caller's transcript numbering,
+ * k m u32; any may be NULL): what a checker needs to replay the chain row by row -- stored row i walks its hits in the
+ * returned order and draws from random stream row_id_base + i. */
+int mmg_problem_download(const mmg_problem *p, uint64_t *row_ptr, uint32_t *col_idx, uint32_t *k);
 int mmg_problem_get_l(const mmg_problem *p, double *l);
 /* Start values and the unique-hit column, src/mmseq.cpp:617-638: mu0[t] = sum_{i: t in row i}
  * k_i/|row i| / l[t]; unique_hits[t] = sum of k_i over rows {t} (bit-exact integer). Either
- * output may be NULL. */
+ * output may be NULL.  The shares are summed exactly (fixed point, 2^-52 resolution), so mu0 does not
+ * depend on the order of the rows. */
 int mmg_problem_start_values(const mmg_problem *p, double *mu0, int32_t *unique_hits);
 /* EM to convergence from mu (in/out), src/mmseq.cpp:741-811: stop when the log-likelihood
  * gain <= epsilon or after max_iter sweeps. */
@@ -140,6 +158,7 @@ int mmg_em_get_mu(mmg_em *e, double *mu);
  * 1 16-bit tile stream, 0 row per thread from the CSR) */
 int mmg_em_stats(const mmg_em *e, int *sweeps, int *repeated_passes, int *stream_kernel);
 void mmg_em_destroy(mmg_em *e);
+/* Samplers and EM handles created from a problem must be destroyed before the problem. */
 void mmg_problem_destroy(mmg_problem *p);
 
 /* ---- sampler ------------------------------------------------------------------------ */
@@ -156,7 +175,8 @@ int mmg_sampler_run(mmg_sampler *s, int n_iter);
 int mmg_sampler_sample(mmg_sampler *s);
 int mmg_sampler_update(mmg_sampler *s);
 /* Device pointers for collectives: counts int32 [n_chains][n]; moments double
- * [2][n_chains][n] (sum log mu, sum log^2 mu over kept samples). */
+ * [2][n_chains][n] (sum log mu, sum log^2 mu over kept samples).  Element t of these buffers is DEVICE transcript t
+ * (mmg_problem_tx_perm); ranks that passed the same tx_order agree on it, which is all a sum needs. */
 int mmg_sampler_counts_devptr(mmg_sampler *s, void **ptr, uint64_t *count);
 int mmg_sampler_moments_devptr(mmg_sampler *s, void **ptr, uint64_t *count);
 int mmg_sampler_sync(mmg_sampler *s);
@@ -174,12 +194,26 @@ int mmg_sampler_get_timing(mmg_sampler *s, mmg_timing *t);
 int mmg_sampler_reset_timing(mmg_sampler *s);
 void mmg_sampler_destroy(mmg_sampler *s);
 
+/* int_of_ext[t] = device index of the caller's transcript t (identity without tx_order). */
+int mmg_problem_tx_perm(const mmg_problem *p, uint32_t *int_of_ext);
+
 /* ---- host-side keyed draws ------------------------------------------------------------ */
 /* out[i] = Gamma(shape, scale) from the keyed stream (seed, tag SIMU, id, i): the simulated traces
  * of isoforms without hits, src/mmseq.cpp:971-978 (which uses rg[0] there).  Pure host code. */
 int mmg_host_gamma_trace(uint64_t seed, uint64_t id, double shape, double scale, int n, double *out);
 
 /* ---- self-test hooks (used by tests only) ------------------------------------------- */
+/* Process-wide overrides of choices the library normally makes itself, so that tests can reach every kernel on small
+ * inputs.  They never change a result.  value < 0 restores the default. */
+enum {
+    MMG_OPT_SAMPLE_KERNEL = 0,     /* 0: k_sample (CSR tiles), 2: k_sample_sell even if few tiles qualify            */
+    MMG_OPT_FORCE_IDX64 = 1,       /* 1: 64-bit device row offsets regardless of nnz                                 */
+    MMG_OPT_SELL_WAVES_PER_CU = 2, /* cap on resident single-wave workgroups per CU (long tile ranges on small inputs) */
+    MMG_OPT_EM_KERNEL = 3,         /* 0: row-per-thread EM kernel, 2: sliced-ELL EM kernel                           */
+    MMG_OPT_EM_GRID = 4,           /* cap on the EM kernel's grid                                                    */
+    MMG_OPT_COUNT_ = 5
+};
+int mmg_selftest_option(int option, int value);
 /* Evaluates the library's own log / exp / sqrt / 1/x on x[0..n) (device >= 0: in a kernel
  * on that device; device == -1: the host instantiation of the same inline code). */
 int mmg_selftest_math(int device, int64_t n, const double *x, double *out_log, double *out_exp,

@@ -17,22 +17,29 @@ class MMGError(RuntimeError):
         self.code = code
 
 
+LAYOUT_CANONICAL, LAYOUT_KEEP_ROWS = 0, 1
+# mmg_selftest_option ids
+OPT_SAMPLE_KERNEL, OPT_FORCE_IDX64, OPT_SELL_WAVES_PER_CU, OPT_EM_KERNEL, OPT_EM_GRID = range(5)
+
+
 class ProblemDesc(C.Structure):
     _fields_ = [("m", C.c_uint64), ("n", C.c_uint32), ("row_ptr", C.c_void_p), ("col_idx", C.c_void_p),
-                ("k", C.c_void_p), ("l", C.c_void_p), ("row_id_base", C.c_uint64)]
+                ("k", C.c_void_p), ("l", C.c_void_p), ("row_id_base", C.c_uint64), ("layout", C.c_uint32),
+                ("tx_order", C.c_void_p)]
 
 
 class SynthDesc(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("rows", C.c_uint64), ("row0", C.c_uint64), ("n", C.c_uint32),
                 ("avg_hits", C.c_double), ("uniform", C.c_int32), ("sorted", C.c_int32),
-                ("mapped_reads", C.c_uint64)]
+                ("mapped_reads", C.c_uint64), ("far_fraction", C.c_double)]
 
 
 class ProblemInfo(C.Structure):
     _fields_ = [("m", C.c_uint64), ("nnz", C.c_uint64), ("total_k", C.c_uint64), ("row_id_base", C.c_uint64),
                 ("n", C.c_uint32), ("max_row_len", C.c_uint32), ("n_tiles", C.c_uint64),
                 ("device_bytes", C.c_uint64), ("index_bits", C.c_int32), ("sample_kernel", C.c_int32),
-                ("stream_bytes", C.c_uint64)]
+                ("stream_bytes", C.c_uint64), ("fast_tiles", C.c_uint64), ("padded_slots", C.c_uint64),
+                ("layout", C.c_int32), ("tx_renumbered", C.c_int32)]
 
 
 class Config(C.Structure):
@@ -54,7 +61,9 @@ SYMBOLS = {
     "mmg_problem_create": (C.c_int, [C.POINTER(ProblemDesc), C.c_int, C.POINTER(C.c_void_p)]),
     "mmg_problem_create_synthetic": (C.c_int, [C.POINTER(SynthDesc), C.c_int, C.POINTER(C.c_void_p)]),
     "mmg_problem_info_get": (C.c_int, [C.c_void_p, C.POINTER(ProblemInfo)]),
-    "mmg_problem_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mmg_problem_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mmg_problem_tx_perm": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mmg_selftest_option": (C.c_int, [C.c_int, C.c_int]),
     "mmg_problem_get_l": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mmg_problem_start_values": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mmg_problem_em": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_int),

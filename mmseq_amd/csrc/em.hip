@@ -1,0 +1,62 @@
+// em.hip -- device TU: EM sweeps (src/mmseq.cpp:741-811), kernels in em_kernels.h
+#include "gibbs_kernels.h"
+#include "sell_kernels.h"
+#include "em_kernels.h"
+#include "mmg_launch.h"
+
+namespace mmg {
+
+// k_em_sell runs as 2 waves per workgroup sharing one window, 4 accumulator replicas (measured at cfg 3: 1.93 ms per sweep;
+// 1 wave x 2 replicas 2.12, 2 x 2 2.01, 4 x 4 1.99, 2 x 1 2.34)
+const void *em_sell_kernel(bool idx64, bool has_k, bool measure)
+{
+    static_assert(EM_SELL_BS == 128, "two waves per workgroup");
+#define EMS_PICK(IDX, HK) (measure ? (const void *)k_em_sell<IDX, HK, true, 1, 2> : (const void *)k_em_sell<IDX, HK, false, 4, 2>)
+    if (idx64) return has_k ? EMS_PICK(uint64_t, true) : EMS_PICK(uint64_t, false);
+    return has_k ? EMS_PICK(uint32_t, true) : EMS_PICK(uint32_t, false);
+#undef EMS_PICK
+}
+
+void launch_em_rows_global(bool idx64, bool measure, const void *row_ptr, const uint32_t *col, const uint32_t *k, uint64_t m,
+                           EmArgs a, hipStream_t s)
+{
+    if (!m) return;
+    const unsigned gr = (unsigned)((m + 255) / 256);
+    if (idx64) {
+        if (measure) hipLaunchKernelGGL((k_em_rows_global<uint64_t, true>), dim3(gr), dim3(256), 0, s, (const uint64_t *)row_ptr, col, k, m, a);
+        else hipLaunchKernelGGL((k_em_rows_global<uint64_t, false>), dim3(gr), dim3(256), 0, s, (const uint64_t *)row_ptr, col, k, m, a);
+    } else {
+        if (measure) hipLaunchKernelGGL((k_em_rows_global<uint32_t, true>), dim3(gr), dim3(256), 0, s, (const uint32_t *)row_ptr, col, k, m, a);
+        else hipLaunchKernelGGL((k_em_rows_global<uint32_t, false>), dim3(gr), dim3(256), 0, s, (const uint32_t *)row_ptr, col, k, m, a);
+    }
+}
+
+void launch_em_colcount(const uint32_t *col, uint64_t nnz, uint64_t *cnt, unsigned grid, hipStream_t s)
+{
+    if (nnz) hipLaunchKernelGGL(k_em_colcount, dim3(grid), dim3(256), 0, s, col, nnz, cnt);
+}
+void launch_fill_i32(int32_t *p, uint32_t n, int32_t v, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_fill_i32, dim3((n + 255) / 256), dim3(256), 0, s, p, n, v);
+}
+void launch_em_prepare(uint32_t n, const double *mu, const double *l, const uint64_t *colcnt, const int32_t *ref, int measured,
+                       uint32_t *word, uint64_t *hi, uint64_t *lo, double *partial, uint64_t *ll, const uint32_t *int_of_ext,
+                       hipStream_t s)
+{
+    hipLaunchKernelGGL(k_em_prepare, dim3((n + 255) / 256), dim3(256), 0, s, n, mu, l, colcnt, ref, measured, word, hi, lo, partial, ll, int_of_ext);
+}
+void launch_em_check(uint32_t n, const uint32_t *word, const uint64_t *hi, uint64_t *ll, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_em_check, dim3((n + 255) / 256), dim3(256), 0, s, n, word, hi, ll);
+}
+void launch_em_finish(const double *partial, uint32_t np, const uint64_t *ll, EmOut *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_em_finish, dim3(1), dim3(1), 0, s, partial, np, ll, out);
+}
+void launch_em_apply(uint32_t n, double *mu, const double *l, const uint32_t *word, const uint64_t *hi, const uint64_t *lo,
+                     int32_t *sexp, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_em_apply, dim3((n + 255) / 256), dim3(256), 0, s, n, mu, l, word, hi, lo, sexp);
+}
+
+} // namespace mmg

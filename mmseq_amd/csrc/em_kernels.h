@@ -2,7 +2,7 @@
 //
 // One sweep is mu_t <- mu_t/l_t * S_t with S_t = sum_{rows i containing t} k_i/d_i, d_i = sum_{t in i} mu_t.
 // The rows pass is the Gibbs row walk with a different second half: instead of picking one hit, every hit of
-// the row receives the row's x_i = k_i/d_i.  It runs on the same 16-bit tile stream and LDS window as K1 (mu
+// the row receives the row's x_i = k_i/d_i.  It runs on the same sliced-ELL stream and LDS window as K1 (mu
 // gathers and the accumulators live in the window), so a sweep costs about as much HBM as a Gibbs iteration.
 //
 // The sums are accumulated in 2 x 64-bit fixed point (HI/LO limbs, integer atomics): exact, hence independent
@@ -23,11 +23,6 @@ __host__ __device__ __forceinline__ uint32_t em_pack(int E, int sl, int cap)
     return ((uint32_t)E & 0xffffu) | ((uint32_t)sl << 16) | ((uint32_t)cap << 22);
 }
 constexpr uint32_t EM_WORD_DEAD = (0x8000u) | (63u << 22);
-
-struct EmOut {
-    double loglik;
-    uint64_t flag;
-};
 
 __device__ __forceinline__ double block_sum_256(double v, double *red)
 {
@@ -58,7 +53,8 @@ __global__ void k_fill_i32(int32_t *p, uint32_t n, int32_t v)
 __global__ __launch_bounds__(256) void k_em_prepare(uint32_t n, const double *__restrict__ mu, const double *__restrict__ l,
                                                     const uint64_t *__restrict__ colcnt, const int32_t *__restrict__ ref,
                                                     int measured, uint32_t *__restrict__ word, uint64_t *__restrict__ hi,
-                                                    uint64_t *__restrict__ lo, double *__restrict__ partial, uint64_t *ll)
+                                                    uint64_t *__restrict__ lo, double *__restrict__ partial, uint64_t *ll,
+                                                    const uint32_t *__restrict__ int_of_ext)
 {
     __shared__ double red[256];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -76,7 +72,9 @@ __global__ __launch_bounds__(256) void k_em_prepare(uint32_t n, const double *__
         word[t] = w;
         hi[t] = 0;
         lo[t] = 0;
-        pen = m * l[t];
+        // the penalty is summed in the CALLER's transcript order (256-blocks of caller ids), whatever the device numbering
+        const uint32_t pt = int_of_ext ? int_of_ext[t] : t;
+        pen = mu[pt] * l[pt];
     }
     if (blockIdx.x == 0 && threadIdx.x < 3) ll[threadIdx.x] = 0;
     const double tot = block_sum_256(pen, red);
@@ -115,15 +113,6 @@ __global__ void k_em_apply(uint32_t n, double *mu, const double *__restrict__ l,
     mu[t] = mu[t] * S / l[t];
     sexp[t] = (S > 0.0 && S < __builtin_huge_val()) ? dilogb(S) : INT32_MIN;
 }
-
-struct EmArgs {
-    uint32_t n;
-    const double *mu;      // n
-    const uint32_t *word;  // n   packed scale words
-    uint64_t *hi, *lo;     // n   accumulators (accumulate pass)
-    int32_t *xe;           // n   max ilogb(x_i) (measure pass)
-    uint64_t *ll;          // [0] LLH  [1] LLL  [2] repeat flag
-};
 
 // per-thread running log-likelihood limbs and check flag
 struct EmAcc {
@@ -211,218 +200,6 @@ __global__ __launch_bounds__(256) void k_em_rows_global(const IdxT *__restrict__
     em_acc_commit(acc, s_ll, a.ll);
 }
 
-// The rows pass on K1's 16-bit tile stream (same tiles, same window policy, same depth-2 prefetch).
-template <typename IdxT, bool HAS_K, int ELEMS, int WIN, int BS, int RC, bool MEASURE, int ABL = 0, int REP = 2>
-__global__ __launch_bounds__(BS) void k_em16(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
-                                             const uint32_t *__restrict__ kmult, const S16Tile *__restrict__ tiles,
-                                             const uint64_t *__restrict__ chunk_tile, const u32x4 *__restrict__ stream16, EmArgs a)
-{
-    const int tid = threadIdx.x;
-    constexpr int ROWS_CAP = RC;
-    constexpr int RPCH = (ROWS_CAP + 8) / 8;
-    constexpr int NC = (RPCH + ELEMS / 8 + BS - 1) / BS;
-    constexpr int NK = (ROWS_CAP + BS - 1) / BS;
-    __shared__ __attribute__((aligned(16))) uint32_t s_col[ELEMS + 8];
-    __shared__ __attribute__((aligned(16))) uint32_t s_rp[RPCH * 8];
-    __shared__ __attribute__((aligned(16))) double s_mu[WIN + 2];          // [WIN] stays 0.0: what pad slots read
-    __shared__ uint32_t s_k[HAS_K ? ROWS_CAP : 1];
-    __shared__ uint32_t s_w[MEASURE ? 1 : WIN + 2];                        // scale words; [WIN] dead
-    // REP replicas of the accumulators, lane l adds to replica l % REP: LDS atomics to one address retire one per two
-    // clocks (tools/lds_atomic_bench.hip), and the abundance skew inside a window sends many lanes to the same transcript
-    constexpr int AST = WIN + 2;                                           // entries per replica
-    __shared__ uint64_t s_hi[MEASURE ? 1 : REP * AST], s_lo[MEASURE ? 1 : REP * AST];
-    const uint32_t rep_off = MEASURE ? 0u : (uint32_t)(tid % REP) * (uint32_t)(AST * 8);
-    __shared__ int32_t s_xe[MEASURE ? WIN + 2 : 1];
-    __shared__ uint64_t s_ll[3];
-
-    const uint64_t t_begin = chunk_tile[blockIdx.x], t_end = chunk_tile[blockIdx.x + 1];
-    if (t_begin >= t_end) return;
-    const uint64_t nt = t_end - t_begin;
-    const S16Tile *__restrict__ T = tiles + t_begin;
-
-    if (tid < 3) s_ll[tid] = 0;
-    for (int i = tid; i < WIN + 2; i += BS) {
-        if (MEASURE) s_xe[i] = INT32_MIN;
-        else { for (int r = 0; r < REP; ++r) { s_hi[r * AST + i] = 0; s_lo[r * AST + i] = 0; } }
-    }
-    if (tid < 2) { s_mu[WIN + tid] = 0.0; if (!MEASURE) s_w[WIN + tid] = EM_WORD_DEAD; }
-
-    auto flush_window = [&](uint32_t base) {
-        for (int i = tid; i < WIN; i += BS) {
-            if (MEASURE) {
-                const int32_t v = s_xe[i];
-                if (v != INT32_MIN) { atomicMax(&a.xe[base + (uint32_t)i], v); s_xe[i] = INT32_MIN; }
-            } else {
-                uint64_t h = 0, l = 0;
-                for (int r = 0; r < REP; ++r) { h += s_hi[r * AST + i]; l += s_lo[r * AST + i]; s_hi[r * AST + i] = 0; s_lo[r * AST + i] = 0; }
-                if (h) atomicAdd((unsigned long long *)&a.hi[base + (uint32_t)i], (unsigned long long)h);
-                if (l) atomicAdd((unsigned long long *)&a.lo[base + (uint32_t)i], (unsigned long long)l);
-            }
-        }
-    };
-    auto load_window = [&](uint32_t base) {
-        for (int i = tid; i < WIN; i += BS) {
-            const uint32_t c = base + (uint32_t)i;
-            s_mu[i] = c < a.n ? a.mu[c] : 0.0;
-            if (!MEASURE) s_w[i] = c < a.n ? a.word[c] : EM_WORD_DEAD;
-        }
-    };
-
-    struct Buf {
-        u32x4 pc[NC];
-        uint32_t pk[HAS_K ? NK : 1];
-    };
-    auto issue = [&](const S16Tile &d, Buf &bf) {
-        if (!(d.flags & S16_FAST)) return; // uniform
-        const uint32_t nch = ((d.nrows + 8) >> 3) + ((d.nnz4 + 7) >> 3);
-        const u32x4 *__restrict__ src = stream16 + d.s16;
-#pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            const uint32_t ch = min((uint32_t)tid + (uint32_t)i * BS, nch - 1);
-            bf.pc[i] = __builtin_nontemporal_load(src + ch);
-        }
-        if (HAS_K) {
-#pragma unroll
-            for (int i = 0; i < NK; ++i) bf.pk[i] = kmult[d.r0 + min((uint32_t)tid + (uint32_t)i * BS, d.nrows - 1)];
-        }
-    };
-    auto commit = [&](const S16Tile &d, const Buf &bf) {
-        const uint32_t rpch = (d.nrows + 8) >> 3, nch = rpch + ((d.nnz4 + 7) >> 3);
-#pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            const uint32_t ch = (uint32_t)tid + (uint32_t)i * BS;
-            const u32x4 v = bf.pc[i];
-            const u32x4 lo = {v.x & 0xffffu, v.x >> 16, v.y & 0xffffu, v.y >> 16};
-            const u32x4 hi = {v.z & 0xffffu, v.z >> 16, v.w & 0xffffu, v.w >> 16};
-            if (ch < rpch) {
-                *(u32x4 *)(s_rp + 8 * ch) = lo;
-                *(u32x4 *)(s_rp + 8 * ch + 4) = hi;
-            } else if (ch < nch) {
-                const uint32_t at = 8 * (ch - rpch);
-                *(u32x4 *)(s_col + at) = lo;
-                *(u32x4 *)(s_col + at + 4) = hi;
-            }
-        }
-        if (HAS_K) {
-#pragma unroll
-            for (int i = 0; i < NK; ++i) {
-                const uint32_t idx = (uint32_t)tid + (uint32_t)i * BS;
-                if (idx < d.nrows) s_k[idx] = bf.pk[i];
-            }
-        }
-    };
-
-    EmAcc acc;
-    auto wo = [&](uint32_t off) { return *(const double *)((const char *)s_mu + off); };
-
-    // The tile ranges here are not the ones K1's window policy was laid out for, so the slide is decided by
-    // comparing bases (S16Tile::wbase is the base in force for that tile), not by the S16_SHIFT flag.
-    auto process = [&](const S16Tile &d, uint32_t &cur_base, const S16Tile &refill, Buf &bf) {
-        if (d.flags & S16_EMPTY) { issue(refill, bf); return; }
-        if (d.wbase != cur_base) { flush_window(cur_base); load_window(d.wbase); cur_base = d.wbase; }
-        if (d.flags & S16_FAST) {
-            commit(d, bf);
-            issue(refill, bf);
-            __syncthreads();
-            for (uint32_t r = tid; r < d.nrows; r += BS) {
-                const uint32_t e0 = s_rp[r], e1 = s_rp[r + 1];
-                const uint32_t b = e0 & ~3u, L4 = (e1 & ~3u) - b;
-                if (L4 == 0) continue;
-                const u32x4 *g = (const u32x4 *)(s_col + b);
-                const uint32_t ng = L4 >> 2;
-                double dsum = 0.0;
-                {
-                    u32x4 o = g[0];
-                    for (uint32_t i = 0; i < ng; ++i) {
-                        const double w0 = wo(o.x), w1 = wo(o.y), w2 = wo(o.z), w3 = wo(o.w);
-                        o = g[i + 1];
-                        dsum += w0; dsum += w1; dsum += w2; dsum += w3;
-                    }
-                }
-                double x;
-                int xe;
-                if (!em_row_head<MEASURE>(dsum, HAS_K ? s_k[r] : 1u, acc, x, xe)) continue;
-                const uint32_t L = L4 - (e0 & 3u);
-                for (uint32_t j = 0; j < L; ++j) {
-                    const uint32_t off = s_col[b + j];
-                    if (MEASURE) {
-                        atomicMax((int32_t *)((char *)s_xe + (off >> 1)), xe);
-                    } else {
-                        uint64_t yh, yl;
-                        if (ABL == 3 && j == 0) continue;
-                        if (em_term(x, xe, *(const uint32_t *)((const char *)s_w + (off >> 1)), acc, yh, yl)) {
-                            if (ABL == 2) { acc.lll ^= yh ^ yl; continue; }
-                            atomicAdd((unsigned long long *)((char *)s_hi + rep_off + off), (unsigned long long)yh);
-                            if (ABL != 1) atomicAdd((unsigned long long *)((char *)s_lo + rep_off + off), (unsigned long long)yl);
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            return;
-        }
-        // slow tile: rows straight from the 32-bit CSR (window where possible)
-        issue(refill, bf);
-        __syncthreads();
-        const uint32_t wbase = d.wbase;
-        for (uint32_t r = tid; r < d.nrows; r += BS) {
-            const uint64_t st = (uint64_t)row_ptr[d.r0 + r];
-            const uint32_t L = (uint32_t)((uint64_t)row_ptr[d.r0 + r + 1] - st);
-            if (L == 0) continue;
-            const uint32_t *cl = col_idx + st;
-            double dsum = 0.0;
-            for (uint32_t j = 0; j < L; ++j) {
-                const uint32_t c = cl[j], dd = c - wbase;
-                dsum += dd < (uint32_t)WIN ? s_mu[dd] : a.mu[c];
-            }
-            double x;
-            int xe;
-            if (!em_row_head<MEASURE>(dsum, HAS_K ? kmult[d.r0 + r] : 1u, acc, x, xe)) continue;
-            for (uint32_t j = 0; j < L; ++j) {
-                const uint32_t c = cl[j], dd = c - wbase;
-                const bool in = dd < (uint32_t)WIN;
-                if (MEASURE) {
-                    if (in) atomicMax(&s_xe[dd], xe);
-                    else atomicMax(&a.xe[c], xe);
-                } else {
-                    uint64_t yh, yl;
-                    if (em_term(x, xe, in ? s_w[dd] : a.word[c], acc, yh, yl)) {
-                        if (in) {
-                            atomicAdd((unsigned long long *)&s_hi[dd], (unsigned long long)yh);
-                            atomicAdd((unsigned long long *)&s_lo[dd], (unsigned long long)yl);
-                        } else {
-                            if (yh) atomicAdd((unsigned long long *)&a.hi[c], (unsigned long long)yh);
-                            if (yl) atomicAdd((unsigned long long *)&a.lo[c], (unsigned long long)yl);
-                        }
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    };
-
-    S16Tile none;
-    none.s16 = 0; none.r0 = 0; none.nrows = 0; none.nnz4 = 0; none.wbase = 0; none.flags = S16_EMPTY;
-    auto tile_at = [&](uint64_t i) { return i < nt ? T[i] : none; };
-
-    S16Tile dA = tile_at(0), dB = tile_at(1);
-    Buf bufA, bufB;
-    issue(dA, bufA);
-    issue(dB, bufB);
-    load_window(dA.wbase);
-    uint32_t cur_base = dA.wbase;
-    for (uint64_t i = 0; i < nt; i += 2) {
-        const S16Tile nA = tile_at(i + 2), nB = tile_at(i + 3);
-        process(dA, cur_base, nA, bufA);
-        if (i + 1 < nt) process(dB, cur_base, nB, bufB);
-        dA = nA;
-        dB = nB;
-    }
-    flush_window(cur_base);
-    if (!MEASURE) em_acc_commit(acc, s_ll, a.ll);
-}
-
-
 // The rows pass on the sliced-ELL 8-bit stream of k_sample_sell: a tile is one wave, every lane holds its row's window
 // indices in registers, nothing is staged through LDS and there are no barriers on the tile path -- which leaves LDS for
 // REP replicas of the accumulators (lane l adds to replica l % REP; same-address LDS atomics retire one per two clocks).
@@ -489,7 +266,7 @@ __global__ __launch_bounds__(64 * W) void k_em_sell(const IdxT *__restrict__ row
     };
     // unconditional, like k_sample_sell::issue (the number of loads per tile must not depend on the path)
     auto issue = [&](const SellTile &d, Buf &bf) {
-        const bool fast = d.flags() & S16_FAST; // uniform
+        const bool fast = d.flags() & SELL_FAST; // uniform
         const uint8_t *__restrict__ blk = stream + (fast ? d.off16 * 16 : 0);
         bf.len = blk[lane];
         if (HAS_K) bf.kk = kmult[(fast ? d.r0 : 0) + min(lane, (fast ? d.nrows() : 1u) - 1u)];
@@ -587,7 +364,7 @@ __global__ __launch_bounds__(64 * W) void k_em_sell(const IdxT *__restrict__ row
     };
 
     SellTile none;
-    none.off16 = 0; none.r0 = 0; none.wbase = 0; none.meta = sell_meta(0, 0, S16_EMPTY);
+    none.off16 = 0; none.r0 = 0; none.wbase = 0; none.meta = sell_meta(0, 0, SELL_EMPTY);
     auto tile_at = [&](uint64_t i) { return i < nt ? T[i] : none; };
     uint32_t cur_base = tile_at(0).wbase;
     uint64_t scan = 0; // tiles of the range already examined for a window slide (by this wave; same sequence in every wave)
@@ -603,11 +380,11 @@ __global__ __launch_bounds__(64 * W) void k_em_sell(const IdxT *__restrict__ row
         if (g < nt) {
             for (; scan <= g; ++scan) {
                 const SellTile q = scan == g ? d : T[scan];
-                if (!(q.flags() & S16_EMPTY) && q.wbase != cur_base) slide_to(q.wbase);
+                if (!(q.flags() & SELL_EMPTY) && q.wbase != cur_base) slide_to(q.wbase);
             }
         }
-        if (d.flags() & S16_EMPTY) { issue(refill, bf); return; }
-        if (d.flags() & S16_FAST) walk(d, bf);
+        if (d.flags() & SELL_EMPTY) { issue(refill, bf); return; }
+        if (d.flags() & SELL_FAST) walk(d, bf);
         else slow_tile(d);
         issue(refill, bf);
     };
@@ -627,7 +404,7 @@ __global__ __launch_bounds__(64 * W) void k_em_sell(const IdxT *__restrict__ row
     }
     for (; scan < nt; ++scan) { // slides after this wave's last tile: the other waves still need them
         const SellTile q = T[scan];
-        if (!(q.flags() & S16_EMPTY) && q.wbase != cur_base) slide_to(q.wbase);
+        if (!(q.flags() & SELL_EMPTY) && q.wbase != cur_base) slide_to(q.wbase);
     }
     __syncthreads();
     flush_window(cur_base);

@@ -14,7 +14,6 @@
 #include <thread>
 #include <mutex>
 #include <condition_variable>
-#include <parallel/algorithm>
 #include <charconv>
 #include <zlib.h>
 
@@ -633,16 +632,14 @@ int main(int argc, char **argv)
     }
 
     stage.mark("write .k .M");
-    // ---- device problem.  Transcripts are numbered in HEADER order, gene by gene, on the device (observed indices are first-seen order,
-    //      src/mmseq.cpp:399-408, which scatters the isoforms of a gene; the sample kernel keeps a window of consecutive
-    //      transcripts in LDS and wants a read's hits close together), rows stably sorted by (wide span last, leading
-    //      transcript, length).
-    //      Both orders are irrelevant to the model; every output stays in the reference's order.
+    // ---- device problem.  Rows go up in first-seen order and observed-transcript numbering, exactly as src/mmseq.cpp:399-418 builds
+    //      them; the library stores the rows in its own canonical order and -- given tx_order -- numbers the transcripts gene by gene
+    //      (header order, the isoforms of a gene adjacent: the sample kernel keeps a window of consecutive transcripts in LDS and
+    //      wants a read's hits close together).  Both orders are irrelevant to the model; every array that comes back is in
+    //      observed-transcript numbering.
     mmg_problem *prob = nullptr;
-    vector<uint32_t> dev_of_obs(n), obs_of_dev(n);
     {
-        // key: (smallest header index of the transcript's gene, own header index) -- header order, with the isoforms of a
-        // gene pulled together wherever the header lists them
+        // key: (smallest header index of the transcript's gene, own header index)
         unordered_map<string, uint32_t> hdr_of_name;
         hdr_of_name.reserve(nHeader * 2);
         for (size_t i = 0; i < nHeader; ++i) hdr_of_name.emplace(transcriptList[i], (uint32_t)i);
@@ -652,62 +649,22 @@ int main(int argc, char **argv)
             for (auto &name : gt.second) { auto it = hdr_of_name.find(name); if (it != hdr_of_name.end()) f = min(f, it->second); }
             gene_first[gt.first] = f;
         }
-        vector<pair<uint64_t, uint32_t>> tkey(n);
+        vector<uint64_t> tx_order(n);
         for (uint32_t t = 0; t < n; ++t) {
             auto tg = transcript2gene.find(sid(t));
             const uint32_t gf = tg == transcript2gene.end() ? obs2hdr[t] : min(gene_first[tg->second], obs2hdr[t]);
-            tkey[t] = {((uint64_t)gf << 32) | obs2hdr[t], t};
+            tx_order[t] = ((uint64_t)gf << 32) | obs2hdr[t];
         }
-        sort(tkey.begin(), tkey.end());
-        for (uint32_t d = 0; d < n; ++d) obs_of_dev[d] = tkey[d].second;
-        for (uint32_t d = 0; d < n; ++d) dev_of_obs[obs_of_dev[d]] = d;
-    }
-    auto to_dev = [&](const vector<double> &v) { vector<double> o(n); for (uint32_t d = 0; d < n; ++d) o[d] = v[obs_of_dev[d]]; return o; };
-    auto to_obs = [&](const vector<double> &v) { vector<double> o(n); for (uint32_t t = 0; t < n; ++t) o[t] = v[dev_of_obs[t]]; return o; };
-    {
-        // rows in device transcript numbering, each sorted ascending
-        vector<uint32_t> dcol(col_idx.size());
-#pragma omp parallel for schedule(static)
-        for (int64_t i = 0; i < (int64_t)m; ++i) {
-            for (uint64_t j = row_ptr[i]; j < row_ptr[i + 1]; ++j) dcol[j] = dev_of_obs[col_idx[j]];
-            sort(dcol.begin() + (ptrdiff_t)row_ptr[i], dcol.begin() + (ptrdiff_t)row_ptr[i + 1]);
-        }
-        // key = (leading transcript + 1 | 0 for an empty row, length), ties by original position: a plain parallel sort of
-        // (key, row) pairs is the stable order
-        vector<pair<uint64_t, uint32_t>> keyed(m);
-#pragma omp parallel for schedule(static)
-        for (int64_t i = 0; i < (int64_t)m; ++i) {
-            const uint64_t L = row_ptr[i + 1] - row_ptr[i];
-            const uint64_t lead = L ? (uint64_t)dcol[row_ptr[i]] + 1 : 0;
-            // rows spanning more transcripts than the LDS window is guaranteed to cover go behind all others, so that
-            // they cannot disqualify the 64-row tiles of their neighbours
-            const uint64_t far = L && dcol[row_ptr[i + 1] - 1] - dcol[row_ptr[i]] >= MMG_ROW_SPAN_HINT ? 1 : 0;
-            keyed[i] = {(far << 63) | (lead << 32) | min<uint64_t>(L, 0xffffffffull), (uint32_t)i};
-        }
-        __gnu_parallel::sort(keyed.begin(), keyed.end());
-        vector<uint32_t> order(m);
-#pragma omp parallel for schedule(static)
-        for (int64_t i = 0; i < (int64_t)m; ++i) order[i] = keyed[i].second;
-        vector<pair<uint64_t, uint32_t>>().swap(keyed);
-        vector<uint64_t> d_rp(m + 1, 0);
-        vector<uint32_t> d_ci(col_idx.size()), d_k(m);
-        for (uint64_t i = 0; i < m; ++i) {
-            const uint32_t r = order[i];
-            const uint64_t L = row_ptr[r + 1] - row_ptr[r];
-            copy(dcol.begin() + (ptrdiff_t)row_ptr[r], dcol.begin() + (ptrdiff_t)row_ptr[r + 1], d_ci.begin() + (ptrdiff_t)d_rp[i]);
-            d_rp[i + 1] = d_rp[i] + L;
-            d_k[i] = k[r];
-        }
-        const vector<double> l_dev = to_dev(l);
         mmg_problem_desc pd;
-        pd.m = m; pd.n = n; pd.row_ptr = d_rp.data(); pd.col_idx = d_ci.data(); pd.k = d_k.data(); pd.l = l_dev.data();
-        pd.row_id_base = 0;
+        memset(&pd, 0, sizeof pd);
+        pd.m = m; pd.n = n; pd.row_ptr = row_ptr.data(); pd.col_idx = col_idx.data(); pd.k = k.data(); pd.l = l.data();
+        pd.row_id_base = 0; pd.layout = MMG_LAYOUT_CANONICAL; pd.tx_order = tx_order.data();
         MMG_TRY(mmg_problem_create(&pd, device, &prob));
         if (stage.on) {
             mmg_problem_info inf;
             MMG_TRY(mmg_problem_info_get(prob, &inf));
-            fprintf(stderr, "[timing] sample kernel %d (2 sliced-ELL stream, 1 16-bit tile stream, 0 CSR tiles), %.1f MB on the device\n",
-                    inf.sample_kernel, inf.device_bytes / 1e6);
+            fprintf(stderr, "[timing] sample kernel %d (2 sliced-ELL stream, 0 CSR tiles), %llu of %llu tiles on the register path, %.1f MB on the device\n",
+                    inf.sample_kernel, (unsigned long long)inf.fast_tiles, (unsigned long long)inf.n_tiles, inf.device_bytes / 1e6);
         }
     }
 
@@ -718,8 +675,7 @@ int main(int argc, char **argv)
     {
         double loglik = 0.0;
         mmg_em *em = nullptr;
-        vector<double> mu_dev = to_dev(mu);
-        MMG_TRY(mmg_em_create(prob, mu_dev.data(), &em, &loglik));
+        MMG_TRY(mmg_em_create(prob, mu.data(), &em, &loglik));
         stage.mark("EM set-up + first pass");
         double llr = epsilon + 1;
         int iter = 0;
@@ -728,7 +684,7 @@ int main(int argc, char **argv)
         while (iter < max_em_iter && llr > epsilon) {
             cout << "EM iteration " << iter << flush;
             if (gz_em) {
-                if (iter) { MMG_TRY(mmg_em_get_mu(em, mu_dev.data())); mu = to_obs(mu_dev); }
+                if (iter) MMG_TRY(mmg_em_get_mu(em, mu.data()));
                 for (uint32_t t = 0; t < n; t++) { gz_em->num(mu[t]); gz_em->str(" "); }
                 gz_em->str("\n");
             }
@@ -739,8 +695,7 @@ int main(int argc, char **argv)
             cout << ", log likelihood ratio: " << llr << "            \r";
             iter++;
         }
-        MMG_TRY(mmg_em_get_mu(em, mu_dev.data()));
-        mu = to_obs(mu_dev);
+        MMG_TRY(mmg_em_get_mu(em, mu.data()));
         mmg_em_destroy(em);
         cout << endl;
         cout.unsetf(ios::floatfield);
@@ -759,8 +714,7 @@ int main(int argc, char **argv)
         cfg.n_chains = 1; cfg.chain_base = 0; cfg.gibbs_iter = gibbs_iter; cfg.trace_len = trace_length;
         cfg.keep_trace = 1; cfg.timing = 0;
         mmg_sampler *smp = nullptr;
-        const vector<double> mu_em_dev = to_dev(mu_em);
-        MMG_TRY(mmg_sampler_create(prob, &cfg, mu_em_dev.data(), &smp));
+        MMG_TRY(mmg_sampler_create(prob, &cfg, mu_em.data(), &smp));
         const int chunk = max(1, gibbs_iter / 16);
         for (int done = 0; done < gibbs_iter; done += chunk) {
             cout << "Gibbs iteration " << done << "       \r" << flush;
@@ -768,13 +722,7 @@ int main(int argc, char **argv)
             MMG_TRY(mmg_sampler_sync(smp));
         }
         cout << "Gibbs iteration " << gibbs_iter - 1 << "       \r" << endl;
-        {
-            vector<double> tr_dev((size_t)n * trace_length);
-            MMG_TRY(mmg_sampler_get_trace(smp, 0, tr_dev.data()));
-#pragma omp parallel for schedule(static)
-            for (int64_t t = 0; t < (int64_t)n; ++t)
-                memcpy(&mu_trace[(size_t)t * trace_length], &tr_dev[(size_t)dev_of_obs[t] * trace_length], (size_t)trace_length * sizeof(double));
-        }
+        MMG_TRY(mmg_sampler_get_trace(smp, 0, mu_trace.data()));
         mmg_sampler_destroy(smp);
     }
     mmg_problem_destroy(prob);

@@ -1,0 +1,242 @@
+// layout.hip -- device TU: the canonical row order of a problem (spec: mmg_types.h; restated in oracle/host_oracle.py).
+//
+// The reference keeps rows in first-seen order (src/mmseq.cpp:409-418), which is an accident of the input file: the model treats
+// rows as exchangeable.  The library sorts them by (near/far, leading-transcript band, multiplicity class, length, content hash),
+// stably, with rocPRIM radix sorts on the device, so that (a) a 64-row tile of the sliced-ELL stream touches one LDS window and
+// holds rows of equal length, and (b) the stored order -- and with it the per-row random streams -- is a function of the SET of
+// rows, not of the order the caller read them in.
+#include <cstring>
+#include <algorithm>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+#include "mmg_launch.h"
+
+namespace mmg {
+
+__global__ __launch_bounds__(256) void k_row_keys(uint64_t m, const uint64_t *__restrict__ rp, const uint32_t *__restrict__ col,
+                                                  const uint32_t *__restrict__ k, uint64_t *__restrict__ key,
+                                                  uint64_t *__restrict__ hash, uint32_t *__restrict__ len)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= m) return;
+    const uint64_t b = rp[r], e = rp[r + 1];
+    const uint64_t L = e - b;
+    const uint32_t kk = k ? k[r] : 1u;
+    uint64_t h = 0x9E3779B97F4A7C15ull + L + ((uint64_t)kk << 32);
+    uint32_t lo = 0xffffffffu, hi = 0;
+    for (uint64_t j = b; j < e; ++j) {
+        const uint32_t c = col[j];
+        lo = min(lo, c);
+        hi = max(hi, c);
+        h = (h ^ (uint64_t)c) * 0xFF51AFD7ED558CCDull;
+        h ^= h >> 32;
+    }
+    uint64_t kv = 0;
+    if (L) {
+        const uint64_t band = lo >> LAYOUT_BAND_SHIFT;
+        const bool near = L <= 255 && (uint64_t)hi - (band << LAYOUT_BAND_SHIFT) < LAYOUT_NEAR_SPAN;
+        const uint64_t kclass = kk <= 1 ? 0 : (kk <= K_SMALL ? 1 : 2);
+        kv = ((uint64_t)(near ? 0 : 1) << 63) | (band << 18) | (kclass << 16) | (L < 0xffff ? L : 0xffff);
+    }
+    key[r] = kv;
+    if (hash) hash[r] = h;
+    if (len) len[r] = (uint32_t)(L < 0xffffffffull ? L : 0xffffffffull);
+}
+
+__global__ __launch_bounds__(256) void k_iota(uint64_t m, uint32_t *idx)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < m) idx[r] = (uint32_t)r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_gather(uint64_t m, const T *__restrict__ in, const uint32_t *__restrict__ idx, T *__restrict__ out)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < m) out[r] = in[idx[r]];
+}
+
+// stored row r <- caller row idx[r]
+__global__ __launch_bounds__(256) void k_gather_csr(uint64_t m, const uint64_t *__restrict__ rp_old, const uint32_t *__restrict__ col_old,
+                                                    const uint32_t *__restrict__ idx, const uint64_t *__restrict__ rp_new,
+                                                    uint32_t *__restrict__ col_new)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= m) return;
+    const uint64_t s = rp_old[idx[r]], d = rp_new[r], L = rp_new[r + 1] - d;
+    for (uint64_t j = 0; j < L; ++j) col_new[d + j] = col_old[s + j];
+}
+
+__global__ __launch_bounds__(256) void k_segment_starts(uint64_t m, const uint64_t *__restrict__ key, uint64_t cap, uint64_t *out,
+                                                        unsigned long long *count)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= m) return;
+    // an empty row (key 0) belongs to the run around it: it neither starts a run nor ends one
+    bool start = r == 0;
+    if (!start && key[r] != 0) {
+        uint64_t q = r;
+        while (q > 0 && key[q - 1] == 0) --q;
+        start = q == 0 ? false : (key[r] >> 18) != (key[q - 1] >> 18);
+    }
+    if (start) {
+        const unsigned long long at = atomicAdd(count, 1ull);
+        if (at < cap) out[at] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_narrow(uint64_t m1, const uint64_t *__restrict__ in, uint32_t *__restrict__ out)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < m1) out[r] = (uint32_t)in[r];
+}
+
+__global__ __launch_bounds__(256) void k_max_len(uint64_t m, const uint64_t *__restrict__ rp, unsigned int *out)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t L = 0;
+    if (r < m) { const uint64_t d = rp[r + 1] - rp[r]; L = (uint32_t)(d < 0xffffffffull ? d : 0xffffffffull); }
+    for (int off = 32; off > 0; off >>= 1) L = max(L, (uint32_t)__shfl_xor((int)L, off));
+    if ((threadIdx.x & 63) == 0 && L) atomicMax(out, L);
+}
+
+static inline unsigned blocks_of(uint64_t n) { return (unsigned)((n + 255) / 256); }
+
+hipError_t layout_row_keys(uint64_t m, const uint64_t *d_rp, const uint32_t *d_col, const uint32_t *d_k, uint64_t *d_key, hipStream_t s)
+{
+    if (m) hipLaunchKernelGGL(k_row_keys, dim3(blocks_of(m)), dim3(256), 0, s, m, d_rp, d_col, d_k, d_key, (uint64_t *)nullptr, (uint32_t *)nullptr);
+    return hipGetLastError();
+}
+
+hipError_t layout_scan_lens(uint64_t m, const uint32_t *d_len, uint64_t *d_rp, hipStream_t s)
+{
+    // d_rp[i] = sum of d_len[0..i) for i in [0, m]: an exclusive scan over m + 1 inputs whose last one is never read as a term
+    if (m == 0) return hipMemsetAsync(d_rp, 0, sizeof(uint64_t), s);
+    auto it = rocprim::make_transform_iterator(d_len, [] __device__(uint32_t x) { return (uint64_t)x; });
+    size_t tmp = 0;
+    hipError_t e = rocprim::inclusive_scan(nullptr, tmp, it, d_rp + 1, m, rocprim::plus<uint64_t>(), s);
+    if (e != hipSuccess) return e;
+    void *d_tmp = nullptr;
+    if ((e = hipMalloc(&d_tmp, tmp ? tmp : 8)) != hipSuccess) return e;
+    e = rocprim::inclusive_scan(d_tmp, tmp, it, d_rp + 1, m, rocprim::plus<uint64_t>(), s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_rp, 0, sizeof(uint64_t), s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_tmp);
+    return e;
+}
+
+static hipError_t sort_pairs(uint64_t m, uint64_t *k_in, uint64_t *k_out, uint32_t *v_in, uint32_t *v_out, hipStream_t s)
+{
+    size_t tmp = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, k_in, k_out, v_in, v_out, m, 0, 64, s);
+    if (e != hipSuccess) return e;
+    void *d_tmp = nullptr;
+    if ((e = hipMalloc(&d_tmp, tmp ? tmp : 8)) != hipSuccess) return e;
+    e = rocprim::radix_sort_pairs(d_tmp, tmp, k_in, k_out, v_in, v_out, m, 0, 64, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_tmp);
+    return e;
+}
+
+hipError_t layout_canonical_sort(uint64_t m, uint64_t nnz, uint64_t **d_rp, uint32_t **d_col, uint32_t **d_k, uint64_t *d_key,
+                                 size_t col_pad, hipStream_t s)
+{
+    if (m == 0) return hipSuccess;
+    uint64_t *hash = nullptr, *k2 = nullptr, *rp_new = nullptr;
+    uint32_t *len = nullptr, *idx = nullptr, *idx2 = nullptr, *col_new = nullptr, *kk_new = nullptr, *len2 = nullptr;
+    hipError_t e = hipSuccess;
+    auto done = [&](hipError_t rc) {
+        for (void *x : {(void *)hash, (void *)k2, (void *)rp_new, (void *)len, (void *)idx, (void *)idx2, (void *)col_new, (void *)kk_new, (void *)len2})
+            if (x) (void)hipFree(x);
+        return rc;
+    };
+#define L_TRY(expr) do { e = (expr); if (e != hipSuccess) return done(e); } while (0)
+    L_TRY(hipMalloc((void **)&hash, m * 8));
+    L_TRY(hipMalloc((void **)&k2, m * 8));
+    L_TRY(hipMalloc((void **)&len, m * 4));
+    L_TRY(hipMalloc((void **)&idx, m * 4));
+    L_TRY(hipMalloc((void **)&idx2, m * 4));
+    const unsigned g = blocks_of(m);
+    hipLaunchKernelGGL(k_row_keys, dim3(g), dim3(256), 0, s, m, *d_rp, *d_col, d_k ? *d_k : (uint32_t *)nullptr, d_key, hash, len);
+    hipLaunchKernelGGL(k_iota, dim3(g), dim3(256), 0, s, m, idx);
+    L_TRY(hipGetLastError());
+    // least significant first: content hash, then the key; both sorts are stable, so equal (key, hash) keep the caller's order
+    L_TRY(sort_pairs(m, hash, k2, idx, idx2, s));
+    hipLaunchKernelGGL(k_gather<uint64_t>, dim3(g), dim3(256), 0, s, m, (const uint64_t *)d_key, (const uint32_t *)idx2, hash); // hash buffer reused: keys in hash order
+    L_TRY(hipGetLastError());
+    L_TRY(sort_pairs(m, hash, d_key, idx2, idx, s)); // d_key: sorted keys, idx: stored row -> caller row
+    (void)hipFree(hash); hash = nullptr;
+    (void)hipFree(k2); k2 = nullptr;
+    (void)hipFree(idx2); idx2 = nullptr;
+    L_TRY(hipMalloc((void **)&len2, m * 4));
+    hipLaunchKernelGGL(k_gather<uint32_t>, dim3(g), dim3(256), 0, s, m, (const uint32_t *)len, (const uint32_t *)idx, len2);
+    L_TRY(hipGetLastError());
+    L_TRY(hipMalloc((void **)&rp_new, (m + 1) * 8));
+    L_TRY(layout_scan_lens(m, len2, rp_new, s));
+    (void)hipFree(len); len = nullptr;
+    (void)hipFree(len2); len2 = nullptr;
+    L_TRY(hipMalloc((void **)&col_new, (nnz + col_pad) * 4));
+    L_TRY(hipMemsetAsync(col_new + nnz, 0, col_pad * 4, s));
+    hipLaunchKernelGGL(k_gather_csr, dim3(g), dim3(256), 0, s, m, (const uint64_t *)*d_rp, (const uint32_t *)*d_col, (const uint32_t *)idx,
+                       (const uint64_t *)rp_new, col_new);
+    if (d_k && *d_k) {
+        L_TRY(hipMalloc((void **)&kk_new, m * 4));
+        hipLaunchKernelGGL(k_gather<uint32_t>, dim3(g), dim3(256), 0, s, m, (const uint32_t *)*d_k, (const uint32_t *)idx, kk_new);
+    }
+    L_TRY(hipGetLastError());
+    L_TRY(hipStreamSynchronize(s));
+    (void)hipFree(*d_rp); *d_rp = rp_new; rp_new = nullptr;
+    (void)hipFree(*d_col); *d_col = col_new; col_new = nullptr;
+    if (kk_new) { (void)hipFree(*d_k); *d_k = kk_new; kk_new = nullptr; }
+#undef L_TRY
+    return done(hipSuccess);
+}
+
+hipError_t layout_segments(uint64_t m, const uint64_t *d_key, uint64_t max_segments, std::vector<uint64_t> &starts, hipStream_t s)
+{
+    starts.clear();
+    if (m == 0) return hipSuccess;
+    uint64_t *d_out = nullptr;
+    unsigned long long *d_count = nullptr;
+    hipError_t e = hipMalloc((void **)&d_out, (max_segments + 1) * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_count, 8);
+    if (e == hipSuccess) e = hipMemsetAsync(d_count, 0, 8, s);
+    unsigned long long count = 0;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_segment_starts, dim3(blocks_of(m)), dim3(256), 0, s, m, d_key, max_segments, d_out, d_count);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&count, d_count, 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess && count <= max_segments) {
+        starts.resize(count);
+        e = hipMemcpy(starts.data(), d_out, count * 8, hipMemcpyDeviceToHost);
+        std::sort(starts.begin(), starts.end());
+    }
+    if (d_out) (void)hipFree(d_out);
+    if (d_count) (void)hipFree(d_count);
+    return e;
+}
+
+hipError_t layout_narrow_row_ptr(uint64_t m, const uint64_t *d_rp64, uint32_t *d_rp32, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_narrow, dim3(blocks_of(m + 1)), dim3(256), 0, s, m + 1, d_rp64, d_rp32);
+    return hipGetLastError();
+}
+
+hipError_t layout_max_row_len(uint64_t m, const uint64_t *d_rp, uint32_t *max_len, hipStream_t s)
+{
+    *max_len = 0;
+    if (m == 0) return hipSuccess;
+    unsigned int *d = nullptr;
+    hipError_t e = hipMalloc((void **)&d, 4);
+    if (e == hipSuccess) e = hipMemsetAsync(d, 0, 4, s);
+    if (e == hipSuccess) { hipLaunchKernelGGL(k_max_len, dim3(blocks_of(m)), dim3(256), 0, s, m, d_rp, d); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(max_len, d, 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (d) (void)hipFree(d);
+    return e;
+}
+
+} // namespace mmg

@@ -1,0 +1,226 @@
+// misc_kernels.h -- K2 (Gamma redraw + trace capture, src/mmseq.cpp:896-917), trace read-out, start values
+// (src/mmseq.cpp:617-638), the synthetic generator of the benchmark inputs, and the self-test kernels.
+#pragma once
+#include "mmg_types.h"
+#include "mmg_math.h"
+
+namespace mmg {
+
+// K2: one lane per (chain, transcript).  HBM: 28 bytes per lane on kept iterations.
+__global__ __launch_bounds__(256) void k_update(UpdateArgs a)
+{
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t total = (uint64_t)a.n * a.n_chains;
+    if (gid >= total) return;
+    const uint32_t c = (uint32_t)(gid / a.n), t = (uint32_t)(gid % a.n);
+    const int32_t x = a.cnt[gid];
+    a.cnt[gid] = 0;
+    a.cnt_last[gid] = x;
+    // the Gamma stream is keyed by the CALLER's transcript id: the chain does not depend on the device numbering
+    Stream s(a.seed, a.chain_base + c, TAG_GAMMA, (uint64_t)(a.ext_of_int ? a.ext_of_int[t] : t), a.iter);
+    const double m = gamma_unit(s, a.alpha + (double)x) * a.scale[t];
+    a.mu[gid] = m;
+    if (a.sample_idx >= 0) {
+        if (a.trace) a.trace[((uint64_t)c * a.trace_len + (uint32_t)a.sample_idx) * a.n + t] = m;
+        const double lg = dlog(m);
+        a.sum_log[gid] += lg;
+        a.sum_log2[gid] += lg * lg;
+    }
+}
+
+// out[t*S + s] = in[s*n + perm(t)]   (sample-major device trace -> the reference's transcript-major mu_trace, :914)
+__global__ __launch_bounds__(256) void k_transpose(const double *__restrict__ in, double *__restrict__ out, uint32_t n,
+                                                   uint32_t S, const uint32_t *__restrict__ int_of_ext)
+{
+    __shared__ double tile[32][33];
+    const uint32_t t0 = blockIdx.x * 32, s0 = blockIdx.y * 32;
+    const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
+    const uint32_t tt = t0 + tx;
+    const uint32_t src = tt < n ? (int_of_ext ? int_of_ext[tt] : tt) : 0;
+    for (uint32_t i = ty; i < 32; i += 8) {
+        const uint32_t s = s0 + i;
+        if (s < S && tt < n) tile[i][tx] = in[(uint64_t)s * n + src];
+    }
+    __syncthreads();
+    for (uint32_t i = ty; i < 32; i += 8) {
+        const uint32_t t = t0 + i, s = s0 + tx;
+        if (s < S && t < n) out[(uint64_t)t * S + s] = tile[tx][i];
+    }
+}
+
+// out[r*n + t] = in[r*n + perm(t)]
+template <typename T>
+__global__ __launch_bounds__(256) void k_gather_rows(const T *__restrict__ in, T *__restrict__ out, uint32_t n, uint32_t rows,
+                                                     const uint32_t *__restrict__ int_of_ext)
+{
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (uint64_t)n * rows) return;
+    const uint32_t r = (uint32_t)(gid / n), t = (uint32_t)(gid % n);
+    out[gid] = in[(uint64_t)r * n + (int_of_ext ? int_of_ext[t] : t)];
+}
+
+// ---------------------------------------------------------------- start values (src/mmseq.cpp:617-638)
+// mu0[t] = (sum over rows i containing t of k_i / |row i|) / l[t].  The reference adds the shares in row order; here every
+// share q = (double)k / (double)L is turned into the integer floor(q * 2^52) (< 2^85) and added as three 32-bit limbs with
+// integer atomics, so the sum is exact, independent of the order of addition, and equal to the oracle's bit for bit.
+__host__ __device__ __forceinline__ void start_share_limbs(uint32_t kk, uint32_t L, uint64_t &a0, uint64_t &a1, uint64_t &a2)
+{
+    const double q = (double)kk / (double)L;           // 2^-32 <= q < 2^32
+    const uint64_t b = bits_of(q);
+    const int e = (int)((b >> 52) & 0x7ff) - 1023;     // ilogb(q) in [-32, 31]; q is normal
+    const uint64_t m = (b & 0xfffffffffffffull) | (1ull << 52);
+    uint64_t lo, hi;                                   // floor(q * 2^52) = m * 2^e
+    if (e >= 0) { lo = m << e; hi = e ? m >> (64 - e) : 0; }
+    else { lo = m >> (-e); hi = 0; }
+    a0 = lo & 0xffffffffull; a1 = lo >> 32; a2 = hi;
+}
+
+template <typename IdxT>
+__global__ __launch_bounds__(256) void k_start_values(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
+                                                      const uint32_t *__restrict__ k, uint64_t m, uint32_t n, uint64_t *acc /* [3][n] */,
+                                                      int32_t *unique_hits)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= m) return;
+    const uint64_t b = row_ptr[r], e = row_ptr[r + 1];
+    const uint32_t L = (uint32_t)(e - b);
+    if (L == 0) return;
+    const uint32_t kk = k ? k[r] : 1u;
+    if (kk == 0) return;
+    uint64_t a0, a1, a2;
+    start_share_limbs(kk, L, a0, a1, a2);
+    for (uint64_t j = b; j < e; ++j) {
+        const uint32_t t = col_idx[j];
+        if (a0) atomicAdd((unsigned long long *)&acc[t], (unsigned long long)a0);
+        if (a1) atomicAdd((unsigned long long *)&acc[(size_t)n + t], (unsigned long long)a1);
+        if (a2) atomicAdd((unsigned long long *)&acc[2 * (size_t)n + t], (unsigned long long)a2);
+    }
+    if (L == 1) atomicAdd(&unique_hits[col_idx[b]], (int32_t)kk);
+}
+
+// ---------------------------------------------------------------- synthetic generator
+// Row r is a pure function of (seed, row0 + r): length 1 + Poisson(avg - 1) clipped to [1, 100]; the first transcript follows
+// the abundance table, the others are distinct members of a 129-wide index window around it (uniform: of all transcripts).
+// far_fraction > 0: a row of >= 2 hits is "far" with that probability; its last drawn hit is then a transcript anywhere in
+// [0, n) outside the window (a read that also hits a paralogue).
+__host__ __device__ __forceinline__ uint32_t synth_len_from_u(const double *len_cdf, double u)
+{
+    uint32_t j = 0;
+    while (j < 99 && !(u < len_cdf[j])) ++j;
+    return 1 + j;
+}
+
+__device__ __forceinline__ uint32_t synth_first(const SynthArgs &a, double ub)
+{
+    const uint32_t T = a.n;
+    const double target = ub * a.cdf[T - 1];
+    uint32_t lo = 0, hi = T - 1;
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (target < a.cdf[mid]) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void k_synth_len(SynthArgs a, uint32_t *lens)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.rows) return;
+    Stream s(a.seed, 0, TAG_SYNTH_ROW, a.row0 + r, 0);
+    double ua, ub;
+    s.pair(ua, ub);
+    uint32_t L = synth_len_from_u(a.len_cdf, ua);
+    if (L > a.n) L = a.n;
+    lens[r] = L;
+}
+
+__global__ __launch_bounds__(256) void k_synth_fill(SynthArgs a, double far_fraction, const uint64_t *__restrict__ row_ptr,
+                                                    uint32_t *col_idx)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.rows) return;
+    Stream s(a.seed, 0, TAG_SYNTH_ROW, a.row0 + r, 0);
+    double ua, ub;
+    s.pair(ua, ub);
+    uint32_t L = synth_len_from_u(a.len_cdf, ua);
+    const uint32_t T = a.n;
+    if (L > T) L = T;
+    uint32_t *cols = col_idx + row_ptr[r];
+    const uint32_t t0 = synth_first(a, ub);
+    cols[0] = t0;
+    if (L <= 1) return;
+    const uint32_t W = a.uniform ? T : (T < 129u ? T : 129u);
+    uint32_t wb = 0;
+    if (!a.uniform) {
+        int64_t b = (int64_t)t0 - 64;
+        if (b < 0) b = 0;
+        if (b + (int64_t)W > (int64_t)T) b = (int64_t)T - (int64_t)W;
+        wb = (uint32_t)b;
+    }
+    const uint32_t nslots = W - 1;
+    uint32_t Wp = 1;
+    while (Wp < nslots) Wp <<= 1;
+    double uc, ud;
+    s.pair(uc, ud);
+    const uint32_t start = (uint32_t)(uc * (double)Wp);
+    const uint32_t stride = ((uint32_t)(ud * (double)(Wp / 2 ? Wp / 2 : 1)) << 1) | 1u;
+    bool far = false;
+    uint32_t tfar = 0;
+    if (far_fraction > 0.0 && !a.uniform && T > 2u * W) {
+        double ue, uf;
+        s.pair(ue, uf);
+        far = ue < far_fraction;
+        tfar = (uint32_t)(uf * (double)T);
+        if (tfar >= T) tfar = T - 1;
+        if (tfar >= wb && tfar < wb + W) tfar = (tfar + W) % T; // outside the window, hence distinct from every other hit
+    }
+    uint32_t got = 1, pos = start & (Wp - 1);
+    while (got < L) {
+        if (pos < nslots) {
+            uint32_t t = wb + pos;
+            if (t >= t0) t += 1;
+            if (far && got == L - 1) t = tfar;
+            // insertion into the sorted prefix (rows ascend, src/mmseq.cpp:412)
+            uint32_t j = got;
+            while (j > 0 && cols[j - 1] > t) { cols[j] = cols[j - 1]; --j; }
+            cols[j] = t;
+            ++got;
+        }
+        pos = (pos + stride) & (Wp - 1);
+    }
+}
+
+// ---------------------------------------------------------------- self-test kernels
+__global__ void k_selftest_math(int64_t n, const double *x, double *ol, double *oe, double *os, double *orc)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ol[i] = dlog(x[i]);
+    oe[i] = dexp(x[i]);
+    os[i] = dsqrt(x[i]);
+    orc[i] = 1.0 / x[i];
+}
+__global__ void k_selftest_philox(const uint32_t *ctr, const uint32_t *key, uint32_t *out)
+{
+    const U4 r = philox4x32_10(U4{ctr[0], ctr[1], ctr[2], ctr[3]}, key[0], key[1]);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+    uint32_t a = ctr[0], b = ctr[1];
+    philox2x32_10(a, b, key[0]);
+    out[4] = a; out[5] = b;
+}
+__global__ void k_selftest_gamma(uint64_t seed, double shape, double scale, int64_t n, double *out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Stream s(seed, 0, TAG_GAMMA, (uint64_t)i, 0);
+    out[i] = gamma_unit(s, shape) * scale;
+}
+__global__ void k_selftest_binomial(uint64_t seed, uint32_t nn, double p, int64_t n, uint32_t *out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Stream2 q(seed, 0, TAG_ROW, (uint64_t)i, 0);
+    out[i] = binomial(q, nn, p);
+}
+
+} // namespace mmg

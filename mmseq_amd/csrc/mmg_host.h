@@ -1,0 +1,81 @@
+// mmg_host.h -- shared by the host translation units of libmmgibbs (mmgibbs.hip, sampler.hip, em_host.hip, post_host.hip):
+// the problem handle, error plumbing, caller <-> device transcript numbering.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/mmgibbs.h"
+#include "mmg_types.h"
+
+struct mmg_problem {
+    int device = 0;
+    uint64_t m = 0, nnz = 0, total_k = 0, row_id_base = 0, device_bytes = 0;
+    uint32_t n = 0, max_row_len = 0;
+    bool idx64 = false;
+    int cu_count = 256;
+    int layout = MMG_LAYOUT_CANONICAL;
+    void *d_row_ptr = nullptr;
+    uint32_t *d_col = nullptr;
+    uint32_t *d_k = nullptr;
+    double *d_l = nullptr;                      // device numbering
+    std::vector<double> h_l;                    // caller numbering
+    // transcript renumbering (tx_order): empty / nullptr = identity
+    std::vector<uint32_t> h_int_of_ext, h_ext_of_int;
+    uint32_t *d_int_of_ext = nullptr, *d_ext_of_int = nullptr;
+    // sliced-ELL stream of k_sample_sell / k_em_sell
+    uint8_t *d_sell = nullptr;
+    uint64_t sell_bytes = 0, n_sell_tiles = 0, n_fast_tiles = 0, padded_slots = 0;
+    mmg::SellTile *d_sell_tiles = nullptr;
+    uint64_t *d_sell_chunk = nullptr;
+    int grid_sell = 0;
+    bool use_sell = false;
+    std::vector<uint64_t> h_sell_cum;           // cumulative tile cost, kept for the EM kernel's own ranges
+    // CSR tiles of the fallback kernel k_sample (built only when the sliced-ELL stream is not used)
+    mmg::TileDesc *d_tiles = nullptr;
+    uint64_t n_tiles = 0;
+    uint64_t *d_chunk_tile = nullptr;
+    int grid_sample = 1;
+    uint64_t *d_colcnt = nullptr;               // hits per transcript, for the EM scale words (lazy)
+    bool renumbered() const { return !h_int_of_ext.empty(); }
+};
+
+namespace mmg {
+
+int fail(int code, const std::string &msg);   // records the thread-local message behind mmg_last_error(), returns code
+int opt(int option);                          // mmg_selftest_option value, -1 = default
+int require_device(int device);
+void weighted_chunks(const std::vector<uint64_t> &cum, uint64_t grid, std::vector<uint64_t> &chunk);
+
+#define HIP_TRY(expr)                                                                                         \
+    do {                                                                                                      \
+        hipError_t _e = (expr);                                                                               \
+        if (_e != hipSuccess)                                                                                 \
+            return mmg::fail(MMG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+    } while (0)
+
+// caller numbering <-> device numbering of per-transcript host arrays
+template <typename T>
+inline void to_int(const mmg_problem *p, const T *ext, std::vector<T> &out)
+{
+    out.resize(p->n);
+    if (p->renumbered()) for (uint32_t i = 0; i < p->n; ++i) out[i] = ext[p->h_ext_of_int[i]];
+    else std::memcpy(out.data(), ext, p->n * sizeof(T));
+}
+template <typename T>
+inline void to_ext(const mmg_problem *p, const std::vector<T> &in, T *ext)
+{
+    if (p->renumbered()) for (uint32_t t = 0; t < p->n; ++t) ext[t] = in[p->h_int_of_ext[t]];
+    else std::memcpy(ext, in.data(), p->n * sizeof(T));
+}
+template <typename T>
+inline int download_ext(const mmg_problem *p, const T *d_src, T *ext)
+{
+    if (!p->renumbered()) { HIP_TRY(hipMemcpy(ext, d_src, p->n * sizeof(T), hipMemcpyDeviceToHost)); return MMG_OK; }
+    std::vector<T> tmp(p->n);
+    HIP_TRY(hipMemcpy(tmp.data(), d_src, p->n * sizeof(T), hipMemcpyDeviceToHost));
+    to_ext(p, tmp, ext);
+    return MMG_OK;
+}
+
+} // namespace mmg

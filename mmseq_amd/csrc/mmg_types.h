@@ -1,0 +1,111 @@
+// mmg_types.h -- plain structs and constants shared by the kernels (device TUs) and the host side of the C ABI.
+// No device code here: mmgibbs.hip fills these and hands them to the launchers declared in mmg_launch.h.
+#pragma once
+#include <stdint.h>
+#include "../../include/mmgibbs.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define MMG_TYPES_HD __host__ __device__
+#else
+#define MMG_TYPES_HD
+#endif
+
+namespace mmg {
+
+constexpr uint32_t K_SMALL = MMG_K_SMALL;   // rows with k <= K_SMALL draw k categoricals; above, a conditional-binomial chain
+
+// ---- canonical layout (restated in oracle/host_oracle.py:canonical_layout) -----------------------
+// Rows are exchangeable in the model (src/mmseq.cpp:857-891 visits them in file order only because that is how they were
+// read); the library stores them sorted by row_key, ties by row_hash, then by the caller's position.
+//   band    = leading transcript >> LAYOUT_BAND_SHIFT         (64 consecutive transcripts)
+//   near    = every hit of the row lies in [band * 64, band * 64 + LAYOUT_NEAR_SPAN) and the row has <= 255 hits
+//   kclass  = 0 (k <= 1), 1 (k <= K_SMALL), 2 (conditional-binomial chain)
+//   key     = !near << 63 | band << 18 | kclass << 16 | min(len, 0xffff)          (an empty row: key 0)
+// A tile of the sliced-ELL stream never crosses a (near, band) boundary, so all its hits fall into ONE 255-wide LDS window
+// starting at band * 64, and its rows have (nearly) equal lengths.
+constexpr uint32_t LAYOUT_BAND_SHIFT = 6;
+constexpr uint32_t LAYOUT_NEAR_SPAN = 240;
+constexpr uint32_t SELL_WIN = 255;          // transcripts per window; slot 255 holds 0.0
+
+// One tile of consecutive rows (k_tile_desc)
+struct TileDesc {
+    uint64_t nz0;   // first hit of the tile in col_idx
+    uint64_t r0;    // first row
+    uint32_t nrows;
+    uint32_t nnz;   // CSR tiles: > tile capacity <=> a single long row handled by the slow path
+    uint32_t cmin;  // leading transcript of the first non-empty row
+    uint32_t clast; // leading transcript of the last non-empty row
+    uint32_t cmax;  // largest transcript id in the tile
+    uint32_t call;  // smallest transcript id in the tile
+    uint32_t nnz4;  // hits when every row is padded to a multiple of 4
+    uint32_t maxlen;// longest row of the tile
+};
+
+// tile flags of the sliced-ELL sample and EM kernels
+enum : uint32_t { SELL_FAST = 1, SELL_EMPTY = 4 };
+
+struct SellTile {
+    uint64_t off16;   // 16-byte-unit offset of the tile's block in the stream
+    uint64_t r0;      // first row
+    uint32_t wbase;   // LDS window base in force while this tile is walked
+    uint32_t meta;    // nrows (<= 64) | ng << 8 (groups of 4 hits stored for every lane: longest row of the tile) | flags << 16
+    MMG_TYPES_HD uint32_t nrows() const { return meta & 0xffu; }
+    MMG_TYPES_HD uint32_t ng() const { return (meta >> 8) & 0xffu; }
+    MMG_TYPES_HD uint32_t flags() const { return meta >> 16; }
+};  // dwords only: the descriptors are fetched with scalar loads
+MMG_TYPES_HD inline uint32_t sell_meta(uint32_t nrows, uint32_t ng, uint32_t flags) { return nrows | (ng << 8) | (flags << 16); }
+
+struct SampleArgs {
+    uint64_t seed;
+    uint64_t row_id_base;
+    uint32_t n;
+    uint32_t chain;
+    uint32_t iter;
+};
+
+struct UpdateArgs {
+    int32_t *cnt;          // [C][n]  read, then zeroed
+    int32_t *cnt_last;     // [C][n]
+    const double *scale;   // n : 1/(beta + l[t])
+    double *mu;            // [C][n]
+    double *trace;         // [C][trace_len][n] or nullptr
+    double *sum_log;       // [C][n]
+    double *sum_log2;      // [C][n]
+    const uint32_t *ext_of_int; // n: the caller's id of device transcript t (keys the Gamma stream), or nullptr = identity
+    uint64_t seed;
+    double alpha;
+    uint32_t n;
+    uint32_t n_chains;
+    uint32_t chain_base;
+    uint32_t iter;
+    int32_t sample_idx;    // >= 0: keep this iteration as trace sample; -1: not kept
+    uint32_t trace_len;
+};
+
+struct EmOut {
+    double loglik;
+    uint64_t flag;
+};
+
+struct EmArgs {
+    uint32_t n;
+    const double *mu;      // n
+    const uint32_t *word;  // n   packed scale words
+    uint64_t *hi, *lo;     // n   accumulators (accumulate pass)
+    int32_t *xe;           // n   max ilogb(x_i) (measure pass)
+    uint64_t *ll;          // [0] LLH  [1] LLL  [2] repeat flag
+};
+
+struct SynthArgs {
+    uint64_t seed, row0, rows;
+    uint32_t n;
+    int32_t uniform;
+    const double *cdf;     // n   inclusive running sum of theta*efflen
+    const double *len_cdf; // 99  Poisson(avg-1) inclusive cdf
+};
+
+// geometry of the CSR fallback kernel k_sample: tiles of <= K1C_ELEMS - 8 hits and <= K1C_ROWS rows
+constexpr int K1C_ELEMS = 2560, K1C_WIN = 256, K1C_UNR = 4, K1C_BS = 128, K1C_ROWS = 128;
+
+} // namespace mmg

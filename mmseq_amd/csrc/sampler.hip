@@ -1,0 +1,346 @@
+// sampler.hip -- host side of the mmg_sampler_* entry points: the Gibbs loop of src/mmseq.cpp:851-918 as a sequence of
+// K1 (sample + scatter) and K2 (Gamma redraw + trace) launches on one stream.
+#include "mmg_host.h"
+#include "mmg_launch.h"
+
+#include <algorithm>
+
+using namespace mmg;
+
+struct mmg_sampler {
+    const mmg_problem *p = nullptr;
+    int device = 0;
+    mmg_config cfg{};
+    hipStream_t own = nullptr, cur = nullptr;
+    double *d_mu = nullptr, *d_scale = nullptr, *d_trace = nullptr, *d_mom = nullptr; // mom: [2][C][n]
+    int32_t *d_cnt = nullptr, *d_cnt_last = nullptr;
+    int iter = 0;          // completed iterations
+    bool sampled = false;  // sample() issued for the current iteration, update() pending
+    int64_t n_kept = 0;
+    // timing
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<std::pair<int, int>> ev_sample, ev_update; // indices into ev_pool
+    size_t ev_used = 0;
+    double acc_sample_ms = 0, acc_update_ms = 0;
+    uint64_t acc_sample_n = 0, acc_update_n = 0;
+};
+
+static void sampler_free(mmg_sampler *s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->own) { (void)hipStreamSynchronize(s->own); }
+    for (auto e : s->ev_pool) (void)hipEventDestroy(e);
+    for (void *x : {(void *)s->d_mu, (void *)s->d_scale, (void *)s->d_trace, (void *)s->d_mom, (void *)s->d_cnt, (void *)s->d_cnt_last})
+        if (x) (void)hipFree(x);
+    if (s->own) (void)hipStreamDestroy(s->own);
+    delete s;
+}
+
+extern "C" int mmg_sampler_create(const mmg_problem *p, const mmg_config *cfg, const double *mu0, mmg_sampler **out)
+{
+    if (!p || !cfg || !mu0 || !out) return fail(MMG_ERR_ARG, "NULL argument");
+    if (cfg->n_chains < 1 || cfg->n_chains > 4096) return fail(MMG_ERR_ARG, "n_chains out of range");
+    if (!(cfg->alpha > 0.0) || !(cfg->beta > 0.0)) return fail(MMG_ERR_ARG, "alpha, beta must be > 0");
+    if (cfg->trace_len < 1 || cfg->gibbs_iter < 1) return fail(MMG_ERR_ARG, "gibbs_iter and trace_len must be >= 1 (src/mmseq.cpp:286)");
+    if (cfg->gibbs_iter % cfg->trace_len != 0) return fail(MMG_ERR_ARG, "gibbs_iter must be a multiple of trace_len (src/mmseq.cpp:278-284)");
+    for (uint32_t t = 0; t < p->n; ++t)
+        if (!(mu0[t] >= 0.0)) return fail(MMG_ERR_ARG, "mu0 must be finite and >= 0");
+    int rc = require_device(p->device);
+    if (rc) return rc;
+    mmg_sampler *s = new mmg_sampler();
+    s->p = p;
+    s->device = p->device;
+    s->cfg = *cfg;
+    const size_t C = (size_t)cfg->n_chains, n = p->n;
+    auto bail = [&](int code) { sampler_free(s); return code; };
+#define S_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return bail(fail(MMG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); } while (0)
+    S_TRY(hipStreamCreateWithFlags(&s->own, hipStreamNonBlocking));
+    s->cur = s->own;
+    S_TRY(hipMalloc((void **)&s->d_mu, C * n * sizeof(double)));
+    S_TRY(hipMalloc((void **)&s->d_scale, n * sizeof(double)));
+    S_TRY(hipMalloc((void **)&s->d_mom, 2 * C * n * sizeof(double)));
+    S_TRY(hipMalloc((void **)&s->d_cnt, C * n * sizeof(int32_t)));
+    S_TRY(hipMalloc((void **)&s->d_cnt_last, C * n * sizeof(int32_t)));
+    if (cfg->keep_trace) S_TRY(hipMalloc((void **)&s->d_trace, C * n * (size_t)cfg->trace_len * sizeof(double)));
+    std::vector<double> scale_ext(n), scale, mu_int;
+    for (size_t t = 0; t < n; ++t) scale_ext[t] = 1.0 / (cfg->beta + p->h_l[t]); // src/mmseq.cpp:907 second argument
+    to_int(p, scale_ext.data(), scale);
+    to_int(p, mu0, mu_int);
+    // every fill goes to the sampler's own stream (non-blocking: not ordered against the NULL stream) and is waited for here
+    S_TRY(hipMemcpyAsync(s->d_scale, scale.data(), n * sizeof(double), hipMemcpyHostToDevice, s->own));
+    for (size_t c = 0; c < C; ++c) S_TRY(hipMemcpyAsync(s->d_mu + c * n, mu_int.data(), n * sizeof(double), hipMemcpyHostToDevice, s->own));
+    S_TRY(hipMemsetAsync(s->d_mom, 0, 2 * C * n * sizeof(double), s->own));
+    S_TRY(hipMemsetAsync(s->d_cnt, 0, C * n * sizeof(int32_t), s->own));
+    S_TRY(hipMemsetAsync(s->d_cnt_last, 0, C * n * sizeof(int32_t), s->own));
+    if (s->d_trace) S_TRY(hipMemsetAsync(s->d_trace, 0, C * n * (size_t)cfg->trace_len * sizeof(double), s->own));
+    S_TRY(hipStreamSynchronize(s->own));
+#undef S_TRY
+    *out = s;
+    return MMG_OK;
+}
+
+extern "C" int mmg_sampler_set_stream(mmg_sampler *s, void *hip_stream)
+{
+    if (!s) return fail(MMG_ERR_ARG, "NULL sampler");
+    s->cur = hip_stream ? (hipStream_t)hip_stream : s->own;
+    return MMG_OK;
+}
+
+static int ev_get(mmg_sampler *s, int &idx)
+{
+    if (s->ev_used == s->ev_pool.size()) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        s->ev_pool.push_back(e);
+    }
+    idx = (int)s->ev_used++;
+    return MMG_OK;
+}
+
+extern "C" int mmg_sampler_sample(mmg_sampler *s)
+{
+    if (!s) return fail(MMG_ERR_ARG, "NULL sampler");
+    if (s->sampled) return fail(MMG_ERR_STATE, "sample() already issued for this iteration; call update()");
+    const mmg_problem *p = s->p;
+    HIP_TRY(hipSetDevice(s->device));
+    int e0 = -1, e1 = -1;
+    const bool timed = s->cfg.timing > 0 && s->iter % s->cfg.timing == 0; // every timing-th iteration: an event pair costs ~9 us of stream time
+    if (timed) {
+        int rc = ev_get(s, e0); if (rc) return rc;
+        rc = ev_get(s, e1); if (rc) return rc;
+        HIP_TRY(hipEventRecord(s->ev_pool[e0], s->cur));
+    }
+    if (p->m > 0) {
+        for (int c = 0; c < s->cfg.n_chains; ++c) {
+            SampleArgs a;
+            a.seed = s->cfg.seed; a.row_id_base = p->row_id_base; a.n = p->n;
+            a.chain = (uint32_t)(s->cfg.chain_base + c);
+            a.iter = (uint32_t)s->iter;
+            const void *rp = p->d_row_ptr;
+            const uint32_t *ci = p->d_col, *kk = p->d_k;
+            const double *mu = s->d_mu + (size_t)c * p->n;
+            int32_t *cnt = s->d_cnt + (size_t)c * p->n;
+            if (p->use_sell) {
+                const SellTile *ts = p->d_sell_tiles;
+                const uint64_t *cs = p->d_sell_chunk;
+                const uint8_t *ss = p->d_sell;
+                void *kargs[] = {(void *)&rp, (void *)&ci, (void *)&kk, (void *)&ts, (void *)&cs, (void *)&mu, (void *)&ss, (void *)&cnt, (void *)&a};
+                HIP_TRY(hipLaunchKernel(k1_sell_kernel(p->idx64, p->d_k != nullptr), dim3(p->grid_sell), dim3(64), kargs, 0, s->cur));
+            } else {
+                const TileDesc *td = p->d_tiles;
+                const uint64_t *ct = p->d_chunk_tile;
+                void *kargs[] = {(void *)&rp, (void *)&ci, (void *)&kk, (void *)&td, (void *)&ct, (void *)&mu, (void *)&cnt, (void *)&a};
+                HIP_TRY(hipLaunchKernel(k1_csr_kernel(p->idx64, p->d_k != nullptr), dim3(p->grid_sample), dim3(K1C_BS), kargs, 0, s->cur));
+            }
+        }
+    }
+    if (timed) {
+        HIP_TRY(hipEventRecord(s->ev_pool[e1], s->cur));
+        s->ev_sample.push_back({e0, e1});
+    }
+    s->sampled = true;
+    return MMG_OK;
+}
+
+extern "C" int mmg_sampler_update(mmg_sampler *s)
+{
+    if (!s) return fail(MMG_ERR_ARG, "NULL sampler");
+    if (!s->sampled) return fail(MMG_ERR_STATE, "update() without a preceding sample()");
+    const mmg_problem *p = s->p;
+    HIP_TRY(hipSetDevice(s->device));
+    const int ss = s->cfg.gibbs_iter / s->cfg.trace_len; // src/mmseq.cpp:284
+    int sample_idx = -1;
+    if (s->iter % ss == 0 && s->iter / ss < s->cfg.trace_len) sample_idx = s->iter / ss; // :911, :914
+    const size_t C = (size_t)s->cfg.n_chains, n = p->n;
+    UpdateArgs a;
+    a.cnt = s->d_cnt; a.cnt_last = s->d_cnt_last; a.scale = s->d_scale; a.mu = s->d_mu; a.trace = s->d_trace;
+    a.sum_log = s->d_mom; a.sum_log2 = s->d_mom + C * n;
+    a.ext_of_int = p->d_ext_of_int;
+    a.seed = s->cfg.seed; a.alpha = s->cfg.alpha; a.n = p->n; a.n_chains = (uint32_t)C;
+    a.chain_base = (uint32_t)s->cfg.chain_base; a.iter = (uint32_t)s->iter; a.sample_idx = sample_idx;
+    a.trace_len = (uint32_t)s->cfg.trace_len;
+    int e0 = -1, e1 = -1;
+    const bool timed = s->cfg.timing > 0 && s->iter % s->cfg.timing == 0;
+    if (timed) {
+        int rc = ev_get(s, e0); if (rc) return rc;
+        rc = ev_get(s, e1); if (rc) return rc;
+        HIP_TRY(hipEventRecord(s->ev_pool[e0], s->cur));
+    }
+    launch_update(a, s->cur);
+    HIP_TRY(hipGetLastError());
+    if (timed) {
+        HIP_TRY(hipEventRecord(s->ev_pool[e1], s->cur));
+        s->ev_update.push_back({e0, e1});
+    }
+    if (sample_idx >= 0) s->n_kept++;
+    s->iter++;
+    s->sampled = false;
+    return MMG_OK;
+}
+
+extern "C" int mmg_sampler_run(mmg_sampler *s, int n_iter)
+{
+    if (!s || n_iter < 0) return fail(MMG_ERR_ARG, "bad argument");
+    for (int i = 0; i < n_iter; ++i) {
+        int rc = mmg_sampler_sample(s);
+        if (rc) return rc;
+        rc = mmg_sampler_update(s);
+        if (rc) return rc;
+    }
+    return MMG_OK;
+}
+
+extern "C" int mmg_sampler_counts_devptr(mmg_sampler *s, void **ptr, uint64_t *count)
+{
+    if (!s || !ptr) return fail(MMG_ERR_ARG, "NULL argument");
+    *ptr = s->d_cnt;
+    if (count) *count = (uint64_t)s->cfg.n_chains * s->p->n;
+    return MMG_OK;
+}
+
+extern "C" int mmg_sampler_moments_devptr(mmg_sampler *s, void **ptr, uint64_t *count)
+{
+    if (!s || !ptr) return fail(MMG_ERR_ARG, "NULL argument");
+    *ptr = s->d_mom;
+    if (count) *count = 2ull * (uint64_t)s->cfg.n_chains * s->p->n;
+    return MMG_OK;
+}
+
+extern "C" int mmg_sampler_sync(mmg_sampler *s)
+{
+    if (!s) return fail(MMG_ERR_ARG, "NULL sampler");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->cur));
+    return MMG_OK;
+}
+
+extern "C" int mmg_sampler_iteration(const mmg_sampler *s, int *iter)
+{
+    if (!s || !iter) return fail(MMG_ERR_ARG, "NULL argument");
+    *iter = s->iter;
+    return MMG_OK;
+}
+
+static int check_chain(const mmg_sampler *s, int chain)
+{
+    if (!s) return fail(MMG_ERR_ARG, "NULL sampler");
+    if (chain < 0 || chain >= s->cfg.n_chains) return fail(MMG_ERR_ARG, "chain index out of range");
+    return MMG_OK;
+}
+
+extern "C" int mmg_sampler_get_trace(mmg_sampler *s, int chain, double *out)
+{
+    int rc = check_chain(s, chain);
+    if (rc) return rc;
+    if (!out) return fail(MMG_ERR_ARG, "NULL out");
+    if (!s->d_trace) return fail(MMG_ERR_STATE, "sampler was created with keep_trace == 0");
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t n = s->p->n, S = (size_t)s->cfg.trace_len;
+    double *d_tmp = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_tmp, n * S * sizeof(double)));
+    launch_transpose(s->d_trace + (size_t)chain * S * n, d_tmp, (uint32_t)n, (uint32_t)S, s->p->d_int_of_ext, s->cur);
+    hipError_t e = hipStreamSynchronize(s->cur);
+    if (e == hipSuccess) e = hipMemcpy(out, d_tmp, n * S * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(d_tmp);
+    if (e != hipSuccess) return fail(MMG_ERR_HIP, std::string("get_trace: ") + hipGetErrorString(e));
+    return MMG_OK;
+}
+
+extern "C" int mmg_sampler_get_trace_rows(mmg_sampler *s, int chain, int first, int count, double *out)
+{
+    int rc = check_chain(s, chain);
+    if (rc) return rc;
+    if (!out || first < 0 || count < 0 || first + count > s->cfg.trace_len) return fail(MMG_ERR_ARG, "bad sample range");
+    if (!s->d_trace) return fail(MMG_ERR_STATE, "sampler was created with keep_trace == 0");
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t n = s->p->n, S = (size_t)s->cfg.trace_len;
+    const double *src = s->d_trace + ((size_t)chain * S + (size_t)first) * n;
+    if (!s->p->renumbered() || count == 0) {
+        HIP_TRY(hipStreamSynchronize(s->cur));
+        HIP_TRY(hipMemcpy(out, src, (size_t)count * n * sizeof(double), hipMemcpyDeviceToHost));
+        return MMG_OK;
+    }
+    double *d_tmp = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_tmp, (size_t)count * n * sizeof(double)));
+    launch_gather_rows(src, d_tmp, (uint32_t)n, (uint32_t)count, 8, s->p->d_int_of_ext, s->cur);
+    hipError_t e = hipStreamSynchronize(s->cur);
+    if (e == hipSuccess) e = hipMemcpy(out, d_tmp, (size_t)count * n * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(d_tmp);
+    if (e != hipSuccess) return fail(MMG_ERR_HIP, std::string("get_trace_rows: ") + hipGetErrorString(e));
+    return MMG_OK;
+}
+
+extern "C" int mmg_sampler_get_mu(mmg_sampler *s, int chain, double *mu)
+{
+    int rc = check_chain(s, chain);
+    if (rc) return rc;
+    if (!mu) return fail(MMG_ERR_ARG, "NULL out");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->cur));
+    return download_ext(s->p, s->d_mu + (size_t)chain * s->p->n, mu);
+}
+
+extern "C" int mmg_sampler_get_counts(mmg_sampler *s, int chain, int32_t *cnt)
+{
+    int rc = check_chain(s, chain);
+    if (rc) return rc;
+    if (!cnt) return fail(MMG_ERR_ARG, "NULL out");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->cur));
+    // between sample() and update() the live counts are the interesting ones
+    const int32_t *src = (s->sampled ? s->d_cnt : s->d_cnt_last) + (size_t)chain * s->p->n;
+    return download_ext(s->p, src, cnt);
+}
+
+extern "C" int mmg_sampler_get_moments(mmg_sampler *s, int chain, double *sum_log, double *sum_log2, int64_t *n_samples)
+{
+    int rc = check_chain(s, chain);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->cur));
+    const size_t C = (size_t)s->cfg.n_chains, n = s->p->n;
+    if (sum_log && (rc = download_ext(s->p, s->d_mom + (size_t)chain * n, sum_log)) != MMG_OK) return rc;
+    if (sum_log2 && (rc = download_ext(s->p, s->d_mom + (C + (size_t)chain) * n, sum_log2)) != MMG_OK) return rc;
+    if (n_samples) *n_samples = s->n_kept;
+    return MMG_OK;
+}
+
+static int drain_events(mmg_sampler *s)
+{
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->cur));
+    for (auto &pr : s->ev_sample) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, s->ev_pool[pr.first], s->ev_pool[pr.second]));
+        s->acc_sample_ms += ms; s->acc_sample_n++;
+    }
+    for (auto &pr : s->ev_update) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, s->ev_pool[pr.first], s->ev_pool[pr.second]));
+        s->acc_update_ms += ms; s->acc_update_n++;
+    }
+    s->ev_sample.clear(); s->ev_update.clear(); s->ev_used = 0;
+    return MMG_OK;
+}
+
+extern "C" int mmg_sampler_get_timing(mmg_sampler *s, mmg_timing *t)
+{
+    if (!s || !t) return fail(MMG_ERR_ARG, "NULL argument");
+    int rc = drain_events(s);
+    if (rc) return rc;
+    t->sample_ms = s->acc_sample_ms; t->update_ms = s->acc_update_ms;
+    t->sample_launches = s->acc_sample_n; t->update_launches = s->acc_update_n;
+    return MMG_OK;
+}
+
+extern "C" int mmg_sampler_reset_timing(mmg_sampler *s)
+{
+    if (!s) return fail(MMG_ERR_ARG, "NULL sampler");
+    int rc = drain_events(s);
+    if (rc) return rc;
+    s->acc_sample_ms = s->acc_update_ms = 0; s->acc_sample_n = s->acc_update_n = 0;
+    return MMG_OK;
+}
+
+extern "C" void mmg_sampler_destroy(mmg_sampler *s) { sampler_free(s); }

@@ -16,20 +16,9 @@
 
 namespace mmg {
 
-struct SellTile {
-    uint64_t off16;   // 16-byte-unit offset of the tile's block in the stream
-    uint64_t r0;      // first row
-    uint32_t wbase;   // LDS window base in force while this tile is walked
-    uint32_t meta;    // nrows (<= 64) | ng << 8 (groups of 4 hits stored for every lane: longest row of the tile) | flags << 16
-    __host__ __device__ uint32_t nrows() const { return meta & 0xffu; }
-    __host__ __device__ uint32_t ng() const { return (meta >> 8) & 0xffu; }
-    __host__ __device__ uint32_t flags() const { return meta >> 16; }
-};  // dwords only: the descriptors are fetched with scalar loads
-__host__ __device__ inline uint32_t sell_meta(uint32_t nrows, uint32_t ng, uint32_t flags) { return nrows | (ng << 8) | (flags << 16); }
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 // Block of a fast tile: 64 length bytes, then ng groups of 64 lanes x 4 u8 window indices (col - wbase), 255 = pad.
-constexpr uint32_t SELL_WIN = 255;   // transcripts per window; slot 255 holds 0.0
 template <typename IdxT>
 __global__ __launch_bounds__(64) void k_encode_sell(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
                                                     const SellTile *__restrict__ tiles, uint64_t n_tiles, uint8_t *stream)
@@ -37,7 +26,7 @@ __global__ __launch_bounds__(64) void k_encode_sell(const IdxT *__restrict__ row
     const uint64_t tile = blockIdx.x;
     if (tile >= n_tiles) return;
     const SellTile d = tiles[tile];
-    if (!(d.flags() & S16_FAST)) return;
+    if (!(d.flags() & SELL_FAST)) return;
     uint8_t *blk = stream + d.off16 * 16;
     const uint32_t lane = threadIdx.x;
     uint64_t b = 0;
@@ -116,7 +105,7 @@ __global__ __launch_bounds__(64) void k_sample_sell(const IdxT *__restrict__ row
     // Loads retire in order and are waited for by count, so the number issued per tile must not depend on the path --
     // otherwise the compiler has to assume the fewest, and every walk waits for the prefetch issued just before it.
     auto issue = [&](const SellTile &d, Buf &bf) {
-        const bool fast = d.flags() & S16_FAST; // uniform
+        const bool fast = d.flags() & SELL_FAST; // uniform
         const uint8_t *__restrict__ blk = stream + (fast ? d.off16 * 16 : 0);
         bf.len = blk[lane];
         if (HAS_K) bf.kk = kmult[(fast ? d.r0 : 0) + min(lane, (fast ? d.nrows() : 1u) - 1u)];
@@ -248,7 +237,7 @@ __global__ __launch_bounds__(64) void k_sample_sell(const IdxT *__restrict__ row
     };
 
     auto process = [&](const SellTile &d, uint32_t &cur_base, const SellTile &refill, Buf &bf) {
-        if (d.flags() & S16_EMPTY) { issue(refill, bf); return; }
+        if (d.flags() & SELL_EMPTY) { issue(refill, bf); return; }
         if (d.wbase != cur_base) {
             __syncthreads();
             flush_window(cur_base);
@@ -256,13 +245,13 @@ __global__ __launch_bounds__(64) void k_sample_sell(const IdxT *__restrict__ row
             cur_base = d.wbase;
             __syncthreads();
         }
-        if (d.flags() & S16_FAST) walk(d, bf);
+        if (d.flags() & SELL_FAST) walk(d, bf);
         else slow_tile(d);
         issue(refill, bf); // the registers are free again only now: tile i+2 travels while tile i+1 is walked
     };
 
     SellTile none;
-    none.off16 = 0; none.r0 = 0; none.wbase = 0; none.meta = sell_meta(0, 0, S16_EMPTY);
+    none.off16 = 0; none.r0 = 0; none.wbase = 0; none.meta = sell_meta(0, 0, SELL_EMPTY);
     auto tile_at = [&](uint64_t i) { return i < nt ? T[i] : none; };
 
     SellTile dA = tile_at(0), dB = tile_at(1);

@@ -30,26 +30,32 @@ class Problem:
         self._lib = _lib.load()
 
     @classmethod
-    def from_csr(cls, row_ptr, col_idx, l, k=None, row_id_base=0, device=0):
+    def from_csr(cls, row_ptr, col_idx, l, k=None, row_id_base=0, device=0, keep_rows=False, tx_order=None):
+        """keep_rows: MMG_LAYOUT_KEEP_ROWS (default: the library's canonical row order); tx_order: n uint64 keys, the
+        device numbers transcripts by ascending (key, index) -- every array crossing this class stays in the caller's."""
         lib = _lib.load()
         row_ptr = np.ascontiguousarray(row_ptr, np.uint64)
         col_idx = np.ascontiguousarray(col_idx, np.uint32)
         l = np.ascontiguousarray(l, np.float64)
         k = None if k is None else np.ascontiguousarray(k, np.uint32)
+        tx_order = None if tx_order is None else np.ascontiguousarray(tx_order, np.uint64)
         if row_ptr.size < 1:
             raise ValueError("row_ptr needs m+1 >= 1 entries")
         if k is not None and k.size != row_ptr.size - 1:
             raise ValueError("k must have one entry per row")
-        d = ProblemDesc(row_ptr.size - 1, l.size, _ptr(row_ptr), _ptr(col_idx), _ptr(k), _ptr(l), row_id_base)
+        if tx_order is not None and tx_order.size != l.size:
+            raise ValueError("tx_order must have one key per transcript")
+        d = ProblemDesc(row_ptr.size - 1, l.size, _ptr(row_ptr), _ptr(col_idx), _ptr(k), _ptr(l), row_id_base,
+                        _lib.LAYOUT_KEEP_ROWS if keep_rows else _lib.LAYOUT_CANONICAL, _ptr(tx_order))
         h = C.c_void_p()
         check(lib.mmg_problem_create(C.byref(d), device, C.byref(h)))
         return cls(h)
 
     @classmethod
     def synthetic(cls, rows, n, avg_hits, seed=1234, row0=0, uniform=False, mapped_reads=0, device=0,
-                  sort=True):
+                  sort=True, far_fraction=0.0):
         lib = _lib.load()
-        d = SynthDesc(seed, rows, row0, n, float(avg_hits), int(uniform), int(sort), mapped_reads)
+        d = SynthDesc(seed, rows, row0, n, float(avg_hits), int(uniform), int(sort), mapped_reads, float(far_fraction))
         h = C.c_void_p()
         check(lib.mmg_problem_create_synthetic(C.byref(d), device, C.byref(h)))
         return cls(h)
@@ -60,12 +66,19 @@ class Problem:
         check(self._lib.mmg_problem_info_get(self._h, C.byref(inf)))
         return inf
 
-    def download(self):
+    def download(self, with_k=False):
+        """The CSR in STORED order (caller's transcript numbering): what a checker replays row by row."""
         inf = self.info
         rp = np.empty(inf.m + 1, np.uint64)
         ci = np.empty(inf.nnz, np.uint32)
-        check(self._lib.mmg_problem_download(self._h, _ptr(rp), _ptr(ci)))
-        return rp, ci
+        k = np.empty(inf.m, np.uint32) if with_k else None
+        check(self._lib.mmg_problem_download(self._h, _ptr(rp), _ptr(ci), _ptr(k)))
+        return (rp, ci, k) if with_k else (rp, ci)
+
+    def tx_perm(self):
+        out = np.empty(self.info.n, np.uint32)
+        check(self._lib.mmg_problem_tx_perm(self._h, _ptr(out)))
+        return out
 
     def l(self):
         out = np.empty(self.info.n, np.float64)
@@ -255,6 +268,33 @@ class Sampler:
 
 
 # ---- self-test hooks -----------------------------------------------------------------------
+def selftest_option(option, value):
+    """Process-wide override of a choice the library normally makes itself (tests only); value < 0 restores the default."""
+    check(_lib.load().mmg_selftest_option(int(option), int(value)))
+
+
+OPT = dict(sample_kernel=_lib.OPT_SAMPLE_KERNEL, force_idx64=_lib.OPT_FORCE_IDX64, sell_waves_per_cu=_lib.OPT_SELL_WAVES_PER_CU,
+           em_kernel=_lib.OPT_EM_KERNEL, em_grid=_lib.OPT_EM_GRID)
+
+
+class options:
+    """with gibbs.options(sample_kernel=0, em_grid=7): ...   -- restores the defaults on exit."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            selftest_option(OPT[k], v)
+        return self
+
+    def __exit__(self, *a):
+        for k in self.kw:
+            selftest_option(OPT[k], -1)
+        return False
+
+
+
 def selftest_math(x, device):
     x = np.ascontiguousarray(x, np.float64)
     outs = [np.empty_like(x) for _ in range(4)]

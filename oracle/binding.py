@@ -60,6 +60,7 @@ def lib():
     L.orc_keyed_binomial_v.argtypes = [C.c_uint64, C.c_uint32, C.c_double, C.c_int64, u32p]
     L.orc_keyed_normal_v.argtypes = [C.c_uint64, C.c_int64, f64p]
     L.orc_start_values.argtypes = [C.c_uint64, C.c_uint32, u64p, u32p, C.c_void_p, f64p, f64p, i32p]
+    L.orc_start_values_exact.argtypes = [C.c_uint64, C.c_uint32, u64p, u32p, C.c_void_p, f64p, f64p]
     L.orc_em.argtypes = [C.c_uint64, C.c_uint32, u64p, u32p, C.c_void_p, f64p, f64p, C.c_int, C.c_double,
                          C.POINTER(C.c_double)]
     L.orc_em.restype = C.c_int
@@ -74,7 +75,7 @@ def lib():
     L.orc_synth_len_cdf.argtypes = [C.c_double, f64p]
     L.orc_synth_row_len.argtypes = [C.c_uint64, C.c_uint64, f64p]
     L.orc_synth_row_len.restype = C.c_uint32
-    L.orc_synth_csr.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, f64p, f64p, C.c_int, u64p,
+    L.orc_synth_csr.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, f64p, f64p, C.c_int, C.c_double, u64p,
                                 C.c_void_p]
     _LIB = L
     return L
@@ -202,6 +203,13 @@ def start_values(p):
     return mu0, uh
 
 
+def start_values_exact(p):
+    """mu0 as the device computes it (mmg_problem_start_values): exact fixed-point sum of the shares, order-independent."""
+    mu0 = np.empty(p.n, np.float64)
+    lib().orc_start_values_exact(p.m, p.n, p.row_ptr, p.col_idx, _kptr(p.k), p.l, mu0)
+    return mu0
+
+
 def em(p, mu, max_iter=1000, epsilon=0.1):
     mu = np.array(mu, np.float64, copy=True)
     ll = C.c_double(0.0)
@@ -260,9 +268,67 @@ def sokal_ref(x):
     return rc, var.value, tau.value, m.value
 
 
+# ----------------------------------------------------------------------------- canonical layout
+# Restates mmseq_amd/csrc/mmg_types.h + layout.hip:k_row_keys: the order in which libmmgibbs stores the rows of a problem.
+LAYOUT_BAND_SHIFT = 6
+LAYOUT_NEAR_SPAN = 240
+K_SMALL = 8
+
+
+def row_keys(row_ptr, col_idx, k=None):
+    """(key, hash) per row: key = !near << 63 | band << 18 | kclass << 16 | min(len, 0xffff) (0 for an empty row);
+    hash = fold of (len, k, hits in stored order)."""
+    rp = np.asarray(row_ptr).astype(np.int64)
+    col = np.asarray(col_idx, np.uint32)
+    L = np.diff(rp)
+    m = L.size
+    kk = np.ones(m, np.uint64) if k is None else np.asarray(k).astype(np.uint64)
+    key = np.zeros(m, np.uint64)
+    ne = L > 0
+    if ne.any():
+        starts = rp[:-1][ne]
+        lo = np.minimum.reduceat(col, starts).astype(np.uint64)
+        hi = np.maximum.reduceat(col, starts).astype(np.uint64)
+        band = lo >> np.uint64(LAYOUT_BAND_SHIFT)
+        Ln = L[ne].astype(np.uint64)
+        near = (Ln <= 255) & (hi - (band << np.uint64(LAYOUT_BAND_SHIFT)) < LAYOUT_NEAR_SPAN)
+        kn = kk[ne]
+        kclass = np.where(kn <= 1, 0, np.where(kn <= K_SMALL, 1, 2)).astype(np.uint64)
+        key[ne] = ((~near).astype(np.uint64) << np.uint64(63)) | (band << np.uint64(18)) | (kclass << np.uint64(16)) | \
+            np.minimum(Ln, 0xffff)
+    with np.errstate(over="ignore"):
+        h = np.uint64(0x9E3779B97F4A7C15) + L.astype(np.uint64) + (kk << np.uint64(32))
+        M = np.uint64(0xFF51AFD7ED558CCD)
+        for j in range(int(L.max()) if m else 0):
+            sel = np.nonzero(L > j)[0]
+            c = col[rp[sel] + j].astype(np.uint64)
+            hj = (h[sel] ^ c) * M
+            h[sel] = hj ^ (hj >> np.uint64(32))
+    return key, h
+
+
+def permute_rows(row_ptr, col_idx, k, perm):
+    rp = np.asarray(row_ptr).astype(np.int64)
+    lens = np.diff(rp)[perm]
+    new_rp = np.zeros(perm.size + 1, np.uint64)
+    new_rp[1:] = np.cumsum(lens)
+    idx = np.repeat(rp[:-1][perm] - new_rp[:-1].astype(np.int64), lens) + np.arange(int(lens.sum()), dtype=np.int64)
+    return new_rp, np.ascontiguousarray(np.asarray(col_idx)[idx]), (None if k is None else np.ascontiguousarray(np.asarray(k)[perm]))
+
+
+def canonical_layout(row_ptr, col_idx, k=None):
+    """Rows in the library's stored order: sorted by (key, hash), ties in the caller's order.  Returns (row_ptr, col_idx, k, perm)
+    with perm[stored row] = caller row."""
+    key, h = row_keys(row_ptr, col_idx, k)
+    perm = np.lexsort((h, key))
+    rp, ci, kk = permute_rows(row_ptr, col_idx, k, perm)
+    return rp, ci, kk, perm
+
+
 # ----------------------------------------------------------------------------- synthetic input
-def synth_problem(R, T, avg_hits, seed=1234, uniform=False, row0=0, mapped_reads=None, sort=True):
-    """Synthetic problem of SURVEY.md App. D: rows [row0,row0+R), k=1. Returns (Problem, efflen)."""
+def synth_problem(R, T, avg_hits, seed=1234, uniform=False, row0=0, mapped_reads=None, sort=True, far_fraction=0.0):
+    """Synthetic problem of SURVEY.md App. D: rows [row0,row0+R), k=1. Returns (Problem, tables).  sort: rows in the library's
+    canonical order (what mmg_problem_create_synthetic stores with sorted = 1); otherwise generator order."""
     L = lib()
     efflen = np.empty(T, np.float64)
     theta = np.empty(T, np.float64)
@@ -271,20 +337,11 @@ def synth_problem(R, T, avg_hits, seed=1234, uniform=False, row0=0, mapped_reads
     len_cdf = np.empty(99, np.float64)
     L.orc_synth_len_cdf(float(avg_hits) - 1.0, len_cdf)
     row_ptr = np.empty(R + 1, np.uint64)
-    L.orc_synth_csr(seed, row0, R, T, cdf, len_cdf, int(uniform), row_ptr, None)
+    L.orc_synth_csr(seed, row0, R, T, cdf, len_cdf, int(uniform), float(far_fraction), row_ptr, None)
     col = np.empty(int(row_ptr[-1]), np.uint32)
-    L.orc_synth_csr(seed, row0, R, T, cdf, len_cdf, int(uniform), row_ptr, col.ctypes.data_as(C.c_void_p))
+    L.orc_synth_csr(seed, row0, R, T, cdf, len_cdf, int(uniform), float(far_fraction), row_ptr, col.ctypes.data_as(C.c_void_p))
     if sort and R > 0:
-        # rows stably ordered by (leading transcript, row length) -- the layout the sample kernel wants
-        lens = np.diff(row_ptr.astype(np.int64))
-        first = col[row_ptr[:-1].astype(np.int64)]
-        perm = np.lexsort((lens, first))
-        new_rp = np.zeros(R + 1, np.uint64)
-        new_rp[1:] = np.cumsum(lens[perm])
-        starts = row_ptr[:-1].astype(np.int64)[perm]
-        idx = np.repeat(starts - new_rp[:-1].astype(np.int64), lens[perm]) + np.arange(col.size, dtype=np.int64)
-        col = np.ascontiguousarray(col[idx])
-        row_ptr = new_rp
+        row_ptr, col, _, _ = canonical_layout(row_ptr, col)
     nreads = R if mapped_reads is None else mapped_reads
     l = efflen * float(nreads) / 1e9  # src/mmseq.cpp:603
     return Problem(row_ptr, col, l), dict(efflen=efflen, theta=theta, cdf=cdf, len_cdf=len_cdf)

@@ -207,17 +207,6 @@ def ingest(h):
                 doublehits=doublehits, mapped=mapped)
 
 
-ROW_SPAN_HINT = 160   # include/mmgibbs.h: MMG_ROW_SPAN_HINT
-
-
-def device_row_order(rows):
-    """The CLI's device layout: rows stably sorted by (wide span last, leading transcript, length); empty rows first."""
-    first = np.array([r[0] if len(r) else -1 for r in rows], np.int64)
-    lens = np.array([len(r) for r in rows], np.int64)
-    far = np.array([1 if len(r) and r[-1] - r[0] >= ROW_SPAN_HINT else 0 for r in rows], np.int64)
-    return np.lexsort((lens, first, far))
-
-
 # ------------------------------------------------------------------------------------ summaries
 def c_round(x):
     return int(math.floor(abs(x) + 0.5)) * (1 if x >= 0 else -1)
@@ -254,7 +243,9 @@ def expected_run(h, alpha=0.1, beta=0.1, seed=1234, gibbs_iter=1024, max_em_iter
     N = g["mapped"]
     sid = g["index_sid"]
     l = np.array([h.efflen[s] * float(N) / 1e9 for s in sid])
-    # device numbering of the transcripts: header order, gene by gene (the CLI's choice, for window locality)
+    # what the CLI hands to mmg_problem_create: rows in first-seen order, tx_order = (first header index of the gene, own header
+    # index).  The library numbers the transcripts by that key and stores the rows in its canonical order (B.canonical_layout on
+    # the renumbered rows); a row's hits are walked in ascending DEVICE id, random streams and sums are keyed by the caller's ids.
     hdr_pos = {name: i for i, name in enumerate(h.names)}
     gene_first, gene_of_t = {}, {}
     for gid, ts in h.genes.items():
@@ -266,11 +257,10 @@ def expected_run(h, alpha=0.1, beta=0.1, seed=1234, gibbs_iter=1024, max_em_iter
     dev_of_obs = np.empty(n, np.int64)
     dev_of_obs[obs_of_dev] = np.arange(n)
     dev_rows = [sorted(int(dev_of_obs[c]) for c in r) for r in rows]
-    order = device_row_order(dev_rows)
-    d_rows = [dev_rows[i] for i in order]
-    rp = np.cumsum([0] + [len(r) for r in d_rows]).astype(np.uint64)
-    ci = np.array([c for r in d_rows for c in r], np.uint32)
-    p = B.Problem(rp, ci, l[obs_of_dev], k=k[order].astype(np.uint32))
+    rp0 = np.cumsum([0] + [len(r) for r in dev_rows]).astype(np.uint64)
+    ci0 = np.array([c for r in dev_rows for c in r], np.uint32)
+    rp, ci_dev, k_st, _ = B.canonical_layout(rp0, ci0, k.astype(np.uint32))
+    p = B.Problem(rp, obs_of_dev[ci_dev.astype(np.int64)].astype(np.uint32), l, k=k_st)
     # start values in FIRST-SEEN row order on the host (deterministic), src/mmseq.cpp:617-638
     mu0 = np.zeros(n)
     uh = np.zeros(n, np.int64)
@@ -280,10 +270,9 @@ def expected_run(h, alpha=0.1, beta=0.1, seed=1234, gibbs_iter=1024, max_em_iter
         if len(r) == 1:
             uh[r[0]] += kk
     mu0 /= l
-    mu_em_dev, em_iters, ll = B.em(p, mu0[obs_of_dev], max_iter=max_em_iter, epsilon=epsilon)
-    chain = B.gibbs_keyed(p, mu_em_dev, alpha=alpha, beta=beta, seed=seed, n_iter=gibbs_iter, trace_len=trace_len)
-    mu_em = mu_em_dev[dev_of_obs]                            # back to the observed (first-seen) order of the outputs
-    trace = chain["trace"][dev_of_obs]                       # [n, trace_len], real scale
+    mu_em, em_iters, ll = B.em(p, mu0, max_iter=max_em_iter, epsilon=epsilon)
+    chain = B.gibbs_keyed(p, mu_em, alpha=alpha, beta=beta, seed=seed, n_iter=gibbs_iter, trace_len=trace_len)
+    trace = chain["trace"]                                   # [n, trace_len], real scale, observed (first-seen) order
     hdr_index = {name: i for i, name in enumerate(h.names)}
     genes = list(h.genes.items())
     # identical / gene sums, simulated traces for isoforms without hits (:927-1008)

@@ -737,6 +737,46 @@ void orc_start_values(uint64_t m, uint32_t n, const uint64_t *row_ptr, const uin
     for (uint32_t t = 0; t < n; ++t) mu0[t] /= l[t];
 }
 
+/* The device's order-independent form of the same start values (mmseq_amd/csrc/misc_kernels.h:k_start_values): every share
+ * q = (double)k / (double)L enters as the integer floor(q * 2^52); the exact integer sum is converted to double with
+ * round-to-nearest-even, scaled by 2^-52 and divided by l[t].  Differs from orc_start_values by rounding only. */
+void orc_start_values_exact(uint64_t m, uint32_t n, const uint64_t *row_ptr, const uint32_t *col_idx,
+                            const uint32_t *k, const double *l, double *mu0)
+{
+    unsigned __int128 *acc = (unsigned __int128 *)calloc(n ? n : 1, sizeof(unsigned __int128));
+    for (uint64_t i = 0; i < m; ++i) {
+        uint64_t b = row_ptr[i], e = row_ptr[i + 1];
+        uint32_t L = (uint32_t)(e - b), ki = k ? k[i] : 1u;
+        if (L == 0 || ki == 0) continue;
+        double q = (double)ki / (double)L;
+        uint64_t bits;
+        memcpy(&bits, &q, 8);
+        int ex = (int)((bits >> 52) & 0x7ff) - 1023;
+        unsigned __int128 mant = (bits & 0xfffffffffffffull) | (1ull << 52);
+        unsigned __int128 T = ex >= 0 ? mant << ex : mant >> (-ex);
+        for (uint64_t j = b; j < e; ++j) acc[col_idx[j]] += T;
+    }
+    for (uint32_t t = 0; t < n; ++t) {
+        unsigned __int128 v = acc[t];
+        double d;
+        if (v == 0) d = 0.0;
+        else {
+            int top = 127;
+            while (!((v >> top) & 1)) --top;
+            if (top <= 52) d = (double)(uint64_t)v;
+            else {
+                int sh = top - 52;
+                uint64_t mant = (uint64_t)(v >> sh);
+                unsigned __int128 rest = v & (((unsigned __int128)1 << sh) - 1), half = (unsigned __int128)1 << (sh - 1);
+                if (rest > half || (rest == half && (mant & 1))) ++mant;
+                d = ldexp((double)mant, sh);
+            }
+        }
+        mu0[t] = d * 0x1p-52 / l[t];
+    }
+    free(acc);
+}
+
 /* src/mmseq.cpp:741-811 in the reference's own summation order (per transcript over rows ascending,
  * log-likelihood over rows then transcripts): EM until llr <= epsilon or max_iter.  mu is updated in
  * place; returns the iteration count.  Kept to pin orc_em (below) to the reference's arithmetic.  Row denominators are cached (same value
@@ -1034,7 +1074,7 @@ uint32_t orc_synth_row_len(uint64_t seed, uint64_t row, const double *len_cdf)
  * distinct members of a 129-wide index window around it, visited by an odd-stride walk;
  * the row is returned sorted ascending (src/mmseq.cpp:412).  Returns the length. */
 uint32_t orc_synth_row(uint64_t seed, uint64_t row, uint32_t T, const double *cdf, const double *len_cdf,
-                       int uniform, uint32_t *cols /* >= 100 */)
+                       int uniform, double far_fraction, uint32_t *cols /* >= 100 */)
 {
     orc_stream s = stream_make(seed, 0, ORC_TAG_SYNTH_ROW, row, 0);
     double ua, ub;
@@ -1064,11 +1104,23 @@ uint32_t orc_synth_row(uint64_t seed, uint64_t row, uint32_t T, const double *cd
         stream_pair(&s, &uc, &ud);
         uint32_t start = (uint32_t)(uc * (double)Wp);
         uint32_t stride = ((uint32_t)(ud * (double)(Wp / 2 ? Wp / 2 : 1)) << 1) | 1u;
+        /* far rows: the last drawn hit becomes a transcript anywhere in [0, T) outside the window */
+        int far = 0;
+        uint32_t tfar = 0;
+        if (far_fraction > 0.0 && !uniform && T > 2u * W) {
+            double ue, uf;
+            stream_pair(&s, &ue, &uf);
+            far = ue < far_fraction;
+            tfar = (uint32_t)(uf * (double)T);
+            if (tfar >= T) tfar = T - 1;
+            if (tfar >= wb && tfar < wb + W) tfar = (tfar + W) % T;
+        }
         uint32_t got = 1, pos = start & (Wp - 1);
         while (got < L) {
             if (pos < nslots) {
                 uint32_t t = wb + pos;
                 if (t >= t0) t += 1; /* skip t0 */
+                if (far && got == L - 1) t = tfar;
                 cols[got++] = t;
             }
             pos = (pos + stride) & (Wp - 1);
@@ -1086,7 +1138,7 @@ uint32_t orc_synth_row(uint64_t seed, uint64_t row, uint32_t T, const double *cd
 /* Whole CSR for rows [row0, row0+R): row_ptr has R+1 entries (row_ptr[0]=0). If
  * col_idx is NULL only row_ptr is filled (sizing pass). */
 void orc_synth_csr(uint64_t seed, uint64_t row0, uint64_t R, uint32_t T, const double *cdf,
-                   const double *len_cdf, int uniform, uint64_t *row_ptr, uint32_t *col_idx)
+                   const double *len_cdf, int uniform, double far_fraction, uint64_t *row_ptr, uint32_t *col_idx)
 {
     row_ptr[0] = 0;
     for (uint64_t r = 0; r < R; ++r) {
@@ -1098,7 +1150,7 @@ void orc_synth_csr(uint64_t seed, uint64_t row0, uint64_t R, uint32_t T, const d
 #pragma omp parallel for schedule(static) if (R > 100000)
     for (int64_t r = 0; r < (int64_t)R; ++r) {
         uint32_t tmp[100];
-        uint32_t L = orc_synth_row(seed, row0 + (uint64_t)r, T, cdf, len_cdf, uniform, tmp);
+        uint32_t L = orc_synth_row(seed, row0 + (uint64_t)r, T, cdf, len_cdf, uniform, far_fraction, tmp);
         memcpy(col_idx + row_ptr[r], tmp, L * sizeof(uint32_t));
     }
 }

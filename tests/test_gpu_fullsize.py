@@ -2,7 +2,7 @@
 config 3/4 (50 M reads x 200 k transcripts, avg 20 hits).  At these sizes the oracle still finishes a few
 sweeps in seconds on the host cores, so the first iterations are compared BIT FOR BIT; beyond that the tests
 use size-independent properties: every read is assigned exactly once, reruns and alternative kernels
-(sliced-ELL stream vs 16-bit tile stream vs 32-bit CSR walk; EM stream kernel vs row-per-thread kernel) give identical bits, the
+(sliced-ELL stream vs 32-bit CSR walk; EM stream kernel vs row-per-thread kernel) give identical bits, the
 EM log-likelihood never decreases."""
 import hashlib
 
@@ -42,16 +42,21 @@ def test_first_sweeps_bit_exact_against_oracle_at_full_size(full, gpu, orc):
     assert np.array_equal(s.counts(0), ref["cnt"])
     assert np.array_equal(s.trace(0), ref["trace"])
     s.close()
-    # unique hits: integer, bit-exact (src/mmseq.cpp:633)
+    # unique hits: integer, bit-exact (src/mmseq.cpp:633); start values: exact fixed-point sums, bit-exact
     _, uh_o = orc.start_values(p)
     assert np.array_equal(uh, uh_o)
+    assert np.array_equal(mu0, orc.start_values_exact(p))
+    inf = prob.info
+    assert inf.sample_kernel == 2 and inf.fast_tiles == inf.n_tiles and inf.layout == 0
+    # length-homogeneous tiles: only the round-up to groups of 4 hits is left (E[4 ceil(L/4)] / E[L]: 1.21 at avg 8 hits, 1.08 at avg 20)
+    assert inf.padded_slots <= (1.25 if name == "cfg2" else 1.10) * inf.nnz
     if name == "cfg2":  # the oracle's EM is sequential: affordable at 40 M hits
         mu_g, it_g, ll_g = prob.em(mu0, max_iter=4, epsilon=-1e308)
         mu_o, it_o, ll_o = orc.em(p, mu0, max_iter=4, epsilon=-1e308)
         assert np.array_equal(mu_g, mu_o) and ll_g == ll_o
 
 
-def test_conservation_and_kernel_independence_at_full_size(full, gpu, monkeypatch):
+def test_conservation_and_kernel_independence_at_full_size(full, gpu):
     name, prob, mu0, uh = full
     R, T, avg = CONFIGS[name]
     n_it = 6
@@ -68,22 +73,19 @@ def test_conservation_and_kernel_independence_at_full_size(full, gpu, monkeypatc
     s.run(n_it)
     assert _digest(s.trace(0), s.counts(0)) == d_stream    # rerun: same bits
     s.close()
-    # the same rows through the other two sample kernels (16-bit tile stream, 32-bit CSR tiles): same bits
+    # the same rows through the other sample kernel (32-bit CSR tiles): same bits
     assert prob.info.sample_kernel == 2
-    monkeypatch.setenv("MMG_K1_SELL", "0")
-    for want in (1, 0):
-        if want == 0:
-            monkeypatch.setenv("MMG_K1_S16", "0")
+    with gpu.options(sample_kernel=0):
         prob2 = gpu.Problem.synthetic(R, T, avg, seed=1234, sort=True)
-        assert prob2.info.sample_kernel == want
-        s = gpu.Sampler(prob2, mu0, seed=77, gibbs_iter=n_it, trace_len=n_it)
-        s.run(n_it)
-        assert _digest(s.trace(0), s.counts(0)) == d_stream
-        s.close()
-        prob2.close()
+    assert prob2.info.sample_kernel == 0
+    s = gpu.Sampler(prob2, mu0, seed=77, gibbs_iter=n_it, trace_len=n_it)
+    s.run(n_it)
+    assert _digest(s.trace(0), s.counts(0)) == d_stream
+    s.close()
+    prob2.close()
 
 
-def test_em_at_full_size(full, gpu, monkeypatch):
+def test_em_at_full_size(full, gpu):
     name, prob, mu0, uh = full
     em = prob.em_stepper(mu0)
     assert em.stats_raw()["stream_kernel"] == 2
@@ -94,22 +96,21 @@ def test_em_at_full_size(full, gpu, monkeypatch):
     assert em.stats()["repeated_passes"] == 0
     mu_stream = em.mu()
     em.close()
-    for env, want in (("1", 1), ("0", 0)):                  # 16-bit tile stream kernel; row-per-thread kernel, global atomics
-        monkeypatch.setenv("MMG_EM_STREAM", env)
+    with gpu.options(em_kernel=0):                          # row-per-thread kernel, global atomics
         em = prob.em_stepper(mu0)
-        assert em.stats_raw()["stream_kernel"] == want
-        lls2 = [em.loglik] + [em.step() for _ in range(8)]
-        assert lls2 == lls and np.array_equal(em.mu(), mu_stream)
-        em.close()
+    assert em.stats_raw()["stream_kernel"] == 0
+    lls2 = [em.loglik] + [em.step() for _ in range(8)]
+    assert lls2 == lls and np.array_equal(em.mu(), mu_stream)
+    em.close()
     # at the EM fixed point sum_t mu_t l_t = number of reads; 8 sweeps from the start value are already close
     tot = float(np.sum(mu_stream * prob.l()))
     assert abs(tot / prob.info.total_k - 1.0) < 1e-9
 
 
-def test_multiplicities_at_config2_size(gpu, orc, monkeypatch):
+def test_multiplicities_at_config2_size(gpu, orc):
     """Config-2 shape with collapsed-hit-set multiplicities (Zipf: half the rows k = 1, 15 % k > 8, up to 10^5): every
     path of the allocation (k categorical draws, conditional-binomial chain) at 5 M rows, bit-exact against the oracle
-    and identical across the three sample kernels."""
+    and identical across the two sample kernels."""
     R, T, avg = CONFIGS["cfg2"]
     base = gpu.Problem.synthetic(R, T, avg, seed=1234, sort=True)
     rp, ci = base.download()
@@ -117,16 +118,16 @@ def test_multiplicities_at_config2_size(gpu, orc, monkeypatch):
     base.close()
     rng = np.random.default_rng(1)
     k = np.minimum(rng.zipf(1.7, size=R), 100000).astype(np.uint32)
-    p = orc.Problem(rp, ci, l, k=k)
     digests = {}
-    for want, env in ((2, {}), (1, {"MMG_K1_SELL": "0"}), (0, {"MMG_K1_SELL": "0", "MMG_K1_S16": "0"})):
-        for key, val in env.items():
-            monkeypatch.setenv(key, val)
-        prob = gpu.Problem.from_csr(rp, ci, l, k=k)
+    for want in (2, 0):
+        with gpu.options(sample_kernel=want):
+            prob = gpu.Problem.from_csr(rp, ci, l, k=k)
         assert prob.info.sample_kernel == want and prob.info.total_k == int(k.astype(np.int64).sum())
         mu0, uh = prob.start_values()
         if want == 2:
             mu_start = mu0
+            d_rp, d_ci, d_k = prob.download(with_k=True)
+            p = orc.Problem(d_rp, d_ci, l, k=d_k)
         s = gpu.Sampler(prob, mu_start, seed=9, gibbs_iter=2, trace_len=2)
         s.run(2)
         digests[want] = _digest(s.trace(0), s.counts(0))
@@ -139,4 +140,4 @@ def test_multiplicities_at_config2_size(gpu, orc, monkeypatch):
             assert np.array_equal(mu_g, mu_o) and ll_g == ll_o
         s.close()
         prob.close()
-    assert digests[2] == digests[1] == digests[0]
+    assert digests[2] == digests[0]

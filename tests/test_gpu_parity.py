@@ -10,16 +10,112 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_unsorted_rows_still_bit_exact(gpu, orc):
-    """Row order only affects speed (LDS window hit rate), never the result."""
+def _dev(gpu, orc, p, **kw):
+    """Uploads oracle problem p; returns (device problem, the oracle's view of it IN STORED ORDER): the library keeps rows in
+    its own canonical order, and a checker replays the chain row by row from mmg_problem_download."""
+    prob = gpu.Problem.from_csr(p.row_ptr, p.col_idx, p.l, k=p.k, **kw)
+    rp, ci, k = prob.download(with_k=True)
+    return prob, orc.Problem(rp, ci, p.l, k=(k if p.k is not None else None))
+
+
+def test_kept_unsorted_rows_still_bit_exact(gpu, orc):
+    """MMG_LAYOUT_KEEP_ROWS with rows in generator order: row order only affects speed (LDS window hit rate), never the result."""
     p, aux = orc.synth_problem(R=40000, T=6000, avg_hits=6, seed=3, sort=False)
     mu0, _ = orc.start_values(p)
-    prob = gpu.Problem.from_csr(p.row_ptr, p.col_idx, p.l)
-    s = gpu.Sampler(prob, mu0, seed=8, gibbs_iter=16, trace_len=16)
-    s.run(16)
-    ref = orc.gibbs_keyed(p, mu0, seed=8, n_iter=16, trace_len=16)
-    assert np.array_equal(s.counts(0), ref["cnt"])
-    assert np.array_equal(s.trace(0), ref["trace"])
+    for kern in (-1, 0):
+        with gpu.options(sample_kernel=kern):
+            prob = gpu.Problem.from_csr(p.row_ptr, p.col_idx, p.l, keep_rows=True)
+            rp, ci = prob.download()
+            assert np.array_equal(rp, p.row_ptr) and np.array_equal(ci, p.col_idx) and prob.info.layout == 1
+            s = gpu.Sampler(prob, mu0, seed=8, gibbs_iter=16, trace_len=16)
+            s.run(16)
+            ref = orc.gibbs_keyed(p, mu0, seed=8, n_iter=16, trace_len=16)
+            assert np.array_equal(s.counts(0), ref["cnt"])
+            assert np.array_equal(s.trace(0), ref["trace"])
+
+
+def test_canonical_layout_is_the_oracles_restatement_and_ignores_the_upload_order(gpu, orc):
+    """mmg_problem_create stores rows sorted by (near/far, band, multiplicity class, length, content hash): the download equals
+    oracle.binding.canonical_layout, and any permutation of the same rows -- the reference's first-seen order
+    (src/mmseq.cpp:409-418) is just one -- yields the same stored problem, hence the same chain."""
+    p, aux = orc.synth_problem(R=30000, T=3000, avg_hits=7, seed=5, sort=False, far_fraction=0.1)
+    rng = np.random.default_rng(1)
+    k = rng.choice([1, 1, 1, 2, 5, 9, 300], size=p.m).astype(np.uint32)
+    rp_c, ci_c, k_c, perm = orc.canonical_layout(p.row_ptr, p.col_idx, k)
+    mu0, _ = orc.start_values(orc.Problem(p.row_ptr, p.col_idx, p.l, k=k))
+    traces = []
+    for trial in range(3):
+        if trial == 0:
+            rp, ci, kk = p.row_ptr, p.col_idx, k
+        else:
+            sh = rng.permutation(p.m)
+            rp, ci, kk = orc.permute_rows(p.row_ptr, p.col_idx, k, sh)
+        prob = gpu.Problem.from_csr(rp, ci, p.l, k=kk)
+        d_rp, d_ci, d_k = prob.download(with_k=True)
+        assert np.array_equal(d_rp, rp_c) and np.array_equal(d_ci, ci_c) and np.array_equal(d_k, k_c)
+        assert prob.info.sample_kernel == 2 and prob.info.layout == 0
+        s = gpu.Sampler(prob, mu0, seed=8, gibbs_iter=8, trace_len=8)
+        s.run(8)
+        traces.append((s.trace(0), s.counts(0)))
+        s.close(); prob.close()
+    for t, c in traces[1:]:
+        assert np.array_equal(t, traces[0][0]) and np.array_equal(c, traces[0][1])
+    ref = orc.gibbs_keyed(orc.Problem(rp_c, ci_c, p.l, k=k_c), mu0, seed=8, n_iter=8, trace_len=8)
+    assert np.array_equal(traces[0][0], ref["trace"]) and np.array_equal(traces[0][1], ref["cnt"])
+
+
+def test_first_seen_numbering_with_tx_order_takes_the_fast_kernel(gpu, orc):
+    """The reference numbers transcripts in first-seen order (src/mmseq.cpp:399-408), which scatters the isoforms of a gene over
+    the index range.  Uploaded like that the rows span the whole range and only the CSR kernel applies; with tx_order (gene
+    ordinal << 32 | ordinal within the gene) the library renumbers internally, runs the sliced-ELL kernel, and every array
+    comes back in the caller's numbering -- the same numbers the oracle produces from the downloaded rows, and the same trace
+    as an upload that did the sorting itself."""
+    p, aux = orc.synth_problem(R=40000, T=4000, avg_hits=6, seed=9, sort=False)
+    rng = np.random.default_rng(4)
+    scat = rng.permutation(p.n).astype(np.uint32)            # caller id of generator transcript g: "first-seen" scatter
+    ci_ext = scat[p.col_idx]
+    rp = p.row_ptr.astype(np.int64)
+    for r in range(p.m):                                     # rows ascend in the CALLER's numbering, as at src/mmseq.cpp:412
+        ci_ext[rp[r]:rp[r + 1]].sort()
+    l_ext = np.empty(p.n); l_ext[scat] = p.l
+    tx_order = np.empty(p.n, np.uint64)
+    tx_order[scat] = (np.arange(p.n, dtype=np.uint64) // np.uint64(7)) << np.uint64(32) | (np.arange(p.n, dtype=np.uint64) % np.uint64(7))
+    plain = gpu.Problem.from_csr(p.row_ptr, ci_ext, l_ext)
+    assert plain.info.sample_kernel == 0 and plain.info.tx_renumbered == 0
+    plain.close()
+    prob = gpu.Problem.from_csr(p.row_ptr, ci_ext, l_ext, tx_order=tx_order)
+    inf = prob.info
+    assert inf.sample_kernel == 2 and inf.tx_renumbered == 1 and inf.fast_tiles == inf.n_tiles
+    int_of_ext = prob.tx_perm()
+    assert np.array_equal(np.argsort(tx_order, kind="stable"), np.argsort(int_of_ext, kind="stable"))
+    d_rp, d_ci = prob.download()
+    pd = orc.Problem(d_rp, d_ci, l_ext)
+    # stored rows walk their hits in ascending DEVICE id and are the canonical order of the renumbered rows
+    ci_int = int_of_ext[ci_ext]
+    for r in range(p.m):
+        ci_int[rp[r]:rp[r + 1]].sort()
+    c_rp, c_ci, _, _ = orc.canonical_layout(p.row_ptr, ci_int)
+    assert np.array_equal(d_rp, c_rp) and np.array_equal(int_of_ext[d_ci], c_ci)
+    assert np.array_equal(prob.l(), l_ext)
+    mu0_g, uh_g = prob.start_values()
+    assert np.array_equal(mu0_g, orc.start_values_exact(pd)) and np.array_equal(uh_g, orc.start_values(pd)[1])
+    em_g, it_g, ll_g = prob.em(mu0_g, max_iter=6, epsilon=-1e308)
+    em_o, it_o, ll_o = orc.em(pd, mu0_g, max_iter=6, epsilon=-1e308)
+    assert np.array_equal(em_g, em_o) and ll_g == ll_o
+    s = gpu.Sampler(prob, em_g, seed=77, n_chains=2, gibbs_iter=24, trace_len=12)
+    s.run(24)
+    for c in range(2):
+        ref = orc.gibbs_keyed(pd, em_g, seed=77, chain=c, n_iter=24, trace_len=12)
+        assert np.array_equal(s.trace(c), ref["trace"]) and np.array_equal(s.counts(c), ref["cnt"])
+        assert np.array_equal(s.mu(c), ref["mu"]) and np.array_equal(s.trace_rows(c).T, ref["trace"])
+        sl, sl2, ns = s.moments(c)
+        assert np.array_equal(sl, ref["sum_log"]) and np.array_equal(sl2, ref["sum_log2"])
+    # an upload that already is in stored order (and says so) runs the same chain
+    pre = gpu.Problem.from_csr(d_rp, d_ci, l_ext, tx_order=tx_order, keep_rows=True)
+    assert pre.info.sample_kernel == 2
+    s2 = gpu.Sampler(pre, em_g, seed=77, gibbs_iter=24, trace_len=12)
+    s2.run(24)
+    assert np.array_equal(s2.trace(0), s.trace(0))
 
 
 def _mk(orc, R, T, avg, seed=1234, **kw):
@@ -67,7 +163,7 @@ def test_device_binomial_bit_exact(gpu, orc, nn, p):
 
 def test_sample_counts_bit_exact_single_sweep(gpu, orc):
     p, mu0, _ = _mk(orc, 50000, 3000, 6)
-    prob = gpu.Problem.from_csr(p.row_ptr, p.col_idx, p.l)
+    prob, p = _dev(gpu, orc, p)
     s = gpu.Sampler(prob, mu0, seed=42, gibbs_iter=4, trace_len=4)
     s.sample()
     cnt = s.counts(0)
@@ -79,19 +175,15 @@ def test_sample_counts_bit_exact_single_sweep(gpu, orc):
     assert np.array_equal(mu1, orc.gamma_update(ref, p.l, 0.1, 0.1, 42, 0, 0))
 
 
-# the three sample kernels: sliced-ELL 8-bit stream (default without multiplicities), 16-bit tile stream, 32-bit CSR tiles
-KERNEL_ENVS = {2: {}, 1: {"MMG_K1_SELL": "0"}, 0: {"MMG_K1_SELL": "0", "MMG_K1_S16": "0"}}
-
-
-@pytest.mark.parametrize("kernel", [2, 1, 0])
+# the two sample kernels: sliced-ELL 8-bit stream (the default), 32-bit CSR tiles (problems whose rows mostly span more than a window)
+@pytest.mark.parametrize("kernel", [2, 0])
 @pytest.mark.parametrize("R,T,avg", [(10000, 1000, 4), (30000, 500, 12), (2000, 4000, 2), (70000, 3000, 30)])
-def test_full_chain_bit_exact(gpu, orc, monkeypatch, R, T, avg, kernel):
-    for k, v in KERNEL_ENVS[kernel].items():
-        monkeypatch.setenv(k, v)
-    p, mu0, _ = _mk(orc, R, T, avg)                      # rows sorted by (leading transcript, length): the fast layout
-    prob = gpu.Problem.from_csr(p.row_ptr, p.col_idx, p.l)
-    got = prob.info.sample_kernel                        # a stream kernel is only chosen when >= 90 % of its tiles qualify
-    assert got <= kernel and (got == kernel or (R, T, avg) not in [(10000, 1000, 4), (70000, 3000, 30)])
+def test_full_chain_bit_exact(gpu, orc, R, T, avg, kernel):
+    p, mu0, _ = _mk(orc, R, T, avg)                      # the generator's rows in canonical order
+    with gpu.options(sample_kernel=kernel):
+        prob, pd = _dev(gpu, orc, p)
+    assert np.array_equal(pd.row_ptr, p.row_ptr) and np.array_equal(pd.col_idx, p.col_idx)   # canonical order is idempotent
+    assert prob.info.sample_kernel == kernel
     s = gpu.Sampler(prob, mu0, seed=1234, gibbs_iter=128, trace_len=64)
     s.run(128)
     ref = orc.gibbs_keyed(p, mu0, seed=1234, n_iter=128, trace_len=64)
@@ -112,7 +204,7 @@ def test_rows_with_multiplicity_bit_exact(gpu, orc):
     k = rng.choice([1, 2, 3, 8, 9, 50, 1000, 20000], size=p.m).astype(np.uint32)
     pk = orc.Problem(p.row_ptr, p.col_idx, p.l * 50, k=k)
     mu0, uh = orc.start_values(pk)
-    prob = gpu.Problem.from_csr(pk.row_ptr, pk.col_idx, pk.l, k=pk.k)
+    prob, pk = _dev(gpu, orc, pk)
     s = gpu.Sampler(prob, mu0, seed=9, gibbs_iter=32, trace_len=32)
     s.run(32)
     ref = orc.gibbs_keyed(pk, mu0, seed=9, n_iter=32, trace_len=32)
@@ -122,7 +214,8 @@ def test_rows_with_multiplicity_bit_exact(gpu, orc):
     assert np.array_equal(s.trace(0), ref["trace"])
 
 
-def test_edge_rows(gpu, orc):
+@pytest.mark.parametrize("keep_rows", [False, True])
+def test_edge_rows(gpu, orc, keep_rows):
     """Empty rows, single-hit rows, a row longer than a tile (> 4096 hits), ragged tail."""
     T = 6000
     rows = [[], [5], [1, 2], list(range(0, 5000)), [7], [], [3, 4, 5], list(range(100, 4300)), [T - 1, ]]
@@ -133,8 +226,10 @@ def test_edge_rows(gpu, orc):
     p = orc.Problem(rp, ci, l, k=k)
     mu0 = np.full(T, 0.25)
     mu0[::7] = 1e-300
-    prob = gpu.Problem.from_csr(rp, ci, l, k=k)
+    prob, p = _dev(gpu, orc, p, keep_rows=keep_rows)
     assert prob.info.max_row_len == 5000
+    if keep_rows:
+        assert np.array_equal(p.row_ptr, rp) and np.array_equal(p.col_idx, ci)
     s = gpu.Sampler(prob, mu0, seed=5, gibbs_iter=16, trace_len=16)
     s.run(16)
     ref = orc.gibbs_keyed(p, mu0, seed=5, n_iter=16, trace_len=16)
@@ -143,14 +238,13 @@ def test_edge_rows(gpu, orc):
     assert int(s.counts(0).sum()) == int(k[[1, 2, 3, 4, 6, 7, 8]].sum())
 
 
+@pytest.mark.parametrize("keep_rows", [True, False])
 @pytest.mark.parametrize("with_k", [False, True])
-def test_sliced_ell_kernel_edge_rows(gpu, orc, monkeypatch, with_k):
+def test_sliced_ell_kernel_edge_rows(gpu, orc, with_k, keep_rows):
     """The sliced-ELL kernel (forced even though few tiles qualify) on the row shapes its format singles out: rows of
     exactly 32 / 33 hits (the register cache holds 8 groups), 255 and 256+ hits (the length byte; longer rows make their
     tile a slow tile), single-hit and empty rows, a window slide inside a workgroup's range, a ragged last tile,
     degenerate weights (all mu of a row zero / infinite) -- bit-exact against the oracle, with and without multiplicities."""
-    monkeypatch.setenv("MMG_K1_SELL", "2")
-    monkeypatch.setenv("MMG_K1_SELL_WAVES_PER_CU", "1")       # few workgroups: long tile ranges, several window slides each
     rng = np.random.default_rng(9)
     T = 40000
     rows = []
@@ -171,8 +265,9 @@ def test_sliced_ell_kernel_edge_rows(gpu, orc, monkeypatch, with_k):
     mu0[::5] = 1e-300
     mu0[2000:2200] = 0.0                                       # rows whose every weight is zero: uniform pick
     mu0[3000:3100] = np.inf                                    # total not finite: uniform pick as well
-    prob = gpu.Problem.from_csr(rp, ci, l, k=k)
-    assert prob.info.sample_kernel == 2
+    with gpu.options(sample_kernel=2, sell_waves_per_cu=1):  # few workgroups: long tile ranges, several window slides each
+        prob, p = _dev(gpu, orc, p, keep_rows=keep_rows)
+    assert prob.info.sample_kernel == 2 and 0 < prob.info.fast_tiles < prob.info.n_tiles
     s = gpu.Sampler(prob, mu0, seed=17, gibbs_iter=12, trace_len=12)
     s.sample()
     ref1 = orc.sample_counts(p, mu0, seed=17, chain=0, it=0)
@@ -197,8 +292,8 @@ def test_chains_and_shards_reproduce_single_chain(gpu, orc):
     # (b) shard rows [0,h) and [h,m) with row_id_base; emulate the int32 all-reduce on the host
     h = p.m // 3
     nz = int(p.row_ptr[h])
-    pa = gpu.Problem.from_csr(p.row_ptr[:h + 1], p.col_idx[:nz], p.l)
-    pb = gpu.Problem.from_csr(p.row_ptr[h:] - p.row_ptr[h], p.col_idx[nz:], p.l, row_id_base=h)
+    pa = gpu.Problem.from_csr(p.row_ptr[:h + 1], p.col_idx[:nz], p.l, keep_rows=True)
+    pb = gpu.Problem.from_csr(p.row_ptr[h:] - p.row_ptr[h], p.col_idx[nz:], p.l, row_id_base=h, keep_rows=True)
     ref = orc.gibbs_keyed(p, mu0, seed=11, chain=0, n_iter=1, trace_len=1)
     sa = gpu.Sampler(pa, mu0, seed=11, gibbs_iter=1, trace_len=1)
     sb = gpu.Sampler(pb, mu0, seed=11, gibbs_iter=1, trace_len=1)
@@ -207,12 +302,13 @@ def test_chains_and_shards_reproduce_single_chain(gpu, orc):
 
 
 def test_device_generator_matches_oracle_generator(gpu, orc):
-    for (R, T, avg, uni, row0, srt) in [(30000, 2000, 8, False, 0, True), (5000, 300, 20, False, 12345, True),
-                                        (4000, 5000, 3, True, 7, True), (1000, 50, 20, False, 0, False),
-                                        (20000, 1000, 8, False, 99, False)]:
-        prob = gpu.Problem.synthetic(R, T, avg, seed=1234, row0=row0, uniform=uni, mapped_reads=R, sort=srt)
+    for (R, T, avg, uni, row0, srt, far) in [(30000, 2000, 8, False, 0, True, 0.0), (5000, 300, 20, False, 12345, True, 0.0),
+                                             (4000, 5000, 3, True, 7, True, 0.0), (1000, 50, 20, False, 0, False, 0.0),
+                                             (20000, 1000, 8, False, 99, False, 0.0), (30000, 3000, 8, False, 5, True, 0.2),
+                                             (9000, 2500, 5, False, 0, False, 0.02)]:
+        prob = gpu.Problem.synthetic(R, T, avg, seed=1234, row0=row0, uniform=uni, mapped_reads=R, sort=srt, far_fraction=far)
         rp, ci = prob.download()
-        p, aux = orc.synth_problem(R=R, T=T, avg_hits=avg, seed=1234, uniform=uni, row0=row0, sort=srt)
+        p, aux = orc.synth_problem(R=R, T=T, avg_hits=avg, seed=1234, uniform=uni, row0=row0, sort=srt, far_fraction=far)
         assert np.array_equal(rp, p.row_ptr)
         assert np.array_equal(ci, p.col_idx)
         assert np.array_equal(prob.l(), p.l)
@@ -230,7 +326,9 @@ def test_start_values_and_em_match_oracle(gpu, orc):
     prob = gpu.Problem.from_csr(p.row_ptr, p.col_idx, p.l)
     g_mu0, g_uh = prob.start_values()
     assert np.array_equal(g_uh, uh)                       # integer: bit-exact
-    np.testing.assert_allclose(g_mu0, mu0, rtol=1e-12, atol=0)
+    assert np.array_equal(g_mu0, orc.start_values_exact(p))  # exact fixed-point sum of the shares: order-independent, bit-exact
+    assert np.array_equal(g_mu0, prob.start_values()[0])
+    np.testing.assert_allclose(g_mu0, mu0, rtol=1e-13, atol=0)  # the reference's sequential fp64 sum (src/mmseq.cpp:617-638)
     em_o, it_o, ll_o = orc.em(p, mu0)
     em_g, it_g, ll_g = prob.em(mu0)
     assert it_g == it_o
@@ -248,15 +346,11 @@ def test_start_values_and_em_match_oracle(gpu, orc):
     np.testing.assert_allclose(mu, orc.em(p, mu0, max_iter=3, epsilon=-1e308)[0], rtol=1e-13)
 
 
-@pytest.mark.parametrize("sort,stream_env,grid", [(True, None, None), (True, None, "7"), (True, "1", None), (True, "1", "7"),
-                                                  (True, "0", None), (False, None, None)])
-def test_em_stepper_paths_match_oracle(gpu, orc, monkeypatch, sort, stream_env, grid):
-    """Tile-stream kernel (sorted rows), row-per-thread kernel (forced / unsorted rows): same bits as the oracle,
-    with multiplicities, dead transcripts and an empty row; the oracle in turn tracks the reference's summation order."""
-    if stream_env is not None:
-        monkeypatch.setenv("MMG_EM_STREAM", stream_env)
-    if grid is not None:
-        monkeypatch.setenv("MMG_EM_GRID", grid)      # few workgroups: long tile ranges, the window slides many times
+@pytest.mark.parametrize("sort,em_kernel,grid", [(True, -1, -1), (True, -1, 7), (True, 0, -1), (False, -1, -1)])
+def test_em_stepper_paths_match_oracle(gpu, orc, sort, em_kernel, grid):
+    """Sliced-ELL stream kernel (canonical rows; also with few workgroups: long tile ranges, the window slides many times),
+    row-per-thread kernel (forced / rows kept in generator order): same bits as the oracle, with multiplicities, dead
+    transcripts and an empty row; the oracle in turn tracks the reference's summation order."""
     p, aux = orc.synth_problem(R=60000, T=2500, avg_hits=7, seed=11, sort=sort)
     rng = np.random.default_rng(5)
     k = rng.choice([1, 1, 1, 2, 7, 1000], size=p.m).astype(np.uint32)
@@ -265,10 +359,10 @@ def test_em_stepper_paths_match_oracle(gpu, orc, monkeypatch, sort, stream_env, 
     pk = orc.Problem(rp, p.col_idx, p.l * 20, k=k)
     mu0, _ = orc.start_values(pk)
     mu0[5::97] = 0.0                                                    # dead from the start
-    prob = gpu.Problem.from_csr(pk.row_ptr, pk.col_idx, pk.l, k=pk.k)
-    em = prob.em_stepper(mu0)
-    st = em.stats()
-    want = 0 if (not sort or stream_env == "0") else (1 if stream_env == "1" else 2)
+    with gpu.options(em_kernel=em_kernel, em_grid=grid):
+        prob, pk = _dev(gpu, orc, pk, keep_rows=not sort)
+        em = prob.em_stepper(mu0)
+    want = 0 if (not sort or em_kernel == 0) else 2
     assert em.stats_raw()["stream_kernel"] == want
     lls = [em.loglik]
     for _ in range(12):
@@ -286,7 +380,7 @@ def test_em_stepper_paths_match_oracle(gpu, orc, monkeypatch, sort, stream_env, 
     mu1, _ = orc.start_values(pk)
     keep = np.ones(pk.m, bool)
     keep[999] = False
-    p2 = orc.Problem(p.row_ptr, p.col_idx, pk.l, k=pk.k[keep])
+    p2 = orc.Problem(p.row_ptr, p.col_idx, pk.l, k=k[keep])
     prob2 = gpu.Problem.from_csr(p2.row_ptr, p2.col_idx, p2.l, k=p2.k)
     mu_g2, it_g2, ll_g2 = prob2.em(mu1, max_iter=12, epsilon=-1e308)
     mu_s, _, ll_s = orc.em_seq(p2, mu1, max_iter=12, epsilon=-1e308)
@@ -339,7 +433,7 @@ def test_golden_tiny_chain_on_device(gpu):
     g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "keyed_chain_tiny.json")))
     f = lambda hs: np.array([float.fromhex(h) for h in hs])
     prob = gpu.Problem.from_csr(np.array(g["row_ptr"], np.uint64), np.array(g["col_idx"], np.uint32), f(g["l"]),
-                                k=np.array(g["k"], np.uint32))
+                                k=np.array(g["k"], np.uint32), keep_rows=True)   # the fixture pins the chain of THESE rows in THIS order
     mu0, uh = prob.start_values()
     assert uh.tolist() == g["unique_hits"]
     np.testing.assert_allclose(mu0, f(g["mu0"]), rtol=1e-14)
@@ -357,7 +451,7 @@ def test_golden_em_on_device(gpu):
     e = json.load(open(os.path.join(gd, "em_fixed_tiny.json")))
     fh = lambda xs: np.array([float.fromhex(x) for x in xs])
     prob = gpu.Problem.from_csr(np.asarray(g["row_ptr"], np.uint64), np.asarray(g["col_idx"], np.uint32), fh(g["l"]),
-                                k=np.asarray(g["k"], np.uint32))
+                                k=np.asarray(g["k"], np.uint32))                 # EM sums are exact: any row order gives these bits
     for r in e["runs"]:
         em = prob.em_stepper(fh(r["mu_start"]))
         for _ in range(r["sweeps"]):
@@ -417,18 +511,22 @@ def test_torch_view_of_device_buffers_and_single_rank_collectives(gpu, orc):
     assert np.array_equal(mom.cpu().numpy()[:900], ref["sum_log"])
 
 
-def test_64bit_row_offsets_path(gpu, orc, monkeypatch):
-    """nnz >= 2^32 switches the device row_ptr to u64; MMG_FORCE_IDX64 exercises that instantiation on a small problem."""
-    monkeypatch.setenv("MMG_FORCE_IDX64", "1")
+def test_64bit_row_offsets_path(gpu, orc):
+    """nnz >= 2^32 switches the device row_ptr to u64; MMG_OPT_FORCE_IDX64 exercises that instantiation on a small problem."""
+    with gpu.options(force_idx64=1):
+        _64bit_body(gpu, orc)
+
+
+def _64bit_body(gpu, orc):
     p, mu0, uh = _mk(orc, 30000, 900, 7)
     rng = np.random.default_rng(2)
     k = rng.choice([1, 1, 1, 2, 9, 300], size=p.m).astype(np.uint32)
     pk = orc.Problem(p.row_ptr, p.col_idx, p.l * 10, k=k)
     mu0, _ = orc.start_values(pk)
-    prob = gpu.Problem.from_csr(pk.row_ptr, pk.col_idx, pk.l, k=pk.k)
+    prob, pk = _dev(gpu, orc, pk)
     assert prob.info.index_bits == 64
     g_mu0, g_uh = prob.start_values()
-    np.testing.assert_allclose(g_mu0, mu0, rtol=1e-12)
+    assert np.array_equal(g_mu0, orc.start_values_exact(pk))
     em_g, it_g, _ = prob.em(mu0)
     em_o, it_o, _ = orc.em(pk, mu0)
     assert it_g == it_o and np.array_equal(em_g, em_o)
@@ -436,8 +534,6 @@ def test_64bit_row_offsets_path(gpu, orc, monkeypatch):
     s.run(32)
     ref = orc.gibbs_keyed(pk, mu0, seed=4, n_iter=32, trace_len=32)
     assert np.array_equal(s.trace(0), ref["trace"]) and np.array_equal(s.counts(0), ref["cnt"])
-    rp, ci = prob.download()
-    assert np.array_equal(rp, pk.row_ptr) and np.array_equal(ci, pk.col_idx)
     syn = gpu.Problem.synthetic(5000, 300, 6, seed=1234)
     assert syn.info.index_bits == 64
     q, _ = orc.synth_problem(R=5000, T=300, avg_hits=6, seed=1234)
@@ -446,9 +542,8 @@ def test_64bit_row_offsets_path(gpu, orc, monkeypatch):
 
 
 @pytest.mark.parametrize("n_chains", [2, 4, 8, 11])
-def test_fused_chains_equal_independent_single_chains(gpu, orc, monkeypatch, n_chains):
-    """Chains advanced together by the fused walk (groups of 8/4/2/1) are bit-identical to single-chain runs."""
-    monkeypatch.setenv("MMG_K1_SELL", "0")               # the fused walk lives in k_sample16
+def test_chains_of_one_sampler_equal_independent_single_chains(gpu, orc, n_chains):
+    """Chains advanced by one sampler are bit-identical to single-chain runs keyed with the same global chain index."""
     p, mu0, _ = _mk(orc, 40000, 1500, 9)
     prob = gpu.Problem.from_csr(p.row_ptr, p.col_idx, p.l)
     s = gpu.Sampler(prob, mu0, seed=21, n_chains=n_chains, chain_base=3, gibbs_iter=16, trace_len=16)

@@ -23,27 +23,28 @@ def one_case(seed, gpu, orc, verbose=True):
         if k is not None:
             k = np.insert(k, cut, 1).astype(np.uint32)
     pk = orc.Problem(rp, ci, p.l * float(rng.choice([0.01, 1.0, 50.0])), k=k)
-    env = {}
-    if rng.integers(0, 4) == 0: env["MMG_FORCE_IDX64"] = "1"
-    kern = int(rng.choice([2, 2, 1, 0]))
-    if kern <= 1: env["MMG_K1_SELL"] = "0"
-    if kern == 0: env["MMG_K1_S16"] = "0"
-    if rng.integers(0, 3) == 0: env["MMG_K1_SELL_WAVES_PER_CU"] = "1"
-    if rng.integers(0, 3) == 0: env["MMG_EM_GRID"] = str(int(rng.integers(1, 9)))
-    if rng.integers(0, 3) == 0: env["MMG_EM_WAVES"] = "1"
-    em_stream = rng.choice(["", "1", "0"])
-    if em_stream: env["MMG_EM_STREAM"] = str(em_stream)
-    keys = ["MMG_FORCE_IDX64", "MMG_K1_SELL", "MMG_K1_S16", "MMG_K1_SELL_WAVES_PER_CU", "MMG_EM_GRID", "MMG_EM_STREAM", "MMG_EM_WAVES"]
-    for key in keys: os.environ.pop(key, None)
-    os.environ.update(env)
-    try:
+    opts = {}
+    if rng.integers(0, 4) == 0: opts["force_idx64"] = 1
+    kern = int(rng.choice([2, 2, -1, 0]))
+    if kern >= 0: opts["sample_kernel"] = kern
+    if rng.integers(0, 3) == 0: opts["sell_waves_per_cu"] = 1
+    if rng.integers(0, 3) == 0: opts["em_grid"] = int(rng.integers(1, 9))
+    if rng.integers(0, 3) == 0: opts["em_kernel"] = 0
+    keep_rows = bool(rng.integers(0, 3) == 0)
+    tx_order = None
+    if rng.integers(0, 3) == 0:                          # device renumbering: random gene sizes over a random scatter
+        tx_order = (rng.permutation(T).astype(np.uint64) // np.uint64(int(rng.integers(1, 9)))) << np.uint64(32)
+    with gpu.options(**opts):
         mu0, uh = orc.start_values(pk)
         if rng.integers(0, 3) == 0: mu0[rng.integers(0, T, size=max(1, T // 20))] = 0.0
         if rng.integers(0, 4) == 0: mu0 *= 10.0 ** rng.uniform(-120, 120, size=T)
         rid0 = int(rng.choice([0, 0, 12345, (1 << 32) - 100, (1 << 40) + 7]))    # shard offset: crosses 2^32 in the middle of a problem
-        prob = gpu.Problem.from_csr(pk.row_ptr, pk.col_idx, pk.l, k=pk.k, row_id_base=rid0)
+        prob = gpu.Problem.from_csr(pk.row_ptr, pk.col_idx, pk.l, k=pk.k, row_id_base=rid0, keep_rows=keep_rows, tx_order=tx_order)
+        d_rp, d_ci, d_k = prob.download(with_k=True)     # stored order: what the oracle replays
+        pk = orc.Problem(d_rp, d_ci, pk.l, k=(d_k if k is not None else None))
         g_mu0, g_uh = prob.start_values()
         assert np.array_equal(g_uh, uh), "unique hits"
+        assert np.array_equal(g_mu0, orc.start_values_exact(pk)), "start values"
         n_it = int(rng.integers(1, 6))
         chains = int(rng.choice([1, 1, 3]))
         alpha, beta = float(rng.choice([0.1, 1.0])), float(rng.choice([0.1, 2.0]))
@@ -64,9 +65,8 @@ def one_case(seed, gpu, orc, verbose=True):
         info = prob.info
         prob.close()
         if verbose:
-            print("seed %d ok: R=%d T=%d avg=%g sort=%s k=%s kernel=%d env=%s" % (seed, pk.m, T, avg, sort, k is not None, info.sample_kernel, env), flush=True)
-    finally:
-        for key in keys: os.environ.pop(key, None)
+            print("seed %d ok: R=%d T=%d avg=%g sort=%s k=%s keep=%s tx=%s kernel=%d opts=%s" % (seed, pk.m, T, avg, sort, k is not None, keep_rows,
+                                                                                             tx_order is not None, info.sample_kernel, opts), flush=True)
 
 
 if __name__ == "__main__":
