@@ -101,20 +101,36 @@ struct Stream {
     }
 };
 
-// Row stream (Philox2x32): key from (seed, chain, tag, id_hi), counter (id_lo, iteration); the b-th
-// uniform uses key + b * 0xBB67AE85.
+// 32 random bits -> uniform strictly inside (0,1): (x + 1/2) 2^-32, exact.  The reference draws its allocations from MT19937,
+// i.e. with the same 32-bit resolution (gsl_rng_uniform of gsl_rng_mt19937, src/mmseq.cpp:836, :880).
+MMG_HD double u32_unit(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    // x as the top mantissa bits of a double in [1,2) is 1 + x 2^-32; subtracting 1 and adding 2^-33 are both exact
+    return (double_of(0x3ff0000000000000ull | ((uint64_t)x << 20)) - 1.0) + 0x1p-33;
+#else
+    return ((double)x + 0.5) * 0x1p-32;
+#endif
+}
+
+// Row stream.  One Philox2x32-10 block serves the TWO rows 2q and 2q+1: key from (seed, chain, tag, q >> 32), counter
+// (q & 0xffffffff, iteration); row id r = 2q + h takes output word h; the b-th uniform of a row uses key + b * 0xBB67AE85.
+// The per-row allocation draw is the bulk of a sweep's integer work (10 quarter-rate multiplies per block): a wave of
+// k_sample_sell computes one block per lane for TWO tiles of 64 rows and hands the words out with ds_bpermute.
+MMG_HD uint32_t stream2_key(uint64_t seed, uint32_t chain, uint32_t tag, uint32_t q_hi)
+{
+    return (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B1u) ^ (chain * 0x85EBCA6Bu) ^ (tag << 28) ^ (q_hi * 0xC2B2AE35u);
+}
 struct Stream2 {
-    uint32_t key, c0, c1, blk;
+    uint32_t key, c0, c1, blk, half;
     MMG_HD Stream2(uint64_t seed, uint32_t chain, uint32_t tag, uint64_t id, uint32_t iter)
-        : key((uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B1u) ^ (chain * 0x85EBCA6Bu) ^ (tag << 28) ^
-              ((uint32_t)(id >> 32) * 0xC2B2AE35u)),
-          c0((uint32_t)id), c1(iter), blk(0) {}
+        : key(stream2_key(seed, chain, tag, (uint32_t)(id >> 33))), c0((uint32_t)(id >> 1)), c1(iter), blk(0), half((uint32_t)id & 1u) {}
     MMG_HD double next()
     {
         uint32_t a = c0, b = c1;
         philox2x32_10(a, b, key + blk * 0xBB67AE85u);
         ++blk;
-        return u52(a, b);
+        return u32_unit(half ? b : a);
     }
 };
 

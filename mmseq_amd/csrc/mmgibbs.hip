@@ -107,15 +107,15 @@ constexpr uint64_t SELL_SLOW_TILE_COST = 24; // measured: a CSR-walked tile agai
 static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_starts)
 {
     if (p->m == 0 || opt(MMG_OPT_SAMPLE_KERNEL) == 0) return MMG_OK;
+    // Tiles of <= 64 rows inside the runs of equal (near, band).  The rows of a tile must lie within 32 consecutive Philox
+    // blocks (a block serves row ids 2q and 2q+1, mmg_math.h: Stream2), so a tile that starts at an odd row id holds 63 rows.
     std::vector<uint64_t> tile_row;
-    if (!seg_starts.empty()) {
-        tile_row.reserve(p->m / 64 + seg_starts.size() + 2);
-        for (size_t sgi = 0; sgi < seg_starts.size(); ++sgi) {
-            const uint64_t s = seg_starts[sgi], e = sgi + 1 < seg_starts.size() ? seg_starts[sgi + 1] : p->m;
-            for (uint64_t r = s; r < e; r += 64) tile_row.push_back(r);
-        }
-    } else {
-        for (uint64_t r = 0; r < p->m; r += 64) tile_row.push_back(r);
+    std::vector<uint64_t> whole(1, 0);
+    const std::vector<uint64_t> &segs = seg_starts.empty() ? whole : seg_starts;
+    tile_row.reserve(p->m / 64 + segs.size() + 2);
+    for (size_t sgi = 0; sgi < segs.size(); ++sgi) {
+        const uint64_t s = segs[sgi], e = sgi + 1 < segs.size() ? segs[sgi + 1] : p->m;
+        for (uint64_t r = s; r < e; r += 64 - ((p->row_id_base + r) & 1)) tile_row.push_back(r);
     }
     tile_row.push_back(p->m);
     const uint64_t nt = tile_row.size() - 1;

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64) void k_encode_sell(const IdxT *__restrict__ row
 }
 
 template <typename IdxT, bool HAS_K, int NGC, int REP = 1>
-__global__ __launch_bounds__(64) void k_sample_sell(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 1 : 7, HAS_K ? 8 : 7))) void k_sample_sell(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
                                                     const uint32_t *__restrict__ kmult, const SellTile *__restrict__ tiles, const uint64_t *__restrict__ chunk_tile,
                                                     const double *__restrict__ gmu, const uint8_t *__restrict__ stream, int32_t *gcnt,
                                                     SampleArgs a)
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(64) void k_sample_sell(const IdxT *__restrict__ row
     };
     auto wo = [&](uint32_t off) { return *(const double *)((const char *)s_mu + off); }; // off = window index * 8
     // byte k of a group word as an LDS byte offset
-#define SELL_OFF0(v) (((v) << 3) & 0x7f8u)
+#define SELL_OFF0(v) (((v) & 0xffu) << 3)
 #define SELL_OFF1(v) (((v) >> 5) & 0x7f8u)
 #define SELL_OFF2(v) (((v) >> 13) & 0x7f8u)
 #define SELL_OFF3(v) (((v) >> 21) & 0x7f8u)
@@ -116,16 +116,48 @@ __global__ __launch_bounds__(64) void k_sample_sell(const IdxT *__restrict__ row
 #undef SELL_ISSUE
     };
 
-    auto walk = [&](const SellTile &d, const Buf &bf) {
+    // Pair RNG: ONE Philox2x32-10 block per lane serves the fast rows of BOTH tiles of the unrolled pair (mmg_math.h: a block
+    // belongs to rows 2q and 2q+1): lanes 0..31 hold the blocks of tile A, lanes 32..63 those of tile B.  A tile spans at most
+    // 32 blocks (the host cuts tiles so that parity + nrows <= 64).
+    uint32_t xrowA = 0, xrowB = 0; // this lane's random word for its row of tile A / tile B
+    auto pair_rng = [&](const SellTile &A, const SellTile &B) {
+        const uint64_t qa = (a.row_id_base + A.r0) >> 1, qb = (a.row_id_base + B.r0) >> 1; // uniform
+        const uint32_t l5 = lane & 31u;
+        uint32_t x0, x1;
+        if ((uint32_t)(qa >> 32) == (uint32_t)(qb >> 32) && (uint32_t)qa <= 0xffffffe0u && (uint32_t)qb <= 0xffffffe0u) {
+            // the usual case: one key for the whole wave, kept in scalar registers
+            const uint32_t key = stream2_key(a.seed, a.chain, TAG_ROW, (uint32_t)(qa >> 32));
+            x0 = (lane < 32u ? (uint32_t)qa : (uint32_t)qb) + l5;
+            x1 = a.iter;
+            philox2x32_10(x0, x1, key);
+        } else { // a pair that straddles a multiple of 2^33 row ids: per-lane keys, same values
+            const uint64_t q = (lane < 32u ? qa : qb) + l5;
+            x0 = (uint32_t)q;
+            x1 = a.iter;
+            philox2x32_10(x0, x1, stream2_key(a.seed, a.chain, TAG_ROW, (uint32_t)(q >> 32)));
+        }
+        // row (parity + lane) of a tile: block (parity + lane) >> 1 of the tile's half-wave, word (parity + lane) & 1.  All 64
+        // lanes are active here (ds_bpermute returns 0 for a source lane that is masked off).
+        const uint32_t pa = ((uint32_t)(a.row_id_base + A.r0) & 1u) + lane, pb = ((uint32_t)(a.row_id_base + B.r0) & 1u) + lane;
+        const int sa = (int)((pa >> 1) << 2), sb = (int)((32u + (pb >> 1)) << 2);
+        const uint32_t a0 = (uint32_t)__builtin_amdgcn_ds_bpermute(sa, (int)x0), a1 = (uint32_t)__builtin_amdgcn_ds_bpermute(sa, (int)x1);
+        const uint32_t b0 = (uint32_t)__builtin_amdgcn_ds_bpermute(sb, (int)x0), b1 = (uint32_t)__builtin_amdgcn_ds_bpermute(sb, (int)x1);
+        xrowA = (pa & 1u) ? a1 : a0;
+        xrowB = (pb & 1u) ? b1 : b0;
+    };
+
+    auto walk = [&](const SellTile &d, const Buf &bf, uint32_t which) {
         const uint32_t ng = d.ng();                                    // uniform
         const uint32_t *__restrict__ src = (const uint32_t *)(stream + d.off16 * 16 + 64) + lane; // groups beyond the cached ones
         const uint32_t L = bf.len;
+        const uint32_t xrow = which ? xrowB : xrowA;
         double t = 0.0;
 #define SELL_SUM(i)                                                                                          \
         if ((uint32_t)i < ng) {                                                                              \
             const uint32_t v = bf.g##i;                                                                      \
             const double w0 = wo(SELL_OFF0(v)), w1 = wo(SELL_OFF1(v)), w2 = wo(SELL_OFF2(v)), w3 = wo(SELL_OFF3(v)); \
-            t += w0; t += w1; t += w2; t += w3;                                                              \
+            if (i == 0) t = w0; else t += w0; /* 0.0 + w0 == w0 exactly */                                   \
+            t += w1; t += w2; t += w3;                                                                       \
         }                                                                                                    \
         const double P##i = t;
         SELL_GROUPS(SELL_SUM)
@@ -187,11 +219,10 @@ __global__ __launch_bounds__(64) void k_sample_sell(const IdxT *__restrict__ row
             }
             return off_of(L - 1); // rounding left target >= total: the last real hit
         };
-        if (!HAS_K || kk <= K_SMALL) {
+        if (!HAS_K) { add(draw(u32_unit(xrow)), 1); return; }
+        if (kk <= K_SMALL) {
             Stream2 s(a.seed, a.chain, TAG_ROW, row_id, a.iter);
-            if (!HAS_K) {
-                add(draw(s.next()), 1);
-            } else {
+            {
 #pragma unroll 1
                 for (uint32_t dd = 0; dd < kk; ++dd) add(draw(s.next()), 1);
             }
@@ -236,7 +267,7 @@ __global__ __launch_bounds__(64) void k_sample_sell(const IdxT *__restrict__ row
         }
     };
 
-    auto process = [&](const SellTile &d, uint32_t &cur_base, const SellTile &refill, Buf &bf) {
+    auto process = [&](const SellTile &d, uint32_t &cur_base, const SellTile &refill, Buf &bf, uint32_t which) {
         if (d.flags() & SELL_EMPTY) { issue(refill, bf); return; }
         if (d.wbase != cur_base) {
             __syncthreads();
@@ -245,7 +276,7 @@ __global__ __launch_bounds__(64) void k_sample_sell(const IdxT *__restrict__ row
             cur_base = d.wbase;
             __syncthreads();
         }
-        if (d.flags() & SELL_FAST) walk(d, bf);
+        if (d.flags() & SELL_FAST) walk(d, bf, which);
         else slow_tile(d);
         issue(refill, bf); // the registers are free again only now: tile i+2 travels while tile i+1 is walked
     };
@@ -265,8 +296,9 @@ __global__ __launch_bounds__(64) void k_sample_sell(const IdxT *__restrict__ row
     issue(dB, bufB);
     for (uint64_t i = 0; i < nt; i += 2) {
         const SellTile nA = tile_at(i + 2), nB = tile_at(i + 3); // scalar loads: in flight while A and B are walked
-        process(dA, cur_base, nA, bufA);
-        process(dB, cur_base, nB, bufB); // past the end of the range dB is the empty tile: same loads, no walk
+        if (!HAS_K) pair_rng(dA, dB);
+        process(dA, cur_base, nA, bufA, 0);
+        process(dB, cur_base, nB, bufB, 1); // past the end of the range dB is the empty tile: same loads, no walk
         dA = nA;
         dB = nB;
     }

@@ -127,18 +127,21 @@ static inline orc_stream stream_make(uint64_t seed, uint32_t chain, uint32_t tag
     return s;
 }
 
-/* Row stream: key from (seed, chain, tag, id_hi), counter (id_lo, iteration); the b-th uniform of the
- * stream uses key + b * 0xBB67AE85. */
-typedef struct { uint32_t key, c0, c1, blk; } orc_stream2;
+/* Row stream (mmseq_amd/csrc/mmg_math.h:Stream2).  One Philox2x32-10 block serves the two rows 2q and 2q+1: key from
+ * (seed, chain, tag, q >> 32), counter (q & 0xffffffff, iteration); row id r = 2q + h takes output word h as the 32-bit
+ * uniform (x + 1/2) 2^-32 -- the resolution of the reference's gsl_rng_mt19937 draws; the b-th uniform of a row uses
+ * key + b * 0xBB67AE85. */
+typedef struct { uint32_t key, c0, c1, blk, half; } orc_stream2;
 
 static inline orc_stream2 stream2_make(uint64_t seed, uint32_t chain, uint32_t tag, uint64_t id, uint32_t iter)
 {
     orc_stream2 s;
     s.key = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B1u) ^ (chain * 0x85EBCA6Bu) ^ (tag << 28) ^
-            ((uint32_t)(id >> 32) * 0xC2B2AE35u);
-    s.c0 = (uint32_t)id;
+            ((uint32_t)(id >> 33) * 0xC2B2AE35u);
+    s.c0 = (uint32_t)(id >> 1);
     s.c1 = iter;
     s.blk = 0;
+    s.half = (uint32_t)id & 1u;
     return s;
 }
 
@@ -147,7 +150,7 @@ static inline double stream2_next(orc_stream2 *s)
     uint32_t a = s->c0, b = s->c1;
     philox2x32_10(&a, &b, s->key + s->blk * 0xBB67AE85u);
     s->blk++;
-    return u52(a, b);
+    return ((double)(s->half ? b : a) + 0.5) * 0x1p-32;
 }
 
 /* one Philox block = one pair of uniforms */

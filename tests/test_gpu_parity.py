@@ -267,7 +267,10 @@ def test_sliced_ell_kernel_edge_rows(gpu, orc, with_k, keep_rows):
     mu0[3000:3100] = np.inf                                    # total not finite: uniform pick as well
     with gpu.options(sample_kernel=2, sell_waves_per_cu=1):  # few workgroups: long tile ranges, several window slides each
         prob, p = _dev(gpu, orc, p, keep_rows=keep_rows)
-    assert prob.info.sample_kernel == 2 and 0 < prob.info.fast_tiles < prob.info.n_tiles
+    # canonical order: nearly every tile runs from the register stream, the 300-hit row and the far row sit in slow tiles; kept
+    # as given, the bands change from row to row and (almost) every 64-row tile is walked from the CSR by the same kernel
+    assert prob.info.sample_kernel == 2 and prob.info.fast_tiles < prob.info.n_tiles
+    assert keep_rows or prob.info.fast_tiles > 0.9 * prob.info.n_tiles
     s = gpu.Sampler(prob, mu0, seed=17, gibbs_iter=12, trace_len=12)
     s.sample()
     ref1 = orc.sample_counts(p, mu0, seed=17, chain=0, it=0)

@@ -1,0 +1,46 @@
+"""A/B timing of K1 between builds of libmmgibbs.so on ONE box (boxes of the pool differ by +-10 %, runs on different boxes cannot
+be compared).  usage: k1_ab.py lib_a.so lib_b.so ... [--rows R --transcripts T --avg A --rounds N]
+Each library is measured in its own subprocess, round-robin, N rounds; prints the mean K1 launch time per library and round."""
+import argparse, json, os, subprocess, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHILD = r'''
+import sys, json
+sys.path.insert(0, %r)
+from mmseq_amd import _lib
+_lib.LIB_PATH = sys.argv[1]
+from mmseq_amd import Problem, Sampler
+R, T, A, C = int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), int(sys.argv[5])
+prob = Problem.synthetic(R, T, A, seed=1234)
+mu0, _ = prob.start_values()
+s = Sampler(prob, mu0, n_chains=C, gibbs_iter=1024, trace_len=1024, keep_trace=False, timing=1)
+s.run(300); s.sync(); s.reset_timing()
+s.run(200); s.sync()
+tm = s.timing()
+print(json.dumps({"k1_ms": tm["sample_ms"] / tm["sample_launches"] / C, "k2_ms": tm["update_ms"] / tm["update_launches"],
+                  "stream": prob.info.stream_bytes}))
+''' % ROOT
+
+ap = argparse.ArgumentParser()
+ap.add_argument("libs", nargs="+")
+ap.add_argument("--rows", type=int, default=50_000_000)
+ap.add_argument("--transcripts", type=int, default=200_000)
+ap.add_argument("--avg", type=float, default=20.0)
+ap.add_argument("--chains", type=int, default=1)
+ap.add_argument("--rounds", type=int, default=2)
+a = ap.parse_args()
+res = {l: [] for l in a.libs}
+for r in range(a.rounds):
+    for l in a.libs:
+        out = subprocess.run([sys.executable, "-c", CHILD, os.path.abspath(l), str(a.rows), str(a.transcripts), str(a.avg), str(a.chains)],
+                             capture_output=True, text=True)
+        line = [x for x in out.stdout.splitlines() if x.startswith("{")]
+        if not line:
+            print(l, "FAILED", out.stderr[-500:], flush=True)
+            continue
+        d = json.loads(line[-1])
+        res[l].append(d["k1_ms"])
+        print("round %d %-40s K1 %.4f ms  K2 %.4f ms  stream %.3f GB" % (r, os.path.basename(l), d["k1_ms"], d["k2_ms"], d["stream"] / 1e9), flush=True)
+for l in a.libs:
+    if res[l]:
+        print("%-40s mean K1 %.4f ms over %d rounds" % (os.path.basename(l), sum(res[l]) / len(res[l]), len(res[l])))
