@@ -194,6 +194,44 @@ int mmg_sampler_get_timing(mmg_sampler *s, mmg_timing *t);
 int mmg_sampler_reset_timing(mmg_sampler *s);
 void mmg_sampler_destroy(mmg_sampler *s);
 
+/* ---- posterior summary of the resident trace ---------------------------------------------------
+ * Everything src/mmseq.cpp:927-1363 derives from mu_trace, computed where the trace lives: simulated traces of isoforms
+ * without hits (:971-978), trace sums over sets of identical transcripts and over genes (:927-1008), proportions of gene
+ * expression (:1014-1031), and per series the percentiles (:1110-1192), the mean of the logged trace (:1195-1227), Sokal's
+ * variance / autocorrelation time of the logged trace (:1307-1363, src/sokal.cc:33-87) and the proportion summaries
+ * (:1235-1305).  The host downloads summary columns and, for the trace writers (:1033-1108), sample rows. */
+typedef struct mmg_summary mmg_summary;
+typedef struct mmg_summary_desc {
+    int32_t chain;
+    /* isoforms that received no hit: trace v is Gamma(alpha) * virtual_scale[v] keyed (seed, id virtual_id[v], sample), :974 */
+    uint32_t n_virtual;
+    const uint64_t *virtual_id;
+    const double *virtual_scale;
+    /* groups whose trace is the sum of their members' traces, members added in the given order; a member < n is the caller's
+     * transcript, n + v is virtual transcript v */
+    uint32_t n_identical;            /* sets of identical transcripts, :927-945 */
+    const uint64_t *identical_ptr;   /* n_identical + 1 offsets into identical_member */
+    const uint32_t *identical_member;
+    uint32_t n_genes;                /* genes, :947-1008; a transcript's proportion is relative to the gene that lists it */
+    const uint64_t *gene_ptr;
+    const uint32_t *gene_member;
+    uint32_t n_percentiles;          /* positions in the sorted trace, round(p / 100 * (trace_len - 1)), :1111-1114 */
+    const int32_t *percentile_index;
+} mmg_summary_desc;
+enum { MMG_SERIES_TRANSCRIPT = 0, MMG_SERIES_VIRTUAL = 1, MMG_SERIES_IDENTICAL = 2, MMG_SERIES_GENE = 3 };
+int mmg_summary_create(mmg_sampler *s, const mmg_summary_desc *d, mmg_summary **out);
+/* Per series of `kind` (n, n_virtual, n_identical or n_genes of them): mean of the logged trace, Sokal's var and tau of the
+ * logged trace with its return code (0; 200 / 201 when trace_len is no power of two >= 4: var = tau = 0), and the
+ * n_percentiles order statistics of the trace itself, [series][percentile].  Any output may be NULL. */
+int mmg_summary_get(mmg_summary *q, int kind, double *log_mean, double *var, double *tau, int32_t *sokal_rc, double *percentiles);
+/* Proportions of gene expression, kind MMG_SERIES_TRANSCRIPT or MMG_SERIES_VIRTUAL: mean proportion, mean and sd of the probit
+ * of the proportion clamped to [1e-9, 1 - 1e-9] (+inf terms for the only transcript of its gene, as at :1243-1262), percentiles. */
+int mmg_summary_get_proportions(mmg_summary *q, int kind, double *mean_prop, double *mean_probit, double *sd_probit, double *percentiles);
+/* Sample rows of the derived traces as the trace writers print them: out[r * width + i], r over [first_sample, first_sample +
+ * n_samples).  MMG_SERIES_IDENTICAL / MMG_SERIES_GENE: the summed traces; MMG_SERIES_TRANSCRIPT: the proportions (width n). */
+int mmg_summary_get_rows(mmg_summary *q, int kind, int first_sample, int n_samples, double *out);
+void mmg_summary_destroy(mmg_summary *q);
+
 /* int_of_ext[t] = device index of the caller's transcript t (identity without tx_order). */
 int mmg_problem_tx_perm(const mmg_problem *p, uint32_t *int_of_ext);
 

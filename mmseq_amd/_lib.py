@@ -42,6 +42,13 @@ class ProblemInfo(C.Structure):
                 ("layout", C.c_int32), ("tx_renumbered", C.c_int32)]
 
 
+class SummaryDesc(C.Structure):
+    _fields_ = [("chain", C.c_int32), ("n_virtual", C.c_uint32), ("virtual_id", C.c_void_p), ("virtual_scale", C.c_void_p),
+                ("n_identical", C.c_uint32), ("identical_ptr", C.c_void_p), ("identical_member", C.c_void_p),
+                ("n_genes", C.c_uint32), ("gene_ptr", C.c_void_p), ("gene_member", C.c_void_p),
+                ("n_percentiles", C.c_uint32), ("percentile_index", C.c_void_p)]
+
+
 class Config(C.Structure):
     _fields_ = [("alpha", C.c_double), ("beta", C.c_double), ("seed", C.c_uint64), ("n_chains", C.c_int32),
                 ("chain_base", C.c_int32), ("gibbs_iter", C.c_int32), ("trace_len", C.c_int32),
@@ -91,6 +98,11 @@ SYMBOLS = {
     "mmg_sampler_get_timing": (C.c_int, [C.c_void_p, C.POINTER(Timing)]),
     "mmg_sampler_reset_timing": (C.c_int, [C.c_void_p]),
     "mmg_sampler_destroy": (None, [C.c_void_p]),
+    "mmg_summary_create": (C.c_int, [C.c_void_p, C.POINTER(SummaryDesc), C.POINTER(C.c_void_p)]),
+    "mmg_summary_get": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mmg_summary_get_proportions": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mmg_summary_get_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mmg_summary_destroy": (None, [C.c_void_p]),
     "mmg_host_gamma_trace": (C.c_int, [C.c_uint64, C.c_uint64, C.c_double, C.c_double, C.c_int, C.c_void_p]),
     "mmg_selftest_math": (C.c_int, [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mmg_selftest_philox": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -222,6 +222,21 @@ static void write_trace_lines(GzText &gz, int n_lines, size_t n_cols, const func
     }
 }
 
+// The same lines from rows fetched on demand (the trace lives on the device, sample-major: a line of the file is a row there).
+static void write_trace_rows(GzText &gz, int n_lines, size_t n_cols, const function<void(int, int, double *)> &fetch,
+                             const function<bool(size_t)> &keep)
+{
+    if (n_cols == 0) { write_trace_lines(gz, n_lines, 0, [](int, size_t) { return 0.0; }, keep); return; }
+    const int lines_per_chunk = (int)max<size_t>(1, (size_t)262144 / max<size_t>(1, n_cols * 9));
+    const int per_round = lines_per_chunk * max(1, omp_get_max_threads() * 2) * 4;
+    vector<double> buf((size_t)min(per_round, n_lines) * n_cols);
+    for (int l0 = 0; l0 < n_lines; l0 += per_round) {
+        const int cnt = min(per_round, n_lines - l0);
+        fetch(l0, cnt, buf.data());
+        write_trace_lines(gz, cnt, n_cols, [&](int i, size_t col) { return buf[(size_t)i * n_cols + col]; }, keep);
+    }
+}
+
 // Stage timings on stderr when MMSEQ_TIMING is set (not part of the reference's output)
 struct StageTimer {
     bool on = getenv("MMSEQ_TIMING") != nullptr;
@@ -705,15 +720,14 @@ int main(int argc, char **argv)
     const vector<double> mu_em = mu;
 
     stage.mark("EM");
-    // ---- Gibbs on the device (src/mmseq.cpp:833-918)
-    vector<double> mu_trace((size_t)n * trace_length);
+    // ---- Gibbs on the device (src/mmseq.cpp:833-918); the trace stays there
+    mmg_sampler *smp = nullptr;
     {
         mmg_config cfg;
         memset(&cfg, 0, sizeof cfg);
         cfg.alpha = alpha; cfg.beta = beta; cfg.seed = (uint64_t)(int64_t)seed;
         cfg.n_chains = 1; cfg.chain_base = 0; cfg.gibbs_iter = gibbs_iter; cfg.trace_len = trace_length;
         cfg.keep_trace = 1; cfg.timing = 0;
-        mmg_sampler *smp = nullptr;
         MMG_TRY(mmg_sampler_create(prob, &cfg, mu_em.data(), &smp));
         const int chunk = max(1, gibbs_iter / 16);
         for (int done = 0; done < gibbs_iter; done += chunk) {
@@ -722,80 +736,75 @@ int main(int argc, char **argv)
             MMG_TRY(mmg_sampler_sync(smp));
         }
         cout << "Gibbs iteration " << gibbs_iter - 1 << "       \r" << endl;
-        MMG_TRY(mmg_sampler_get_trace(smp, 0, mu_trace.data()));
-        mmg_sampler_destroy(smp);
     }
-    mmg_problem_destroy(prob);
+    stage.mark("Gibbs");
 
-    stage.mark("Gibbs + trace download");
-    // ---- .trace_gibbs.gz (src/mmseq.cpp:823-831, :911-917), written after the loop
+    cout << "Amalgamating transcripts and calculating summary statistics..." << flush;
+    // ---- posterior summary on the device (src/mmseq.cpp:927-1363): trace sums over identical sets and genes, simulated traces of
+    //      isoforms without hits, proportions, percentiles, log means, Sokal.  Only summary columns and the rows the trace
+    //      writers print come back.
+    const size_t nI = identical_transcripts.size(), nG = gene2transcripts.size();
+    const size_t nP = percentiles.size();
+    vector<int> pind(nP);
+    for (size_t i = 0; i < nP; i++) pind[i] = static_cast<int>(round(percentiles[i] / 100.0 * (trace_length - 1)));
+    map<string, uint32_t> headerIndexOf;
+    for (size_t i = 0; i < nHeader; ++i) headerIndexOf[transcriptList[i]] = (uint32_t)i;
+    map<string, uint32_t> simuIndex; // isoform without hits -> its simulated ("virtual") trace
+    mmg_summary *summ = nullptr;
+    {
+        vector<uint64_t> vid, iptr(1, 0), gptr(1, 0);
+        vector<double> vscale;
+        vector<uint32_t> imem, gmem;
+        for (size_t v = 0; v < nI; ++v) {
+            for (auto &name : identical_transcripts[v]) { const int32_t t = obs_of(name); if (t >= 0) imem.push_back((uint32_t)t); }
+            iptr.push_back(imem.size());
+        }
+        size_t g = 0;
+        for (auto &gt : gene2transcripts) {
+            for (auto &name : gt.second) {
+                const int32_t t = obs_of(name);
+                if (t >= 0) { gmem.push_back((uint32_t)t); continue; }
+                // no hits: simulate from the prior-only conditional (keyed by the header index, :971-978)
+                simuIndex[name] = (uint32_t)vid.size();
+                gmem.push_back(n + (uint32_t)vid.size());
+                vid.push_back(headerIndexOf.count(name) ? headerIndexOf[name] : (uint64_t)nHeader + g);
+                vscale.push_back(1.0 / (beta + sidLen[name] * (double)numbermappedreads / 1000000000.0));
+            }
+            gptr.push_back(gmem.size());
+            g++;
+        }
+        mmg_summary_desc sd;
+        memset(&sd, 0, sizeof sd);
+        sd.chain = 0;
+        sd.n_virtual = (uint32_t)vid.size(); sd.virtual_id = vid.data(); sd.virtual_scale = vscale.data();
+        sd.n_identical = (uint32_t)nI; sd.identical_ptr = iptr.data(); sd.identical_member = imem.data();
+        sd.n_genes = (uint32_t)nG; sd.gene_ptr = gptr.data(); sd.gene_member = gmem.data();
+        sd.n_percentiles = (uint32_t)nP; sd.percentile_index = pind.data();
+        MMG_TRY(mmg_summary_create(smp, &sd, &summ));
+    }
+    const size_t nV = simuIndex.size();
+    stage.mark("device summary");
+
+    // ---- trace files (src/mmseq.cpp:823-831, :911-917, :1033-1108), written after the loop from rows fetched off the device
     {
         GzText gz(output_base + ".trace_gibbs.gz");
         for (uint32_t t = 0; t < n; t++) { gz.str(sid(t)); gz.str(" "); }
         gz.str("\n");
-        write_trace_lines(gz, trace_length, n, [&](int i, size_t t) { return mu_trace[t * trace_length + i]; },
-                          [](size_t) { return true; });
+        write_trace_rows(gz, trace_length, n, [&](int first, int count, double *out) { MMG_TRY(mmg_sampler_get_trace_rows(smp, 0, first, count, out)); },
+                         [](size_t) { return true; });
         gz.close();
     }
-
-    cout << "Amalgamating transcripts and calculating summary statistics..." << flush;
-
+    mmg_sampler_destroy(smp);
+    mmg_problem_destroy(prob);
     stage.mark("write .trace_gibbs.gz");
-    // ---- trace aggregation (src/mmseq.cpp:927-1008)
-    const size_t nI = identical_transcripts.size(), nG = gene2transcripts.size();
-    vector<double> mu_trace_identical(nI * trace_length, 0.0), mu_trace_gene(nG * trace_length, 0.0);
-    for (size_t v = 0; v < nI; ++v)
-        for (auto &name : identical_transcripts[v]) {
-            const int32_t t = obs_of(name);
-            if (t >= 0) for (int i = 0; i < trace_length; i++) mu_trace_identical[v * trace_length + i] += mu_trace[(size_t)t * trace_length + i];
-        }
-    map<string, uint32_t> headerIndexOf;
-    for (size_t i = 0; i < nHeader; ++i) headerIndexOf[transcriptList[i]] = (uint32_t)i;
-    map<string, vector<double>> mu_trace_simu, prop_trace_simu;
     {
-        size_t g = 0;
-        for (auto &gt : gene2transcripts) {
-            for (auto &name : gt.second) {
-                const int32_t t = obs_of(name);
-                if (t >= 0) {
-                    for (int i = 0; i < trace_length; i++) mu_trace_gene[g * trace_length + i] += mu_trace[(size_t)t * trace_length + i];
-                } else { // no hits: simulate from the prior-only conditional (keyed by the header index, :971-978)
-                    vector<double> temp(trace_length);
-                    const uint64_t id = headerIndexOf.count(name) ? headerIndexOf[name] : (uint64_t)nHeader + g;
-                    MMG_TRY(mmg_host_gamma_trace((uint64_t)(int64_t)seed, id, alpha,
-                                                 1.0 / (beta + sidLen[name] * (double)numbermappedreads / 1000000000.0), trace_length,
-                                                 temp.data()));
-                    for (int i = 0; i < trace_length; i++) mu_trace_gene[g * trace_length + i] += temp[i];
-                    mu_trace_simu[name] = temp;
-                }
-            }
-            g++;
-        }
-    }
-    vector<double> prop_trace((size_t)n * trace_length, NAN);
-    {
-        size_t g = 0;
-        for (auto &gt : gene2transcripts) {
-            for (auto &name : gt.second) {
-                const int32_t t = obs_of(name);
-                if (t >= 0) {
-                    for (int i = 0; i < trace_length; i++)
-                        prop_trace[(size_t)t * trace_length + i] = mu_trace[(size_t)t * trace_length + i] / mu_trace_gene[g * trace_length + i];
-                } else {
-                    vector<double> temp(trace_length);
-                    for (int i = 0; i < trace_length; i++) temp[i] = mu_trace_simu[name][i] / mu_trace_gene[g * trace_length + i];
-                    prop_trace_simu[name] = temp;
-                }
-            }
-            g++;
-        }
-    }
-
-    // ---- identical / gene / proportion traces (src/mmseq.cpp:1033-1108)
-    {
+        // a set / gene whose first summed sample has no finite logarithm is left out of its trace file (:1040, :1068)
+        vector<double> firstI(max<size_t>(nI, 1)), firstG(max<size_t>(nG, 1));
+        MMG_TRY(mmg_summary_get_rows(summ, MMG_SERIES_IDENTICAL, 0, 1, firstI.data()));
+        MMG_TRY(mmg_summary_get_rows(summ, MMG_SERIES_GENE, 0, 1, firstG.data()));
         vector<char> keepI(nI), keepG(nG);
-        for (size_t v = 0; v < nI; ++v) keepI[v] = isfinite(log(mu_trace_identical[v * trace_length])) != 0;
-        for (size_t g = 0; g < nG; ++g) keepG[g] = isfinite(log(mu_trace_gene[g * trace_length])) != 0;
+        for (size_t v = 0; v < nI; ++v) keepI[v] = isfinite(log(firstI[v])) != 0;
+        for (size_t g = 0; g < nG; ++g) keepG[g] = isfinite(log(firstG[g])) != 0;
         GzText gi(output_base + ".identical.trace_gibbs.gz");
         for (size_t v = 0; v < nI; ++v)
             if (keepI[v]) {
@@ -806,108 +815,59 @@ int main(int argc, char **argv)
                 gi.str(" ");
             }
         gi.str("\n");
-        write_trace_lines(gi, trace_length, nI, [&](int i, size_t v) { return mu_trace_identical[v * trace_length + i]; },
-                          [&](size_t v) { return keepI[v] != 0; });
+        write_trace_rows(gi, trace_length, nI, [&](int first, int count, double *out) { MMG_TRY(mmg_summary_get_rows(summ, MMG_SERIES_IDENTICAL, first, count, out)); },
+                         [&](size_t v) { return keepI[v] != 0; });
         gi.close();
         GzText gg(output_base + ".gene.trace_gibbs.gz");
         { size_t g = 0; for (auto &gt : gene2transcripts) { if (keepG[g]) { gg.str(gt.first); gg.str(" "); } g++; } }
         gg.str("\n");
-        write_trace_lines(gg, trace_length, nG, [&](int i, size_t g) { return mu_trace_gene[g * trace_length + i]; },
-                          [&](size_t g) { return keepG[g] != 0; });
+        write_trace_rows(gg, trace_length, nG, [&](int first, int count, double *out) { MMG_TRY(mmg_summary_get_rows(summ, MMG_SERIES_GENE, first, count, out)); },
+                         [&](size_t g) { return keepG[g] != 0; });
         gg.close();
         GzText gp(output_base + ".prop.trace_gibbs.gz");
         for (uint32_t t = 0; t < n; t++) { gp.str(sid(t)); gp.str(" "); }
         gp.str("\n");
-        write_trace_lines(gp, trace_length, n, [&](int i, size_t t) { return prop_trace[t * trace_length + i]; },
-                          [](size_t) { return true; });
+        write_trace_rows(gp, trace_length, n, [&](int first, int count, double *out) { MMG_TRY(mmg_summary_get_rows(summ, MMG_SERIES_TRANSCRIPT, first, count, out)); },
+                         [](size_t) { return true; });
         gp.close();
     }
+    stage.mark("write derived traces");
 
-    stage.mark("aggregate traces + write");
-    // ---- percentiles (src/mmseq.cpp:1110-1192)
-    const size_t nP = percentiles.size();
-    vector<int> pind(nP);
-    for (size_t i = 0; i < nP; i++) pind[i] = static_cast<int>(round(percentiles[i] / 100.0 * (trace_length - 1)));
-    auto pct_of = [&](const double *tr, vector<double> &out) {
-        vector<double> v(tr, tr + trace_length);
-        std::sort(v.begin(), v.end());
-        out.resize(nP);
-        for (size_t j = 0; j < nP; j++) out[j] = v[pind[j]];
-    };
-    vector<vector<double>> percentiles_prop(n), percentiles_transcript(n), percentiles_identical(nI), percentiles_gene(nG);
-#pragma omp parallel for schedule(static)
-    for (int64_t i = 0; i < (int64_t)n; i++) {
-        pct_of(&prop_trace[(size_t)i * trace_length], percentiles_prop[i]);
-        pct_of(&mu_trace[(size_t)i * trace_length], percentiles_transcript[i]);
-    }
-#pragma omp parallel for schedule(static)
-    for (int64_t i = 0; i < (int64_t)nI; i++) pct_of(&mu_trace_identical[(size_t)i * trace_length], percentiles_identical[i]);
-#pragma omp parallel for schedule(static)
-    for (int64_t i = 0; i < (int64_t)nG; i++) pct_of(&mu_trace_gene[(size_t)i * trace_length], percentiles_gene[i]);
-    map<string, vector<double>> percentiles_simu, percentiles_prop_simu;
-    for (auto &s : mu_trace_simu) pct_of(s.second.data(), percentiles_simu[s.first]);
-    for (auto &s : prop_trace_simu) pct_of(s.second.data(), percentiles_prop_simu[s.first]);
-
-    // ---- log traces and their means (src/mmseq.cpp:1195-1227)
-    vector<double> meanmu(n, 0), meanmu_identical(nI, 0), meanmu_gene(nG, 0);
-    auto log_and_mean = [&](vector<double> &tr, vector<double> &mean, size_t count) {
-#pragma omp parallel for schedule(static)
-        for (int64_t t = 0; t < (int64_t)count; t++) {
-            double sacc = 0;
-            for (int i = 0; i < trace_length; i++) { double &x = tr[(size_t)t * trace_length + i]; x = log(x); sacc += x; }
-            mean[t] = sacc / trace_length;
+    // ---- summary columns (src/mmseq.cpp:1110-1363)
+    struct Series { vector<double> mean, sd, mcse, iact, pct; };
+    auto fetch_series = [&](int kind, size_t count, Series &o) {
+        o.mean.resize(max<size_t>(count, 1)); o.sd.resize(max<size_t>(count, 1)); o.mcse.resize(max<size_t>(count, 1));
+        o.iact.resize(max<size_t>(count, 1)); o.pct.resize(max<size_t>(count * nP, 1));
+        vector<double> var(max<size_t>(count, 1)), tau(max<size_t>(count, 1));
+        vector<int32_t> rc(max<size_t>(count, 1));
+        MMG_TRY(mmg_summary_get(summ, kind, o.mean.data(), var.data(), tau.data(), rc.data(), o.pct.data()));
+        for (size_t t = 0; t < count; ++t) { // :1311-1324
+            if (rc[t] != 0) { o.mcse[t] = trace_length; o.iact[t] = NAN; }
+            else { o.mcse[t] = sqrt(tau[t] * var[t] / trace_length); o.iact[t] = tau[t]; }
+            o.sd[t] = sqrt(var[t]);
         }
     };
-    log_and_mean(mu_trace, meanmu, n);
-    log_and_mean(mu_trace_identical, meanmu_identical, nI);
-    log_and_mean(mu_trace_gene, meanmu_gene, nG);
-
-    // ---- proportion summaries (src/mmseq.cpp:1235-1305)
-    auto prop_summary = [&](const double *pt, bool multi, double &meanprop, double &meanprobit, double &sdprobit) {
-        double sp = 0, s1 = 0, s2 = 0;
-        for (int i = 0; i < trace_length; i++) {
-            sp += pt[i];
-            const double temp = multi ? mmnum::probit(min(max(pt[i], 0.000000001), 0.999999999)) : numeric_limits<double>::infinity();
-            s1 += temp;
-            s2 += temp * temp;
-        }
-        meanprop = sp / trace_length;
-        sdprobit = sqrt((s2 - s1 * s1 / trace_length) / (trace_length - 1.0));
-        meanprobit = s1 / trace_length;
+    Series sT, sV, sI, sG;
+    fetch_series(MMG_SERIES_TRANSCRIPT, n, sT);
+    fetch_series(MMG_SERIES_VIRTUAL, nV, sV);
+    fetch_series(MMG_SERIES_IDENTICAL, nI, sI);
+    fetch_series(MMG_SERIES_GENE, nG, sG);
+    const vector<double> &meanmu = sT.mean, &meanmu_identical = sI.mean, &meanmu_gene = sG.mean;
+    const vector<double> &sd = sT.sd, &mumcse = sT.mcse, &iact = sT.iact;
+    const vector<double> &sd_identical = sI.sd, &mumcse_identical = sI.mcse, &iact_identical = sI.iact;
+    const vector<double> &sd_gene = sG.sd, &mumcse_gene = sG.mcse, &iact_gene = sG.iact;
+    struct Props { vector<double> mean, probit_mean, probit_sd, pct; };
+    auto fetch_props = [&](int kind, size_t count, Props &o) {
+        o.mean.resize(max<size_t>(count, 1)); o.probit_mean.resize(max<size_t>(count, 1)); o.probit_sd.resize(max<size_t>(count, 1));
+        o.pct.resize(max<size_t>(count * nP, 1));
+        MMG_TRY(mmg_summary_get_proportions(summ, kind, o.mean.data(), o.probit_mean.data(), o.probit_sd.data(), o.pct.data()));
     };
-    vector<double> meanprop(n), meanprobitprop(n), sdprobitprop(n);
-#pragma omp parallel for schedule(static)
-    for (int64_t t = 0; t < (int64_t)n; t++) {
-        const bool multi = gene2transcripts.find(transcript2gene.find(sid((uint32_t)t))->second)->second.size() > 1;
-        prop_summary(&prop_trace[(size_t)t * trace_length], multi, meanprop[t], meanprobitprop[t], sdprobitprop[t]);
-    }
-    map<string, double> meanprop_simu, meanprobitprop_simu, sdprobitprop_simu;
-    for (auto &s : prop_trace_simu) {
-        const bool multi = gene2transcripts[transcript2gene[s.first]].size() > 1;
-        prop_summary(s.second.data(), multi, meanprop_simu[s.first], meanprobitprop_simu[s.first], sdprobitprop_simu[s.first]);
-    }
-
-    // ---- sd, mcse, iact via Sokal (src/mmseq.cpp:1307-1363)
-    auto sokal_summary = [&](const vector<double> &tr, size_t count, vector<double> &sd, vector<double> &mcse, vector<double> &iact) {
-        sd.resize(count); mcse.resize(count); iact.resize(count);
-#pragma omp parallel for schedule(static)
-        for (int64_t t = 0; t < (int64_t)count; t++) {
-            double var = 0, tau = 0;
-            int mm = 0;
-            if (mmnum::sokal_iact(&tr[(size_t)t * trace_length], trace_length, &var, &tau, &mm) != 0) {
-                mcse[t] = trace_length;
-                iact[t] = NAN;
-            } else {
-                mcse[t] = sqrt(tau * var / trace_length);
-                iact[t] = tau;
-            }
-            sd[t] = sqrt(var);
-        }
-    };
-    vector<double> sd, mumcse, iact, sd_identical, mumcse_identical, iact_identical, sd_gene, mumcse_gene, iact_gene;
-    sokal_summary(mu_trace, n, sd, mumcse, iact);
-    sokal_summary(mu_trace_identical, nI, sd_identical, mumcse_identical, iact_identical);
-    sokal_summary(mu_trace_gene, nG, sd_gene, mumcse_gene, iact_gene);
+    Props pT, pV;
+    fetch_props(MMG_SERIES_TRANSCRIPT, n, pT);
+    fetch_props(MMG_SERIES_VIRTUAL, nV, pV);
+    mmg_summary_destroy(summ);
+    const vector<double> &meanprop = pT.mean, &meanprobitprop = pT.probit_mean, &sdprobitprop = pT.probit_sd;
+    auto pct_row = [&](const vector<double> &pct, size_t i) { return vector<double>(pct.begin() + (ptrdiff_t)(i * nP), pct.begin() + (ptrdiff_t)((i + 1) * nP)); };
 
     const double digalpha = mmnum::digamma(alpha);                 // gsl_sf_psi(alpha)        :1372
     const double sqrtpolygalpha = sqrt(mmnum::trigamma(alpha));    // sqrt(gsl_sf_psi_n(1,.))  :1373
@@ -940,7 +900,7 @@ int main(int argc, char **argv)
         for (size_t i = 0; i < nP; i++) { o << percentiles[i]; o << (i == nP - 1 ? term : ","); }
     };
 
-    stage.mark("summaries (pct, log, sokal)");
+    stage.mark("summary columns");
     // ---- .mmseq (src/mmseq.cpp:1469-1554)
     ofs.open((output_base + ".mmseq").c_str());
     ofs << "# Mapped fragments: " << numbermappedreads << endl;
@@ -956,21 +916,21 @@ int main(int argc, char **argv)
                 << sdprobitprop[t] << "\t" << log(mu_em[t]) << "\t"
                 << "1"
                 << "\t" << gene2transcripts[transcript2gene[name]].size() << "\t";
-            join_pct(ofs, percentiles_transcript[t], "\t");
-            join_pct(ofs, percentiles_prop[t], "\n");
+            join_pct(ofs, pct_row(sT.pct, t), "\t");
+            join_pct(ofs, pct_row(pT.pct, t), "\n");
         } else {
             ofs << name << "\t" << prior_logmu(name) << "\t" << sqrtpolygalpha << "\t"
                 << "0"
                 << "\t"
                 << "1"
-                << "\t" << sidLen[name] << "\t" << sidSeqLen[name] << "\t" << 0 << "\t" << meanprop_simu[name] << "\t"
-                << meanprobitprop_simu[name] << "\t" << sdprobitprop_simu[name] << "\t"
+                << "\t" << sidLen[name] << "\t" << sidSeqLen[name] << "\t" << 0 << "\t" << pV.mean[simuIndex[name]] << "\t"
+                << pV.probit_mean[simuIndex[name]] << "\t" << pV.probit_sd[simuIndex[name]] << "\t"
                 << "NA"
                 << "\t"
                 << "0"
                 << "\t" << gene2transcripts[transcript2gene[name]].size() << "\t";
-            join_pct(ofs, percentiles_simu[name], "\t");
-            join_pct(ofs, percentiles_prop_simu[name], "\n");
+            join_pct(ofs, pct_row(sV.pct, simuIndex[name]), "\t");
+            join_pct(ofs, pct_row(pV.pct, simuIndex[name]), "\n");
         }
     }
     ofs.close(); ofs.clear();
@@ -1000,7 +960,7 @@ int main(int argc, char **argv)
                     << "0"
                     << "\t" << set.size() << "\t";
         }
-        if (fin) join_pct(ofs, percentiles_identical[v], "\n");
+        if (fin) join_pct(ofs, pct_row(sI.pct, v), "\n");
         else for (size_t i = 0; i < nP; i++) ofs << "NA" << (i == nP - 1 ? "\n" : ",");
     }
     ofs.close(); ofs.clear();
@@ -1032,7 +992,7 @@ int main(int argc, char **argv)
                     << "0"
                     << "\t";
             }
-            join_pct(ofs, percentiles_gene[g], "\n");
+            join_pct(ofs, pct_row(sG.pct, g), "\n");
             g++;
         }
     }

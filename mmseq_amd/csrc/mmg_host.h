@@ -40,7 +40,19 @@ struct mmg_problem {
     bool renumbered() const { return !h_int_of_ext.empty(); }
 };
 
+struct mmg_sampler;
+
 namespace mmg {
+
+// what the summary code needs to see of a sampler (sampler.hip)
+struct SamplerView {
+    const mmg_problem *p;
+    mmg_config cfg;
+    const double *d_trace;   // [C][trace_len][n] sample-major, device numbering; nullptr without keep_trace
+    hipStream_t stream;
+    int iter;
+};
+int sampler_view(mmg_sampler *s, SamplerView *v);
 
 int fail(int code, const std::string &msg);   // records the thread-local message behind mmg_last_error(), returns code
 int opt(int option);                          // mmg_selftest_option value, -1 = default

@@ -37,6 +37,13 @@ static void sampler_free(mmg_sampler *s)
     delete s;
 }
 
+int mmg::sampler_view(mmg_sampler *s, SamplerView *v)
+{
+    if (!s || !v) return fail(MMG_ERR_ARG, "NULL argument");
+    v->p = s->p; v->cfg = s->cfg; v->d_trace = s->d_trace; v->stream = s->cur; v->iter = s->iter;
+    return MMG_OK;
+}
+
 extern "C" int mmg_sampler_create(const mmg_problem *p, const mmg_config *cfg, const double *mu0, mmg_sampler **out)
 {
     if (!p || !cfg || !mu0 || !out) return fail(MMG_ERR_ARG, "NULL argument");

@@ -267,6 +267,71 @@ class Sampler:
             pass
 
 
+SERIES_TRANSCRIPT, SERIES_VIRTUAL, SERIES_IDENTICAL, SERIES_GENE = range(4)
+
+
+def _csr(groups):
+    ptr = np.zeros(len(groups) + 1, np.uint64)
+    ptr[1:] = np.cumsum([len(g) for g in groups])
+    mem = np.array([m for g in groups for m in g], np.uint32)
+    return ptr, mem
+
+
+class Summary:
+    """Posterior summary of a sampler's resident trace on the device (mmg_summary_*; src/mmseq.cpp:927-1363).
+    identical / genes: lists of member lists (a member < n: transcript, n + v: virtual transcript v)."""
+
+    def __init__(self, sampler, chain=0, virtual_id=(), virtual_scale=(), identical=(), genes=(), percentile_index=()):
+        from ._lib import SummaryDesc
+        self._lib = _lib.load()
+        self.n = sampler.n
+        self.S = sampler.trace_len
+        vid = np.ascontiguousarray(virtual_id, np.uint64)
+        vsc = np.ascontiguousarray(virtual_scale, np.float64)
+        iptr, imem = _csr(identical)
+        gptr, gmem = _csr(genes)
+        pidx = np.ascontiguousarray(percentile_index, np.int32)
+        self.counts = [self.n, vid.size, len(identical), len(genes)]
+        self.np_ = pidx.size
+        d = SummaryDesc(chain, vid.size, _ptr(vid), _ptr(vsc), len(identical), _ptr(iptr), _ptr(imem), len(genes), _ptr(gptr), _ptr(gmem),
+                        pidx.size, _ptr(pidx))
+        h = C.c_void_p()
+        check(self._lib.mmg_summary_create(sampler._h, C.byref(d), C.byref(h)))
+        self._h = h
+
+    def series(self, kind):
+        c = self.counts[kind]
+        lm, var, tau = np.empty(c), np.empty(c), np.empty(c)
+        rc = np.empty(c, np.int32)
+        pct = np.empty((c, self.np_))
+        check(self._lib.mmg_summary_get(self._h, kind, _ptr(lm), _ptr(var), _ptr(tau), _ptr(rc), _ptr(pct)))
+        return dict(log_mean=lm, var=var, tau=tau, rc=rc, percentiles=pct)
+
+    def proportions(self, kind):
+        c = self.counts[kind]
+        mp, pm, ps = np.empty(c), np.empty(c), np.empty(c)
+        pct = np.empty((c, self.np_))
+        check(self._lib.mmg_summary_get_proportions(self._h, kind, _ptr(mp), _ptr(pm), _ptr(ps), _ptr(pct)))
+        return dict(mean=mp, probit_mean=pm, probit_sd=ps, percentiles=pct)
+
+    def rows(self, kind, first=0, count=None):
+        count = self.S - first if count is None else count
+        out = np.empty((count, self.counts[kind]))
+        check(self._lib.mmg_summary_get_rows(self._h, kind, first, count, _ptr(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mmg_summary_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ---- self-test hooks -----------------------------------------------------------------------
 def selftest_option(option, value):
     """Process-wide override of a choice the library normally makes itself (tests only); value < 0 restores the default."""

@@ -1,0 +1,115 @@
+"""The posterior summary computed on the device (mmg_summary_*, src/mmseq.cpp:927-1363) against numpy and the oracle's Sokal
+(which is pinned to the reference's own sokal.cc): trace sums, proportions, simulated traces and percentiles bit for bit (they
+are sums / quotients in the reference's order and order statistics of the trace itself), log means and Sokal to the rounding of
+log(), probit summaries to the accuracy of AS 241."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(gpu, orc, trace_len, tx_order=False, seed=5):
+    p, _ = orc.synth_problem(R=30000, T=900, avg_hits=5, seed=seed, sort=False)
+    n = p.n
+    rng = np.random.default_rng(seed)
+    txo = None
+    if tx_order:
+        txo = (rng.permutation(n).astype(np.uint64) // np.uint64(3)) << np.uint64(32)
+    prob = gpu.Problem.from_csr(p.row_ptr, p.col_idx, p.l, tx_order=txo)
+    mu0, _ = prob.start_values()
+    s = gpu.Sampler(prob, mu0, seed=31, n_chains=2, gibbs_iter=2 * trace_len, trace_len=trace_len)
+    s.run(2 * trace_len)
+    return prob, s, n, rng
+
+
+@pytest.mark.parametrize("tx_order", [False, True])
+def test_device_summary_matches_numpy_and_the_pinned_sokal(gpu, orc, tx_order):
+    S = 1024
+    prob, s, n, rng = _setup(gpu, orc, S, tx_order)
+    chain = 1
+    trace = s.trace(chain)                                      # [n, S], caller's numbering
+    # 40 isoforms without hits, genes of 1..5 members mixing observed and virtual transcripts, a few identical sets
+    nv = 40
+    vid = (10_000 + np.arange(nv) * 7).astype(np.uint64)
+    vscale = rng.uniform(0.01, 2.0, nv)
+    members = rng.permutation(n + nv)
+    genes, i = [], 0
+    while i < members.size:
+        sz = int(rng.integers(1, 6))
+        genes.append([int(m) for m in members[i:i + sz]])
+        i += sz
+    identical = [[3, 4], [10, 11, 12], [700]]
+    pidx = [int(np.floor(abs(q / 100.0 * (S - 1)) + 0.5)) for q in (5, 25, 50, 75, 95)]   # src/mmseq.cpp:1113
+    q = gpu.Summary(s, chain=chain, virtual_id=vid, virtual_scale=vscale, identical=identical, genes=genes, percentile_index=pidx)
+
+    # simulated traces: the keyed draws of the oracle (src/mmseq.cpp:971-978)
+    V = np.stack([orc.simu_gamma_trace(31, int(vid[v]), 0.1, vscale[v], S) for v in range(nv)])
+    full = np.concatenate([trace, V])                            # member index -> trace
+    t_gene = np.zeros((len(genes), S))
+    for g, ms in enumerate(genes):
+        for m in ms:
+            t_gene[g] += full[m]                                 # same order of additions as :947-1008
+    t_ident = np.zeros((len(identical), S))
+    for g, ms in enumerate(identical):
+        for m in ms:
+            t_ident[g] += full[m]
+    gene_of = np.empty(n + nv, np.int64)
+    for g, ms in enumerate(genes):
+        gene_of[ms] = g
+    prop = full / t_gene[gene_of]
+    assert np.array_equal(q.rows(gpu.SERIES_GENE).T, t_gene)
+    assert np.array_equal(q.rows(gpu.SERIES_IDENTICAL).T, t_ident)
+    assert np.array_equal(q.rows(gpu.SERIES_TRANSCRIPT).T, prop[:n])
+    assert np.array_equal(q.rows(gpu.SERIES_GENE, 17, 5), t_gene[:, 17:22].T)
+
+    def check_series(kind, tr):
+        r = q.series(kind)
+        assert np.array_equal(r["percentiles"], np.sort(tr, axis=1)[:, pidx])
+        with np.errstate(divide="ignore"):
+            lt = np.log(tr)
+        np.testing.assert_allclose(r["log_mean"], lt.mean(axis=1), rtol=1e-12, atol=1e-12)
+        assert (r["rc"] == 0).all()
+        for i in range(0, tr.shape[0], max(1, tr.shape[0] // 150)):
+            rc, var, tau, m = orc.sokal(lt[i])                   # pinned to the reference's compiled sokal.cc (test_oracle_sokal.py)
+            assert rc == 0
+            np.testing.assert_allclose([r["var"][i], r["tau"][i]], [var, tau], rtol=1e-9)
+
+    check_series(gpu.SERIES_TRANSCRIPT, trace)
+    check_series(gpu.SERIES_VIRTUAL, V)
+    check_series(gpu.SERIES_IDENTICAL, t_ident)
+    check_series(gpu.SERIES_GENE, t_gene)
+
+    from scipy.special import ndtri
+    multi = np.array([len(genes[g]) > 1 for g in gene_of])
+    for kind, pr, mu in ((gpu.SERIES_TRANSCRIPT, prop[:n], multi[:n]), (gpu.SERIES_VIRTUAL, prop[n:], multi[n:])):
+        r = q.proportions(kind)
+        assert np.array_equal(r["percentiles"], np.sort(pr, axis=1)[:, pidx])
+        np.testing.assert_allclose(r["mean"], pr.mean(axis=1), rtol=1e-12)
+        z = ndtri(np.clip(pr, 1e-9, 1 - 1e-9))
+        s1, s2 = z.sum(axis=1), (z * z).sum(axis=1)
+        np.testing.assert_allclose(r["probit_mean"][mu], (s1 / S)[mu], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(r["probit_sd"][mu], np.sqrt((s2 - s1 * s1 / S) / (S - 1.0))[mu], rtol=1e-7)
+        assert np.isinf(r["probit_mean"][~mu]).all() and np.isnan(r["probit_sd"][~mu]).all()   # :1243-1262 with a single-transcript gene
+    q.close()
+
+
+def test_summary_edge_shapes(gpu, orc):
+    """No virtual transcripts, no identical sets, a transcript outside every gene, a trace length that is no power of two
+    (Sokal refuses: return code 201 as src/sokal.cc:119-126), percentile index at both ends."""
+    S = 48
+    prob, s, n, rng = _setup(gpu, orc, S, seed=8)
+    genes = [[t for t in range(1, n)]]                           # transcript 0 belongs to no gene
+    q = gpu.Summary(s, chain=0, genes=genes, percentile_index=[0, S - 1])
+    trace = s.trace(0)
+    r = q.series(gpu.SERIES_TRANSCRIPT)
+    assert (r["rc"] == 201).all() and (r["var"] == 0).all()
+    assert np.array_equal(r["percentiles"], np.stack([trace.min(axis=1), trace.max(axis=1)], axis=1))
+    np.testing.assert_allclose(r["log_mean"], np.log(trace).mean(axis=1), rtol=1e-12)
+    pr = q.rows(gpu.SERIES_TRANSCRIPT)
+    assert np.isnan(pr[:, 0]).all() and np.isfinite(pr[:, 1:]).all()
+    tg = np.zeros(S)
+    for t in range(1, n):
+        tg += trace[t]
+    assert np.array_equal(q.rows(gpu.SERIES_GENE)[:, 0], tg)
+    assert q.series(gpu.SERIES_VIRTUAL)["log_mean"].size == 0 and q.rows(gpu.SERIES_IDENTICAL).shape == (S, 0)
+    q.close()
