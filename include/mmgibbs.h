@@ -232,6 +232,29 @@ int mmg_summary_get_proportions(mmg_summary *q, int kind, double *mean_prop, dou
 int mmg_summary_get_rows(mmg_summary *q, int kind, int first_sample, int n_samples, double *out);
 void mmg_summary_destroy(mmg_summary *q);
 
+/* ---- several GPUs of one node, one process (RCCL over xGMI) ----------------------------------------
+ * The reference parallelises with OpenMP threads inside one process (src/mmseq.cpp:834-838, :864); here the unit is a device.
+ * A group owns one RCCL communicator per device (ncclCommInitAll); sampler i of every call below must live on device i of the
+ * group.  RCCL is loaded on first use. */
+typedef struct mmg_group mmg_group;
+int mmg_group_create(const int *devices, int n, mmg_group **out);
+int mmg_group_size(const mmg_group *g, int *n);
+void mmg_group_destroy(mmg_group *g);
+/* Read-shard mode: the samplers hold contiguous ranges of the stored rows of ONE chain (same seed, chain_base, iteration;
+ * row_id_base = offset of the range).  n_iter iterations of: sample on every device (:857-891), ncclAllReduce(int32, sum) of
+ * the count vectors in place (:896-899 across devices), the identical update everywhere (:905-917).  Asynchronous, like
+ * mmg_sampler_run; the chain equals the chain of the unsharded problem bit for bit. */
+int mmg_group_run_sharded(mmg_group *g, mmg_sampler *const *samplers, int n_iter);
+/* Chains mode: every sampler advances its own chains (distinct chain_base) by n_iter iterations; nothing is exchanged. */
+int mmg_group_run_chains(mmg_group *g, mmg_sampler *const *samplers, int n_iter);
+/* ncclAllReduce(fp64, sum) of the posterior moments over the devices (in place: afterwards every sampler's moments hold the
+ * sums over devices), then summed over the chains of a device: sum_log[n], sum_log2[n] (caller's numbering) over n_samples
+ * kept samples of all chains. */
+int mmg_group_pool_moments(mmg_group *g, mmg_sampler *const *samplers, double *sum_log, double *sum_log2, int64_t *n_samples);
+/* Host helper: contiguous row ranges of (nearly) equal hit counts for `parts` shards: bounds[i] = first row of part i (even),
+ * bounds[parts] = m. */
+int mmg_shard_bounds(const uint64_t *row_ptr, uint64_t m, int parts, uint64_t *bounds);
+
 /* int_of_ext[t] = device index of the caller's transcript t (identity without tx_order). */
 int mmg_problem_tx_perm(const mmg_problem *p, uint32_t *int_of_ext);
 

@@ -103,6 +103,13 @@ SYMBOLS = {
     "mmg_summary_get_proportions": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mmg_summary_get_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mmg_summary_destroy": (None, [C.c_void_p]),
+    "mmg_group_create": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "mmg_group_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "mmg_group_destroy": (None, [C.c_void_p]),
+    "mmg_group_run_sharded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "mmg_group_run_chains": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "mmg_group_pool_moments": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+    "mmg_shard_bounds": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]),
     "mmg_host_gamma_trace": (C.c_int, [C.c_uint64, C.c_uint64, C.c_double, C.c_double, C.c_int, C.c_void_p]),
     "mmg_selftest_math": (C.c_int, [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mmg_selftest_philox": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -64,7 +64,10 @@ static void printUsage(ostream &out)
         << "  -debug             output additional diagnostic files" << endl
         << "  -help              print this help message" << endl
         << "  -version           print the version" << endl
-        << "  -device INT        HIP device to run on (default: 0)              [MI355X build]" << endl
+        << "  -device INT        first HIP device to run on (default: 0)        [MI355X build]" << endl
+        << "  -gpus INT          number of devices, device .. device+gpus-1 (default: 1).  With one chain the reads are sharded" << endl
+        << "                     over them (same results as on one device); with -chains >= gpus every device runs chains/gpus chains" << endl
+        << "  -chains INT        independent Gibbs chains (default: 1); log_mu, sd and mcse pool all chains, traces are chain 0's" << endl
         << endl;
 }
 
@@ -267,7 +270,7 @@ int main(int argc, char **argv)
     vector<string> tokens;
     int seed = 1234;
     bool debug = false;
-    int device = 0;
+    int device = 0, gpus = 1, chains = 1;
 
     vector<string> arguments;
     for (int i = 1; i < argc; i++) arguments.push_back(string(argv[i]));
@@ -299,6 +302,12 @@ int main(int argc, char **argv)
         } else if (arguments.size() > 0 && arguments[0] == "-device") {
             need_value(); arguments.erase(arguments.begin());
             device = atoi(arguments[0].c_str()); arguments.erase(arguments.begin());
+        } else if (arguments.size() > 0 && arguments[0] == "-gpus") {
+            need_value(); arguments.erase(arguments.begin());
+            gpus = atoi(arguments[0].c_str()); arguments.erase(arguments.begin());
+        } else if (arguments.size() > 0 && arguments[0] == "-chains") {
+            need_value(); arguments.erase(arguments.begin());
+            chains = atoi(arguments[0].c_str()); arguments.erase(arguments.begin());
         } else if (arguments.size() > 0 && arguments[0] == "-percentiles") {
             need_value(); arguments.erase(arguments.begin());
             tokens.clear();
@@ -343,6 +352,11 @@ int main(int argc, char **argv)
         printUsage(cerr);
         exit(1);
     }
+    if (gpus < 1 || chains < 1 || (gpus > 1 && chains > 1 && chains % gpus != 0)) {
+        cerr << "Error: -gpus and -chains must be positive, and chains a multiple of gpus when both exceed 1.\n";
+        printUsage(cerr);
+        exit(1);
+    }
     if (!powerof2(trace_length)) {
         cerr << "Error: gibbs_iter/gibbs_ss must be a power of 2.\n";
         printUsage(cerr);
@@ -363,7 +377,9 @@ int main(int argc, char **argv)
          << "  seed[0]:       " << seed << endl
          << "  debug:         " << debug << endl
          << "  threads:       " << max_threads << endl
-         << "  device:        " << device << " (HIP, libmmgibbs ABI " << mmg_abi_version() << ")" << endl;
+         << "  device:        " << device << " (HIP, libmmgibbs ABI " << mmg_abi_version() << ")" << endl
+         << "  gpus:          " << gpus << endl
+         << "  chains:        " << chains << endl;
 
     // ---- header (src/mmseq.cpp:332-379)
     map<string, double> sidLen;
@@ -720,22 +736,87 @@ int main(int argc, char **argv)
     const vector<double> mu_em = mu;
 
     stage.mark("EM");
-    // ---- Gibbs on the device (src/mmseq.cpp:833-918); the trace stays there
-    mmg_sampler *smp = nullptr;
+    // ---- Gibbs on the device(s) (src/mmseq.cpp:833-918); the trace stays there.
+    //      one device: `chains` chains in one sampler.  several devices, one chain: the stored rows are cut into contiguous shards
+    //      (mmg_shard_bounds), one per device, counts all-reduced over RCCL every iteration -- bit-identical to the one-device run.
+    //      several devices, chains >= devices: the stored problem is replicated, every device runs chains / gpus chains.
+    vector<mmg_problem *> dprob;   // problems created here (besides prob)
+    vector<mmg_sampler *> smps;
+    mmg_group *grp = nullptr;
     {
         mmg_config cfg;
         memset(&cfg, 0, sizeof cfg);
         cfg.alpha = alpha; cfg.beta = beta; cfg.seed = (uint64_t)(int64_t)seed;
-        cfg.n_chains = 1; cfg.chain_base = 0; cfg.gibbs_iter = gibbs_iter; cfg.trace_len = trace_length;
+        cfg.n_chains = gpus > 1 ? max(1, chains / gpus) : chains; cfg.chain_base = 0; cfg.gibbs_iter = gibbs_iter; cfg.trace_len = trace_length;
         cfg.keep_trace = 1; cfg.timing = 0;
-        MMG_TRY(mmg_sampler_create(prob, &cfg, mu_em.data(), &smp));
+        const bool shard = gpus > 1 && chains == 1;
+        if (gpus == 1) {
+            smps.resize(1);
+            MMG_TRY(mmg_sampler_create(prob, &cfg, mu_em.data(), &smps[0]));
+        } else {
+            vector<int> devs(gpus);
+            for (int i = 0; i < gpus; ++i) devs[i] = device + i;
+            MMG_TRY(mmg_group_create(devs.data(), gpus, &grp));
+            // the rows as the library stores them (its canonical order): shards / replicas keep them as they are
+            mmg_problem_info inf;
+            MMG_TRY(mmg_problem_info_get(prob, &inf));
+            vector<uint64_t> srp(inf.m + 1);
+            vector<uint32_t> sci(inf.nnz), sk(inf.m);
+            MMG_TRY(mmg_problem_download(prob, srp.data(), sci.data(), sk.data()));
+            vector<uint64_t> tx_order(n);
+            {
+                vector<uint32_t> perm(n);
+                MMG_TRY(mmg_problem_tx_perm(prob, perm.data()));
+                for (uint32_t t = 0; t < n; ++t) tx_order[t] = perm[t]; // the same device numbering on every device
+            }
+            vector<uint64_t> bounds(gpus + 1, 0);
+            if (shard) MMG_TRY(mmg_shard_bounds(srp.data(), inf.m, gpus, bounds.data()));
+            smps.resize(gpus);
+            for (int i = 0; i < gpus; ++i) {
+                const uint64_t lo = shard ? bounds[i] : 0, hi = shard ? bounds[i + 1] : inf.m;
+                mmg_problem *pi = prob;
+                if (shard || i > 0) {
+                    vector<uint64_t> rp(hi - lo + 1);
+                    for (size_t r = 0; r < rp.size(); ++r) rp[r] = srp[lo + r] - srp[lo];
+                    mmg_problem_desc pd;
+                    memset(&pd, 0, sizeof pd);
+                    pd.m = hi - lo; pd.n = n; pd.row_ptr = rp.data(); pd.col_idx = sci.data() + srp[lo]; pd.k = sk.data() + lo; pd.l = l.data();
+                    pd.row_id_base = lo; pd.layout = MMG_LAYOUT_KEEP_ROWS; pd.tx_order = tx_order.data();
+                    MMG_TRY(mmg_problem_create(&pd, devs[i], &pi));
+                    dprob.push_back(pi);
+                }
+                mmg_config ci = cfg;
+                ci.chain_base = shard ? 0 : i * cfg.n_chains;
+                MMG_TRY(mmg_sampler_create(pi, &ci, mu_em.data(), &smps[i]));
+            }
+        }
         const int chunk = max(1, gibbs_iter / 16);
         for (int done = 0; done < gibbs_iter; done += chunk) {
             cout << "Gibbs iteration " << done << "       \r" << flush;
-            MMG_TRY(mmg_sampler_run(smp, min(chunk, gibbs_iter - done)));
-            MMG_TRY(mmg_sampler_sync(smp));
+            const int it = min(chunk, gibbs_iter - done);
+            if (gpus == 1) MMG_TRY(mmg_sampler_run(smps[0], it));
+            else if (gpus > 1 && chains == 1) MMG_TRY(mmg_group_run_sharded(grp, smps.data(), it));
+            else MMG_TRY(mmg_group_run_chains(grp, smps.data(), it));
+            for (auto sp : smps) MMG_TRY(mmg_sampler_sync(sp));
         }
         cout << "Gibbs iteration " << gibbs_iter - 1 << "       \r" << endl;
+    }
+    mmg_sampler *smp = smps[0]; // traces and per-feature summaries come from chain 0 (every shard holds the whole chain)
+    // moments of log mu pooled over all chains and devices (one fp64 all-reduce): log_mu, sd and mcse of multi-chain runs
+    vector<double> pooled_sl, pooled_sl2;
+    int64_t pooled_ns = 0;
+    if (chains > 1) {
+        pooled_sl.resize(n); pooled_sl2.resize(n);
+        if (grp) MMG_TRY(mmg_group_pool_moments(grp, smps.data(), pooled_sl.data(), pooled_sl2.data(), &pooled_ns));
+        else {
+            vector<double> a_(n), b_(n);
+            for (int c = 0; c < chains; ++c) {
+                int64_t ns = 0;
+                MMG_TRY(mmg_sampler_get_moments(smp, c, a_.data(), b_.data(), &ns));
+                for (uint32_t t = 0; t < n; ++t) { pooled_sl[t] += a_[t]; pooled_sl2[t] += b_[t]; }
+                pooled_ns += ns;
+            }
+        }
     }
     stage.mark("Gibbs");
 
@@ -794,8 +875,10 @@ int main(int argc, char **argv)
                          [](size_t) { return true; });
         gz.close();
     }
-    mmg_sampler_destroy(smp);
+    for (auto sp : smps) mmg_sampler_destroy(sp);
+    for (auto pp : dprob) mmg_problem_destroy(pp);
     mmg_problem_destroy(prob);
+    if (grp) mmg_group_destroy(grp);
     stage.mark("write .trace_gibbs.gz");
     {
         // a set / gene whose first summed sample has no finite logarithm is left out of its trace file (:1040, :1068)
@@ -849,6 +932,15 @@ int main(int argc, char **argv)
     };
     Series sT, sV, sI, sG;
     fetch_series(MMG_SERIES_TRANSCRIPT, n, sT);
+    if (chains > 1 && pooled_ns > 1) { // all chains: mean and sd of log mu from the pooled moments, Monte Carlo error of the pooled mean
+        for (uint32_t t = 0; t < n; ++t) {
+            const double mean = pooled_sl[t] / (double)pooled_ns;
+            const double var = (pooled_sl2[t] - (double)pooled_ns * mean * mean) / (double)(pooled_ns - 1);
+            sT.mean[t] = mean;
+            sT.sd[t] = sqrt(var > 0 ? var : 0.0);
+            sT.mcse[t] = sT.mcse[t] / sqrt((double)chains);
+        }
+    }
     fetch_series(MMG_SERIES_VIRTUAL, nV, sV);
     fetch_series(MMG_SERIES_IDENTICAL, nI, sI);
     fetch_series(MMG_SERIES_GENE, nG, sG);

@@ -267,6 +267,53 @@ class Sampler:
             pass
 
 
+def shard_bounds(row_ptr, parts):
+    """mmg_shard_bounds: first rows of `parts` contiguous shards of (nearly) equal hit counts, even boundaries."""
+    row_ptr = np.ascontiguousarray(row_ptr, np.uint64)
+    out = np.empty(parts + 1, np.uint64)
+    check(_lib.load().mmg_shard_bounds(_ptr(row_ptr), row_ptr.size - 1, parts, _ptr(out)))
+    return out
+
+
+class Group:
+    """Several GPUs of this node driven from one process over RCCL (mmg_group_*); samplers[i] lives on devices[i]."""
+
+    def __init__(self, devices):
+        self._lib = _lib.load()
+        devs = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        check(self._lib.mmg_group_create(devs, len(devices), C.byref(h)))
+        self._h = h
+        self.size = len(devices)
+
+    def _arr(self, samplers):
+        assert len(samplers) == self.size
+        return (C.c_void_p * self.size)(*[s._h for s in samplers])
+
+    def run_sharded(self, samplers, n_iter):
+        check(self._lib.mmg_group_run_sharded(self._h, self._arr(samplers), n_iter))
+
+    def run_chains(self, samplers, n_iter):
+        check(self._lib.mmg_group_run_chains(self._h, self._arr(samplers), n_iter))
+
+    def pool_moments(self, samplers):
+        n = samplers[0].n
+        sl, sl2, ns = np.empty(n), np.empty(n), C.c_int64(0)
+        check(self._lib.mmg_group_pool_moments(self._h, self._arr(samplers), _ptr(sl), _ptr(sl2), C.byref(ns)))
+        return sl, sl2, ns.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mmg_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 SERIES_TRANSCRIPT, SERIES_VIRTUAL, SERIES_IDENTICAL, SERIES_GENE = range(4)
 
 

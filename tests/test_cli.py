@@ -297,3 +297,40 @@ def test_config1_plumbing_text_and_binary_agree(tmp_path, gpu, orc):
     for got, exp in zip(tab, e["transcripts"]):
         for col in ("log_mu", "sd", "mcse", "iact", "unique_hits", "log_mu_em", "observed", "mean_proportion"):
             assert _same_number(got[col], exp[col]), (got["feature_id"], col, got[col], exp[col])
+
+
+@pytest.mark.gpu
+def test_chains_flag_pools_moments_and_keeps_chain0_traces(tmp_path, gpu):
+    """-chains 4 on one device: chain 0 is the single-chain run (same traces, percentiles, iact), log_mu / sd pool the four
+    chains (close to chain 0's within Monte Carlo error, mcse halved), -gpus 1 is accepted, bad combinations are refused."""
+    h = dataset(seed=11, n_reads=3000)
+    p = tmp_path / "in.hits"
+    p.write_bytes(H.write_hits_binary(h))
+    o1, o4 = str(tmp_path / "c1"), str(tmp_path / "c4")
+    assert run(["-gibbs_iter", "1024", str(p), o1], timeout=300).returncode == 0
+    r = run(["-gibbs_iter", "1024", "-chains", "4", "-gpus", "1", str(p), o4], timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    assert b"chains:        4" in r.stdout
+    for ext in (".trace_gibbs.gz", ".gene.trace_gibbs.gz", ".prop.trace_gibbs.gz"):
+        assert gzip.open(o1 + ext, "rb").read() == gzip.open(o4 + ext, "rb").read()
+    _, ghdr, g1 = _table(o1 + ".gene.mmseq")
+    _, _, g4 = _table(o4 + ".gene.mmseq")
+    for a, b in zip(g1, g4):                          # gene rows are chain 0's, except the expression-weighted length (pooled log_mu)
+        assert all(a[c] == b[c] for c in ghdr if c != "effective_length")
+        assert abs(float(a["effective_length"]) - float(b["effective_length"])) <= 0.05 * float(a["effective_length"])
+    _, hdr, t1 = _table(o1 + ".mmseq")
+    _, _, t4 = _table(o4 + ".mmseq")
+    n_obs = 0
+    for a, b in zip(t1, t4):
+        assert a["feature_id"] == b["feature_id"] and a["iact"] == b["iact"] and a[hdr[14]] == b[hdr[14]]
+        if a["observed"] == "1":
+            n_obs += 1
+            sd = float(a["sd"])
+            assert abs(float(a["log_mu"]) - float(b["log_mu"])) <= 6 * max(float(a["mcse"]), 1e-3 * sd) + 1e-6
+            assert 0.7 * sd <= float(b["sd"]) <= 1.4 * sd
+            assert abs(float(b["mcse"]) - float(a["mcse"]) / 2) <= 1e-4 * float(a["mcse"]) + 1e-12
+        else:
+            assert a == b
+    assert n_obs > 20
+    r = run(["-gpus", "2", "-chains", "3", str(p), str(tmp_path / "x")])
+    assert r.returncode == 1 and b"chains a multiple of gpus" in r.stderr

@@ -1,0 +1,73 @@
+"""Multi-GPU from the C++ side (mmg_group_*, RCCL behind the C ABI).  CPU: the shard arithmetic (mmg_shard_bounds) at world
+sizes 2..8 and the loud failure without a device.  GPU: the native test binary (tests/native/test_group.cpp, no Python or torch
+in the process) -- read-shard chain over a group bit-identical to the unsharded chain, pooled moments -- plus the same entry
+points through ctypes."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "mmseq_amd", "csrc", "test_group")
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_shard_bounds_cover_rows_once_and_balance_hits(orc, world):
+    from mmseq_amd import gibbs
+    from mmseq_amd import dist as mdist
+    p, _ = orc.synth_problem(R=50000, T=3000, avg_hits=8, seed=2)
+    b = gibbs.shard_bounds(p.row_ptr, world)
+    assert b[0] == 0 and b[-1] == p.m and (np.diff(b.astype(np.int64)) >= 0).all()
+    assert (b[:-1] % 2 == 0).all()                       # shards start on even rows: a Philox block (rows 2q, 2q+1) stays on one device
+    hits = np.diff(p.row_ptr[b.astype(np.int64)].astype(np.int64))
+    assert abs(hits / p.nnz - 1.0 / world).max() < 0.01
+    # the sharded count vectors add up to the unsharded one (the all-reduce), with the oracle standing in for the devices
+    mu0, _ = orc.start_values(p)
+    ref = orc.sample_counts(p, mu0, 7, 0, 3)
+    tot = np.zeros_like(ref)
+    for i in range(world):
+        lo, hi = int(b[i]), int(b[i + 1])
+        nz0, nz1 = int(p.row_ptr[lo]), int(p.row_ptr[hi])
+        q = orc.Problem(p.row_ptr[lo:hi + 1] - p.row_ptr[lo], p.col_idx[nz0:nz1], p.l)
+        tot += orc.sample_counts(q, mu0, 7, 0, 3, row_id_base=lo)
+    assert np.array_equal(tot, ref)
+    # the Python mirror's plain row split covers the rows once as well
+    cover = [mdist.row_shard(p.m, r, world) for r in range(world)]
+    assert cover[0][0] == 0 and cover[-1][1] == p.m and all(a[1] == c[0] for a, c in zip(cover, cover[1:]))
+
+
+def test_group_needs_a_device():
+    from mmseq_amd import gibbs
+    from mmseq_amd._lib import MMGError
+    if gibbs.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(MMGError) as e:
+        gibbs.Group([0])
+    assert e.value.code == 2
+
+
+@pytest.mark.gpu
+def test_native_group_binary(gpu):
+    assert os.path.exists(BIN), "test_group not built (make -C mmseq_amd/csrc)"
+    r = subprocess.run([BIN], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stdout.decode() + r.stderr.decode()
+    assert b"read-shard chain bit-identical to the unsharded chain" in r.stdout
+
+
+@pytest.mark.gpu
+def test_group_through_ctypes(gpu, orc):
+    p, _ = orc.synth_problem(R=30000, T=1200, avg_hits=6, seed=4)
+    mu0, _ = orc.start_values(p)
+    prob = gpu.Problem.from_csr(p.row_ptr, p.col_idx, p.l)
+    grp = gpu.Group([0])
+    s = gpu.Sampler(prob, mu0, seed=5, n_chains=2, gibbs_iter=16, trace_len=16)
+    grp.run_sharded([s], 16)
+    for c in range(2):
+        ref = orc.gibbs_keyed(p, mu0, seed=5, chain=c, n_iter=16, trace_len=16)
+        assert np.array_equal(s.trace(c), ref["trace"])
+    sl, sl2, ns = grp.pool_moments([s])
+    a0, b0, _ = s.moments(0)
+    a1, b1, _ = s.moments(1)
+    assert ns == 32 and np.array_equal(sl, a0 + a1) and np.array_equal(sl2, b0 + b1)
+    grp.close()
