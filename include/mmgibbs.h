@@ -165,7 +165,8 @@ void mmg_problem_destroy(mmg_problem *p);
 /* mu0: n doubles (every chain starts there, like mu = EM optimum at src/mmseq.cpp:820). */
 int mmg_sampler_create(const mmg_problem *p, const mmg_config *cfg, const double *mu0, mmg_sampler **out);
 /* Launch on a caller-owned hipStream_t (e.g. the framework's current stream) instead of
- * the sampler's own stream. NULL restores the own stream. */
+ * the sampler's own stream.  NULL restores the own stream (a non-blocking stream: NOT ordered against the legacy
+ * default stream); to run on the legacy default stream itself pass hipStreamLegacy, (void *)1. */
 int mmg_sampler_set_stream(mmg_sampler *s, void *hip_stream);
 /* n_iter full Gibbs iterations = src/mmseq.cpp:851-918 (sample+scatter, gamma redraw,
  * trace capture), enqueued asynchronously. */

@@ -29,8 +29,12 @@ def devptr_tensor(ptr, count, dtype):
 
 
 def use_current_stream(sampler):
+    """Launch the sampler's kernels on torch's current stream, so that collectives issued through torch are ordered after them.
+    torch's default stream is the legacy NULL stream (handle 0), which the C ABI reserves for "the sampler's own stream":
+    it is passed as hipStreamLegacy (1)."""
     import torch
-    sampler.set_stream(torch.cuda.current_stream().cuda_stream)
+    h = torch.cuda.current_stream().cuda_stream
+    sampler.set_stream(h if h else 1)
 
 
 def counts_tensor(sampler):
@@ -47,10 +51,16 @@ def moments_tensor(sampler):
 
 def shard_step(sampler, counts, group=None):
     """One read-sharded Gibbs iteration: local sample, all-reduce counts, identical update."""
+    import torch
     import torch.distributed as dist
     sampler.sample()
     if dist.is_initialized() and dist.get_world_size(group) > 1:
+        staged = dist.get_backend(group) != "nccl"     # gloo moves CUDA tensors through the host on streams of its own
+        if staged:
+            torch.cuda.current_stream().synchronize()
         dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+        if staged:
+            torch.cuda.synchronize()
     sampler.update()
 
 
