@@ -262,7 +262,8 @@ def main():
         pmc = pmc_counters(args.rows, args.transcripts, args.avg_hits, 1, kname)
         t_k1 = k1_ms * 1e-3
         traffic = (pmc["hbm_read_bytes_per_launch"] + pmc["hbm_write_bytes_per_launch"]) if pmc else None
-        passes = pmc.get("valu_issue_passes_per_launch") if pmc else None
+        # VALU issue passes: every instruction one pass, the quarter-rate Philox multiplies three more (5 per register-path tile)
+        passes = (pmc["valu_insts_per_launch"] + 3 * pmc["quarter_rate_valu_per_fast_tile"] * inf.fast_tiles) if pmc and "valu_insts_per_launch" in pmc else None
         ach = passes / t_k1 / 1e9 if passes else None
         out = {
             "metric": "gibbs_iterations_per_sec", "value": iters_per_s, "unit": "iterations/s",
@@ -289,11 +290,15 @@ def main():
                          "padded_slots_per_hit": (inf.padded_slots / inf.nnz) if inf.nnz else None,
                          "avg_launch_ms": k1_ms, "timed_launches": tm["sample_launches"] * C,
                          "valu_issue_passes_per_launch": passes,
+                         "instructions_per_64_row_tile": ({k[9:].lower(): round(v / max(inf.n_tiles, 1), 1) for k, v in pmc["counters_per_launch"].items()
+                                                           if k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_INSTS_SMEM")}
+                                                          if pmc else None),
                          "pmc_source": (pmc or {}).get("source"),
-                         "note": "bound by VALU issue (Philox2x32-10, fp64 prefix walk, pick sweep), not by HBM: frac = counted VALU "
-                                 "issue passes / (1024 SIMDs x 2.4 GHz / 4) / time; hbm_frac = PMC HBM bytes / time / 8 TB/s; "
-                                 "algorithmic_x_peak = SURVEY 8(d) u32-CSR bytes / time / 8 TB/s (> 1: the kernel streams a 1.1 B/hit "
-                                 "encoding, not the CSR).  PMC figures are null when profiles/pmc_counters.json was collected on other kernel sources",
+                         "note": "bound by instruction issue, not by HBM: a wave issues one instruction per 4-clock slot and a 64-row tile "
+                                 "costs ~140 VALU + ~150 scalar/branch + ~30 LDS instructions; frac = counted VALU issue passes / "
+                                 "(1024 SIMDs x 2.4 GHz / 4) / time; hbm_frac = PMC HBM bytes / time / 8 TB/s; algorithmic_x_peak = SURVEY "
+                                 "8(d) u32-CSR bytes / time / 8 TB/s (> 1: the kernel streams a 1.1 B/hit encoding, not the CSR).  PMC "
+                                 "figures are null when profiles/pmc_counters.json was collected on other kernel sources",
                          "k_update_avg_launch_ms": k2_ms, "sweep_bytes": b_sweep},
         }
         if world == 1 and not args.no_extra:

@@ -9,6 +9,11 @@ import sys, json
 sys.path.insert(0, %r)
 from mmseq_amd import _lib
 _lib.LIB_PATH = sys.argv[1]
+import ctypes
+_probe = ctypes.CDLL(sys.argv[1])
+for _name in list(_lib.SYMBOLS):          # older builds export fewer entry points: bind what is there
+    if not hasattr(_probe, _name):
+        del _lib.SYMBOLS[_name]
 from mmseq_amd import Problem, Sampler
 R, T, A, C = int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), int(sys.argv[5])
 prob = Problem.synthetic(R, T, A, seed=1234)
