@@ -270,8 +270,7 @@ __global__ __launch_bounds__(64 * W) void k_em_sell(const IdxT *__restrict__ row
         const uint8_t *__restrict__ blk = stream + (fast ? d.off16 * 16 : 0);
         bf.len = blk[lane];
         if (HAS_K) bf.kk = kmult[(fast ? d.r0 : 0) + min(lane, (fast ? d.nrows() : 1u) - 1u)];
-        const uint32_t last = fast ? d.ng() - 1u : 0u;
-#define EMS_ISSUE(i) bf.g##i = __builtin_nontemporal_load((const uint32_t *)(blk + 64 + (size_t)min((uint32_t)i, last) * 256) + lane);
+#define EMS_ISSUE(i) bf.g##i = __builtin_nontemporal_load((const uint32_t *)(blk + 64 + (size_t)i * 256) + lane);
         EMS_GROUPS(EMS_ISSUE)
 #undef EMS_ISSUE
     };

@@ -63,7 +63,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 1 : 
 
     const uint64_t t_begin = chunk_tile[blockIdx.x], t_end = chunk_tile[blockIdx.x + 1];
     if (t_begin >= t_end) return;
-    const uint64_t nt = t_end - t_begin;
+    // a range holds fewer than 2^31 tiles: 32-bit scalar loop arithmetic
+    const uint32_t nt = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(t_end - t_begin));
     const SellTile *__restrict__ T = tiles + t_begin;
 
     for (int i = lane; i < REP * (WIN + 1); i += 64) s_cnt[i] = 0;
@@ -100,18 +101,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 1 : 
         uint32_t len;
         uint32_t kk; // multiplicity of the lane's row (HAS_K)
     };
-    // request a tile's block: the lane's length byte and its first NGC groups (clamped, unconditional)
-    // UNCONDITIONAL: tiles without a block (empty, slow, past the end of the range) read the head of the stream instead.
-    // Loads retire in order and are waited for by count, so the number issued per tile must not depend on the path --
-    // otherwise the compiler has to assume the fewest, and every walk waits for the prefetch issued just before it.
+    // request a tile's block: the lane's length byte and NGC groups, UNCONDITIONALLY (tiles without a block -- empty, slow, past
+    // the end of the range -- read the head of the stream instead).  Loads retire in order and are waited for by count, so the
+    // number issued per tile must not depend on the path -- otherwise the compiler has to assume the fewest, and every walk
+    // waits for the prefetch issued just before it.  Groups beyond the tile's ng are simply the first groups of the NEXT block
+    // (the stream has NGC groups of head room behind its last block): one base address and immediate offsets, no scalar
+    // arithmetic per group.  Clamping them to the last group saved a quarter of the HBM traffic and cost 10 % of the time.
     auto issue = [&](const SellTile &d, Buf &bf) {
         const bool fast = d.flags() & SELL_FAST; // uniform
         const uint8_t *__restrict__ blk = stream + (fast ? d.off16 * 16 : 0);
         bf.len = blk[lane];
         if (HAS_K) bf.kk = kmult[(fast ? d.r0 : 0) + min(lane, (fast ? d.nrows() : 1u) - 1u)];
-        const uint32_t last = fast ? d.ng() - 1u : 0u;
-        // scalar base per group + one shared lane offset: the loads use the SGPR-base addressing form
-#define SELL_ISSUE(i) bf.g##i = __builtin_nontemporal_load((const uint32_t *)(blk + 64 + (size_t)min((uint32_t)i, last) * 256) + lane);
+#define SELL_ISSUE(i) bf.g##i = __builtin_nontemporal_load((const uint32_t *)(blk + 64 + (size_t)i * 256) + lane);
         SELL_GROUPS(SELL_ISSUE)
 #undef SELL_ISSUE
     };
@@ -124,7 +125,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 1 : 
         const uint64_t qa = (a.row_id_base + A.r0) >> 1, qb = (a.row_id_base + B.r0) >> 1; // uniform
         const uint32_t l5 = lane & 31u;
         uint32_t x0, x1;
-        if ((uint32_t)(qa >> 32) == (uint32_t)(qb >> 32) && (uint32_t)qa <= 0xffffffe0u && (uint32_t)qb <= 0xffffffe0u) {
+        // one key for the whole wave unless a multiple of 2^33 row ids lies between the first row of A and the last of B
+        if ((((a.row_id_base + A.r0) ^ (a.row_id_base + B.r0 + 63u)) >> 33) == 0 && A.r0 <= B.r0) {
             // the usual case: one key for the whole wave, kept in scalar registers
             const uint32_t key = stream2_key(a.seed, a.chain, TAG_ROW, (uint32_t)(qa >> 32));
             x0 = (lane < 32u ? (uint32_t)qa : (uint32_t)qb) + l5;
@@ -152,16 +154,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 1 : 
         const uint32_t L = bf.len;
         const uint32_t xrow = which ? xrowB : xrowA;
         double t = 0.0;
-#define SELL_SUM(i)                                                                                          \
-        if ((uint32_t)i < ng) {                                                                              \
+        // Tiles of four or more groups (most: rows are sorted by length) run their first four groups without the per-group
+        // test: a wave issues one instruction per slot, scalar compares and branches included, and they were a third of a tile's
+        // instructions.
+        double P0, P1, P2, P3, P4, P5, P6, P7;
+#define SELL_ADD(i)                                                                                          \
+        {                                                                                                    \
             const uint32_t v = bf.g##i;                                                                      \
             const double w0 = wo(SELL_OFF0(v)), w1 = wo(SELL_OFF1(v)), w2 = wo(SELL_OFF2(v)), w3 = wo(SELL_OFF3(v)); \
             if (i == 0) t = w0; else t += w0; /* 0.0 + w0 == w0 exactly */                                   \
             t += w1; t += w2; t += w3;                                                                       \
-        }                                                                                                    \
-        const double P##i = t;
-        SELL_GROUPS(SELL_SUM)
-#undef SELL_SUM
+        }
+#define SELL_SUM_U(i) SELL_ADD(i) P##i = t;
+#define SELL_SUM_C(i) if ((uint32_t)i < ng) SELL_ADD(i) P##i = t;
+        if (ng >= 4) {
+            SELL_SUM_U(0) SELL_SUM_U(1) SELL_SUM_U(2) SELL_SUM_U(3)
+            SELL_SUM_C(4) SELL_SUM_C(5) SELL_SUM_C(6) SELL_SUM_C(7)
+        } else {
+            SELL_SUM_C(0) SELL_SUM_C(1) SELL_SUM_C(2)
+            P3 = t; P4 = t; P5 = t; P6 = t; P7 = t;
+        }
+#undef SELL_SUM_U
+#undef SELL_SUM_C
+#undef SELL_ADD
 #pragma unroll 1
         for (uint32_t g = NGC; g < ng; ++g) { // rows of more than 4 * NGC hits: rare, keep it small
             const uint32_t v = src[(size_t)g * 64];
@@ -283,7 +298,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 1 : 
 
     SellTile none;
     none.off16 = 0; none.r0 = 0; none.wbase = 0; none.meta = sell_meta(0, 0, SELL_EMPTY);
-    auto tile_at = [&](uint64_t i) { return i < nt ? T[i] : none; };
+    // past the end of the range: the last descriptor re-read (one unconditional scalar load per tile) and marked empty
+    auto tile_at = [&](uint32_t i) {
+        SellTile d = T[min(i, nt - 1u)];
+        d.meta = i < nt ? d.meta : none.meta;
+        return d;
+    };
 
     SellTile dA = tile_at(0), dB = tile_at(1);
     Buf bufA, bufB; // A: even tiles of the range, B: odd tiles
@@ -294,7 +314,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 1 : 
     __syncthreads();
     issue(dA, bufA);
     issue(dB, bufB);
-    for (uint64_t i = 0; i < nt; i += 2) {
+    for (uint32_t i = 0; i < nt; i += 2) {
         const SellTile nA = tile_at(i + 2), nB = tile_at(i + 3); // scalar loads: in flight while A and B are walked
         if (!HAS_K) pair_rng(dA, dB);
         process(dA, cur_base, nA, bufA, 0);
