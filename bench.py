@@ -42,9 +42,14 @@ KERNEL_SOURCES = ["mmg_math.h", "mmg_types.h", "gibbs_kernels.h", "sell_kernels.
 
 
 def kernel_hash():
+    """Hash of the K1 kernel sources with comments and white space removed (what the compiler sees)."""
+    import re
     h = hashlib.sha256()
     for f in KERNEL_SOURCES:
-        h.update(open(os.path.join(ROOT, "mmseq_amd", "csrc", f), "rb").read())
+        src = open(os.path.join(ROOT, "mmseq_amd", "csrc", f)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        src = re.sub(r"//[^\n]*", "", src)
+        h.update(re.sub(r"\s+", "", src).encode())
     return h.hexdigest()[:16]
 
 

@@ -273,7 +273,8 @@ enum {
     MMG_OPT_SELL_WAVES_PER_CU = 2, /* cap on resident single-wave workgroups per CU (long tile ranges on small inputs) */
     MMG_OPT_EM_KERNEL = 3,         /* 0: row-per-thread EM kernel, 2: sliced-ELL EM kernel                           */
     MMG_OPT_EM_GRID = 4,           /* cap on the EM kernel's grid                                                    */
-    MMG_OPT_COUNT_ = 5
+    MMG_OPT_FUSE_CHAINS = 5,       /* chains advanced per K1 launch: 1 (never fuse), 2 (the default), 4              */
+    MMG_OPT_COUNT_ = 6
 };
 int mmg_selftest_option(int option, int value);
 /* Evaluates the library's own log / exp / sqrt / 1/x on x[0..n) (device >= 0: in a kernel

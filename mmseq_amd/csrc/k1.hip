@@ -1,6 +1,7 @@
 // k1.hip -- device TU: the sample kernels (src/mmseq.cpp:857-891) and the builders of their streams
 #include "gibbs_kernels.h"
 #include "sell_kernels.h"
+#include "sell_multi_kernels.h"
 #include "mmg_launch.h"
 
 namespace mmg {
@@ -9,6 +10,13 @@ const void *k1_sell_kernel(bool idx64, bool has_k)
 {
     if (idx64) return has_k ? (const void *)k_sample_sell<uint64_t, true, 8> : (const void *)k_sample_sell<uint64_t, false, 8>;
     return has_k ? (const void *)k_sample_sell<uint32_t, true, 8> : (const void *)k_sample_sell<uint32_t, false, 8>;
+}
+
+const void *k1_sell_multi_kernel(bool idx64, int nch)
+{
+    if (nch == 2) return idx64 ? (const void *)k_sample_sell_multi<uint64_t, 2> : (const void *)k_sample_sell_multi<uint32_t, 2>;
+    if (nch == 4) return idx64 ? (const void *)k_sample_sell_multi<uint64_t, 4> : (const void *)k_sample_sell_multi<uint32_t, 4>;
+    return nullptr;
 }
 
 const void *k1_csr_kernel(bool idx64, bool has_k)

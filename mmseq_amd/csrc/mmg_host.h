@@ -29,6 +29,8 @@ struct mmg_problem {
     mmg::SellTile *d_sell_tiles = nullptr;
     uint64_t *d_sell_chunk = nullptr;
     int grid_sell = 0;
+    uint64_t *d_sell_chunk_m[2] = {nullptr, nullptr}; // tile ranges of the fused-chain kernels (2 and 4 chains: fewer resident waves)
+    int grid_sell_m[2] = {0, 0};
     bool use_sell = false;
     std::vector<uint64_t> h_sell_cum;           // cumulative tile cost, kept for the EM kernel's own ranges
     // CSR tiles of the fallback kernel k_sample (built only when the sliced-ELL stream is not used)

@@ -28,7 +28,7 @@ extern "C" const char *mmg_last_error(void) { return g_err.c_str(); }
 extern "C" int mmg_abi_version(void) { return MMG_ABI_VERSION; }
 
 // self-test overrides (mmg_selftest_option): -1 = the library decides
-static std::atomic<int> g_opt[MMG_OPT_COUNT_] = {{-1}, {-1}, {-1}, {-1}, {-1}};
+static std::atomic<int> g_opt[MMG_OPT_COUNT_] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
 int mmg::opt(int o) { return g_opt[o].load(std::memory_order_relaxed); }
 extern "C" int mmg_selftest_option(int option, int value)
 {
@@ -80,7 +80,8 @@ static void problem_free(mmg_problem *p)
     if (!p) return;
     (void)hipSetDevice(p->device);
     for (void *x : {(void *)p->d_row_ptr, (void *)p->d_col, (void *)p->d_k, (void *)p->d_l, (void *)p->d_int_of_ext, (void *)p->d_ext_of_int,
-                    (void *)p->d_sell, (void *)p->d_sell_tiles, (void *)p->d_sell_chunk, (void *)p->d_tiles, (void *)p->d_chunk_tile,
+                    (void *)p->d_sell, (void *)p->d_sell_tiles, (void *)p->d_sell_chunk, (void *)p->d_sell_chunk_m[0], (void *)p->d_sell_chunk_m[1],
+                    (void *)p->d_tiles, (void *)p->d_chunk_tile,
                     (void *)p->d_colcnt})
         if (x) (void)hipFree(x);
     delete p;
@@ -193,6 +194,20 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
     HIP_TRY(hipMemcpy(p->d_sell_tiles, st.data(), nt * sizeof(SellTile), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void **)&p->d_sell_chunk, chunk.size() * sizeof(uint64_t)));
     HIP_TRY(hipMemcpy(p->d_sell_chunk, chunk.data(), chunk.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    if (!p->d_k) { // fused-chain kernels: their own (fewer, longer) tile ranges over the same tiles
+        for (int q = 0; q < 2; ++q) {
+            int pc = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, k1_sell_multi_kernel(p->idx64, 2 << q), 64, 0) != hipSuccess || pc < 1) { (void)hipGetLastError(); pc = 8; }
+            if (pc > 32) pc = 32;
+            if (opt(MMG_OPT_SELL_WAVES_PER_CU) >= 1 && opt(MMG_OPT_SELL_WAVES_PER_CU) < pc) pc = opt(MMG_OPT_SELL_WAVES_PER_CU);
+            const uint64_t gq = std::max<uint64_t>(1, std::min<uint64_t>(nt, (uint64_t)p->cu_count * pc));
+            std::vector<uint64_t> cq;
+            weighted_chunks(p->h_sell_cum, gq, cq);
+            HIP_TRY(hipMalloc((void **)&p->d_sell_chunk_m[q], cq.size() * sizeof(uint64_t)));
+            HIP_TRY(hipMemcpy(p->d_sell_chunk_m[q], cq.data(), cq.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+            p->grid_sell_m[q] = (int)gq;
+        }
+    }
     launch_encode_sell(p->idx64, p->d_row_ptr, p->d_col, p->d_sell_tiles, nt, p->d_sell, 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());

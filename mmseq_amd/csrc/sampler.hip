@@ -119,7 +119,16 @@ extern "C" int mmg_sampler_sample(mmg_sampler *s)
         HIP_TRY(hipEventRecord(s->ev_pool[e0], s->cur));
     }
     if (p->m > 0) {
-        for (int c = 0; c < s->cfg.n_chains; ++c) {
+        for (int c = 0; c < s->cfg.n_chains;) {
+            // chains are advanced in fused pairs where the fused kernel exists (sliced-ELL stream, no multiplicities).  Measured at
+            // config 3 with 8 chains: 3190 chain-iterations/s one chain per launch, 3640 in pairs (111 VGPRs, 4 waves per SIMD),
+            // 2820 in fours (175 VGPRs, 2 waves per SIMD): fours exist for tests and experiments only (MMG_OPT_FUSE_CHAINS).
+            int fuse = 1;
+            if (p->use_sell && !p->d_k && opt(MMG_OPT_FUSE_CHAINS) != 1) {
+                const int cap = opt(MMG_OPT_FUSE_CHAINS) > 0 ? opt(MMG_OPT_FUSE_CHAINS) : 2;
+                if (cap >= 4 && c + 4 <= s->cfg.n_chains && p->grid_sell_m[1] > 0) fuse = 4;
+                else if (cap >= 2 && c + 2 <= s->cfg.n_chains && p->grid_sell_m[0] > 0) fuse = 2;
+            }
             SampleArgs a;
             a.seed = s->cfg.seed; a.row_id_base = p->row_id_base; a.n = p->n;
             a.chain = (uint32_t)(s->cfg.chain_base + c);
@@ -128,7 +137,13 @@ extern "C" int mmg_sampler_sample(mmg_sampler *s)
             const uint32_t *ci = p->d_col, *kk = p->d_k;
             const double *mu = s->d_mu + (size_t)c * p->n;
             int32_t *cnt = s->d_cnt + (size_t)c * p->n;
-            if (p->use_sell) {
+            if (fuse > 1) {
+                const SellTile *ts = p->d_sell_tiles;
+                const uint64_t *cs = p->d_sell_chunk_m[fuse == 4 ? 1 : 0];
+                const uint8_t *ss = p->d_sell;
+                void *kargs[] = {(void *)&rp, (void *)&ci, (void *)&ts, (void *)&cs, (void *)&mu, (void *)&ss, (void *)&cnt, (void *)&a};
+                HIP_TRY(hipLaunchKernel(k1_sell_multi_kernel(p->idx64, fuse), dim3(p->grid_sell_m[fuse == 4 ? 1 : 0]), dim3(64), kargs, 0, s->cur));
+            } else if (p->use_sell) {
                 const SellTile *ts = p->d_sell_tiles;
                 const uint64_t *cs = p->d_sell_chunk;
                 const uint8_t *ss = p->d_sell;
@@ -140,6 +155,7 @@ extern "C" int mmg_sampler_sample(mmg_sampler *s)
                 void *kargs[] = {(void *)&rp, (void *)&ci, (void *)&kk, (void *)&td, (void *)&ct, (void *)&mu, (void *)&cnt, (void *)&a};
                 HIP_TRY(hipLaunchKernel(k1_csr_kernel(p->idx64, p->d_k != nullptr), dim3(p->grid_sample), dim3(K1C_BS), kargs, 0, s->cur));
             }
+            c += fuse;
         }
     }
     if (timed) {

@@ -1,0 +1,293 @@
+// K1 for NCH chains at once on the sliced-ELL stream (BASELINE configs[2]: several chains in one GPU).
+//
+// A tile's instructions are one third scalar bookkeeping (descriptors, branches, waits), one tenth stream and unpack work, and
+// its LDS gathers are limited by instruction count, not bytes: all of that is independent of the chain.  k_sample_sell_multi
+// walks a tile ONCE for NCH chains: the window holds mu interleaved [index][chain], so one 16-byte LDS read returns a hit's
+// weight for two chains; the byte unpack, the stream loads and every scalar instruction are paid once.  Per chain remain the
+// fp64 prefix additions, one Philox block per row pair, and the pick.  Every chain performs exactly the additions, draws and
+// comparisons of k_sample_sell with its own key: chain c of a fused launch equals a single-chain launch bit for bit.
+// Multiplicities (k != NULL) keep the single-chain kernel.
+#pragma once
+
+namespace mmg {
+
+template <typename IdxT, int NCH>
+__global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
+                                                          const SellTile *__restrict__ tiles, const uint64_t *__restrict__ chunk_tile,
+                                                          const double *__restrict__ gmu /* [NCH][n] */, const uint8_t *__restrict__ stream,
+                                                          int32_t *gcnt /* [NCH][n] */, SampleArgs a)
+{
+    static_assert(NCH == 2 || NCH == 4, "chains are fused in pairs or fours");
+    constexpr int WIN = (int)SELL_WIN;
+    constexpr int SH = NCH == 2 ? 4 : 5;                       // log2 of the bytes per window entry
+    __shared__ __attribute__((aligned(16))) double s_mu[(WIN + 1) * NCH]; // entry [WIN] stays 0.0 for every chain: what pad slots read
+    __shared__ int32_t s_cnt[NCH * (WIN + 1)];                 // [chain][index]
+    const uint32_t lane = threadIdx.x;
+
+    const uint64_t t_begin = chunk_tile[blockIdx.x], t_end = chunk_tile[blockIdx.x + 1];
+    if (t_begin >= t_end) return;
+    const uint32_t nt = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(t_end - t_begin));
+    const SellTile *__restrict__ T = tiles + t_begin;
+
+    for (int i = lane; i < NCH * (WIN + 1); i += 64) s_cnt[i] = 0;
+    if (lane < NCH) s_mu[WIN * NCH + lane] = 0.0;
+
+    auto flush_window = [&](uint32_t base) {
+        for (int i = lane; i < WIN; i += 64) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int32_t v = s_cnt[c * (WIN + 1) + i];
+                s_cnt[c * (WIN + 1) + i] = 0;
+                if (v) global_count_add(gcnt + (size_t)c * a.n, base + (uint32_t)i, v);
+            }
+        }
+    };
+    auto load_window = [&](uint32_t base) {
+        for (int i = lane; i < WIN; i += 64) {
+            const uint32_t col = base + (uint32_t)i;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) s_mu[i * NCH + c] = col < a.n ? gmu[(size_t)c * a.n + col] : 0.0;
+        }
+    };
+    // byte k of a group word as the LDS byte offset of the window entry (all chains)
+#define SM_OFF0(v) (((v) & 0xffu) << SH)
+#define SM_OFF1(v) ((((v) >> 8) & 0xffu) << SH)
+#define SM_OFF2(v) ((((v) >> 16) & 0xffu) << SH)
+#define SM_OFF3(v) (((v) >> 24) << SH)
+    struct W { double c[NCH]; };
+    auto wo = [&](uint32_t off) {
+        W r;
+        const f64x2 *p = (const f64x2 *)((const char *)s_mu + off);
+#pragma unroll
+        for (int q = 0; q < NCH / 2; ++q) { const f64x2 v = p[q]; r.c[2 * q] = v.x; r.c[2 * q + 1] = v.y; }
+        return r;
+    };
+
+#define SM_GROUPS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+    struct Buf {
+        uint32_t g0, g1, g2, g3, g4, g5, g6, g7;
+        uint32_t len;
+    };
+    auto issue = [&](const SellTile &d, Buf &bf) {
+        const bool fast = d.flags() & SELL_FAST; // uniform
+        const uint8_t *__restrict__ blk = stream + (fast ? d.off16 * 16 : 0);
+        bf.len = blk[lane];
+#define SM_ISSUE(i) bf.g##i = __builtin_nontemporal_load((const uint32_t *)(blk + 64 + (size_t)i * 256) + lane);
+        SM_GROUPS(SM_ISSUE)
+#undef SM_ISSUE
+    };
+
+    // pair RNG per chain (k_sample_sell): this lane's random word for its row of tile A / tile B
+    uint32_t xrowA[NCH], xrowB[NCH];
+    auto pair_rng = [&](const SellTile &A, const SellTile &B) {
+        const uint64_t qa = (a.row_id_base + A.r0) >> 1, qb = (a.row_id_base + B.r0) >> 1; // uniform
+        const uint32_t l5 = lane & 31u;
+        const bool one_key = (((a.row_id_base + A.r0) ^ (a.row_id_base + B.r0 + 63u)) >> 33) == 0 && A.r0 <= B.r0;
+        const uint64_t q = (lane < 32u ? qa : qb) + l5;
+        const uint32_t pa = ((uint32_t)(a.row_id_base + A.r0) & 1u) + lane, pb = ((uint32_t)(a.row_id_base + B.r0) & 1u) + lane;
+        const int sa = (int)((pa >> 1) << 2), sb = (int)((32u + (pb >> 1)) << 2);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            uint32_t x0 = (uint32_t)q, x1 = a.iter;
+            if (one_key) philox2x32_10(x0, x1, stream2_key(a.seed, a.chain + (uint32_t)c, TAG_ROW, (uint32_t)(qa >> 32)));
+            else philox2x32_10(x0, x1, stream2_key(a.seed, a.chain + (uint32_t)c, TAG_ROW, (uint32_t)(q >> 32)));
+            const uint32_t a0 = (uint32_t)__builtin_amdgcn_ds_bpermute(sa, (int)x0), a1 = (uint32_t)__builtin_amdgcn_ds_bpermute(sa, (int)x1);
+            const uint32_t b0 = (uint32_t)__builtin_amdgcn_ds_bpermute(sb, (int)x0), b1 = (uint32_t)__builtin_amdgcn_ds_bpermute(sb, (int)x1);
+            xrowA[c] = (pa & 1u) ? a1 : a0;
+            xrowB[c] = (pb & 1u) ? b1 : b0;
+        }
+    };
+
+    auto walk = [&](const SellTile &d, const Buf &bf, uint32_t which) {
+        const uint32_t ng = d.ng();                                    // uniform
+        const uint32_t *__restrict__ src = (const uint32_t *)(stream + d.off16 * 16 + 64) + lane; // groups beyond the cached ones
+        const uint32_t L = bf.len;
+        double t[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) t[c] = 0.0;
+        double P0[NCH], P1[NCH], P2[NCH], P3[NCH], P4[NCH], P5[NCH], P6[NCH], P7[NCH];
+#define SM_ADD(i)                                                                                            \
+        {                                                                                                    \
+            const uint32_t v = bf.g##i;                                                                      \
+            const W w0 = wo(SM_OFF0(v)), w1 = wo(SM_OFF1(v)), w2 = wo(SM_OFF2(v)), w3 = wo(SM_OFF3(v));      \
+            _Pragma("unroll") for (int c = 0; c < NCH; ++c) {                                                \
+                if (i == 0) t[c] = w0.c[c]; else t[c] += w0.c[c]; /* 0.0 + w == w exactly */                 \
+                t[c] += w1.c[c]; t[c] += w2.c[c]; t[c] += w3.c[c];                                           \
+            }                                                                                                \
+        }
+#define SM_SET(i) _Pragma("unroll") for (int c = 0; c < NCH; ++c) P##i[c] = t[c];
+#define SM_SUM_U(i) SM_ADD(i) SM_SET(i)
+#define SM_SUM_C(i) if ((uint32_t)i < ng) SM_ADD(i) SM_SET(i)
+        if (ng >= 4) {
+            SM_SUM_U(0) SM_SUM_U(1) SM_SUM_U(2) SM_SUM_U(3)
+            SM_SUM_C(4) SM_SUM_C(5) SM_SUM_C(6) SM_SUM_C(7)
+        } else {
+            SM_SUM_C(0) SM_SUM_C(1) SM_SUM_C(2)
+            SM_SET(3) SM_SET(4) SM_SET(5) SM_SET(6) SM_SET(7)
+        }
+#undef SM_SUM_U
+#undef SM_SUM_C
+#undef SM_SET
+#undef SM_ADD
+#pragma unroll 1
+        for (uint32_t g = 8; g < ng; ++g) { // rows of more than 32 hits: rare, keep it small
+            const uint32_t v = src[(size_t)g * 64];
+            const W w0 = wo(SM_OFF0(v)), w1 = wo(SM_OFF1(v)), w2 = wo(SM_OFF2(v)), w3 = wo(SM_OFF3(v));
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) { t[c] += w0.c[c]; t[c] += w1.c[c]; t[c] += w2.c[c]; t[c] += w3.c[c]; }
+        }
+        if (L == 0) return;
+        auto group_of = [&](uint32_t g) -> uint32_t {
+            uint32_t r = bf.g0;
+            asm("" : "+v"(r));
+#define SM_SEL(i) { r = (g == (uint32_t)i) ? bf.g##i : r; asm("" : "+v"(r)); }
+            SM_GROUPS(SM_SEL)
+#undef SM_SEL
+            if (g >= 8u) r = src[(size_t)g * 64];
+            return r;
+        };
+        auto off_of = [&](uint32_t j) -> uint32_t { return ((group_of(j >> 2) >> (8u * (j & 3u))) & 0xffu) << SH; };
+        if (L == 1) {
+            const uint32_t off = SM_OFF0(bf.g0);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) atomicAdd((int32_t *)((char *)s_cnt + c * (WIN + 1) * 4 + (off >> (SH - 2))), 1);
+            return;
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const double tc = t[c];
+            const bool degenerate = !(tc > 0.0) || !(tc < __builtin_huge_val());
+            const double u = u32_unit(which ? xrowB[c] : xrowA[c]);
+            uint32_t sel; // LDS byte offset of the selected window entry
+            if (degenerate) {
+                const uint32_t j = (uint32_t)(u * (double)L);
+                sel = off_of(j < L ? j : L - 1);
+            } else {
+                const double target = u * tc;
+                bool hit = false;
+                uint32_t v = 0;
+                double acc = 0.0;
+#define SM_FIND(i, prev) { const bool cc = target < P##i[c]; hit = cc ? true : hit; v = cc ? bf.g##i : v; acc = cc ? (prev) : acc; asm("" : "+v"(v), "+v"(acc)); }
+                SM_FIND(7, P6[c]) SM_FIND(6, P5[c]) SM_FIND(5, P4[c]) SM_FIND(4, P3[c]) SM_FIND(3, P2[c]) SM_FIND(2, P1[c]) SM_FIND(1, P0[c]) SM_FIND(0, 0.0)
+#undef SM_FIND
+                if (hit) {
+                    const uint32_t o0 = SM_OFF0(v), o1 = SM_OFF1(v), o2 = SM_OFF2(v), o3 = SM_OFF3(v);
+                    const double *m = (const double *)((const char *)s_mu + c * 8);
+                    const double p0 = acc + *(const double *)((const char *)m + o0), p1 = p0 + *(const double *)((const char *)m + o1),
+                                 p2 = p1 + *(const double *)((const char *)m + o2);
+                    sel = target < p0 ? o0 : (target < p1 ? o1 : (target < p2 ? o2 : o3));
+                } else {
+                    double accl = P7[c];
+                    sel = 0xffffffffu;
+#pragma unroll 1
+                    for (uint32_t g = 8; g < ng && sel == 0xffffffffu; ++g) {
+                        const uint32_t vv = src[(size_t)g * 64];
+                        const uint32_t o0 = SM_OFF0(vv), o1 = SM_OFF1(vv), o2 = SM_OFF2(vv), o3 = SM_OFF3(vv);
+                        const double *m = (const double *)((const char *)s_mu + c * 8);
+                        const double p0 = accl + *(const double *)((const char *)m + o0), p1 = p0 + *(const double *)((const char *)m + o1),
+                                     p2 = p1 + *(const double *)((const char *)m + o2), p3 = p2 + *(const double *)((const char *)m + o3);
+                        if (target < p3) sel = target < p0 ? o0 : (target < p1 ? o1 : (target < p2 ? o2 : o3));
+                        accl = p3;
+                    }
+                    if (sel == 0xffffffffu) sel = off_of(L - 1); // rounding left target >= total: the last real hit
+                }
+            }
+            atomicAdd((int32_t *)((char *)s_cnt + c * (WIN + 1) * 4 + (sel >> (SH - 2))), 1);
+        }
+    };
+#undef SM_GROUPS
+
+    // rows of a slow tile: straight from the 32-bit CSR, chain by chain
+    struct RowViewMulti {
+        const uint32_t *cl;
+        uint32_t L, wbase, n;
+        const double *s_mu_c; // s_mu + chain
+        const double *gmu_c;  // gmu + chain * n
+        __device__ __forceinline__ uint32_t col(uint32_t j) const { return cl[j]; }
+        __device__ __forceinline__ double w(uint32_t j) const
+        {
+            const uint32_t col = cl[j], dd = col - wbase;
+            return dd < (uint32_t)SELL_WIN ? s_mu_c[dd * NCH] : gmu_c[col];
+        }
+        __device__ __forceinline__ double total() const
+        {
+            double tt = 0.0;
+            for (uint32_t j = 0; j < L; ++j) tt += w(j);
+            return tt;
+        }
+        __device__ __forceinline__ uint32_t pick(double target) const
+        {
+            double acc = 0.0;
+            for (uint32_t j = 0; j < L; ++j) {
+                acc += w(j);
+                if (target < acc) return j;
+            }
+            return L - 1;
+        }
+    };
+    auto slow_tile = [&](const SellTile &d) {
+        const uint32_t wbase = d.wbase;
+        if (lane < d.nrows()) {
+            const uint64_t st = (uint64_t)row_ptr[d.r0 + lane];
+            const uint32_t L = (uint32_t)((uint64_t)row_ptr[d.r0 + lane + 1] - st);
+#pragma unroll 1
+            for (int c = 0; c < NCH; ++c) {
+                int32_t *gc = gcnt + (size_t)c * a.n;
+                auto add = [&](uint32_t col, int32_t x) {
+                    const uint32_t dd = col - wbase;
+                    if (dd < (uint32_t)WIN) atomicAdd(&s_cnt[c * (WIN + 1) + dd], x);
+                    else global_count_add(gc, col, x);
+                };
+                RowViewMulti v{col_idx + st, L, wbase, a.n, s_mu + c, gmu + (size_t)c * a.n};
+                SampleArgs ac = a;
+                ac.chain = a.chain + (uint32_t)c;
+                allocate_row<false>(v, add, 1u, ac, a.row_id_base + d.r0 + lane);
+            }
+        }
+    };
+
+    auto process = [&](const SellTile &d, uint32_t &cur_base, const SellTile &refill, Buf &bf, uint32_t which) {
+        if (d.flags() & SELL_EMPTY) { issue(refill, bf); return; }
+        if (d.wbase != cur_base) {
+            __syncthreads();
+            flush_window(cur_base);
+            load_window(d.wbase);
+            cur_base = d.wbase;
+            __syncthreads();
+        }
+        if (d.flags() & SELL_FAST) walk(d, bf, which);
+        else slow_tile(d);
+        issue(refill, bf);
+    };
+
+    SellTile none;
+    none.off16 = 0; none.r0 = 0; none.wbase = 0; none.meta = sell_meta(0, 0, SELL_EMPTY);
+    auto tile_at = [&](uint32_t i) {
+        SellTile d = T[min(i, nt - 1u)];
+        d.meta = i < nt ? d.meta : none.meta;
+        return d;
+    };
+    SellTile dA = tile_at(0), dB = tile_at(1);
+    Buf bufA, bufB;
+    load_window(dA.wbase);
+    uint32_t cur_base = dA.wbase;
+    __syncthreads();
+    issue(dA, bufA);
+    issue(dB, bufB);
+    for (uint32_t i = 0; i < nt; i += 2) {
+        const SellTile nA = tile_at(i + 2), nB = tile_at(i + 3);
+        pair_rng(dA, dB);
+        process(dA, cur_base, nA, bufA, 0);
+        process(dB, cur_base, nB, bufB, 1);
+        dA = nA;
+        dB = nB;
+    }
+    __syncthreads();
+    flush_window(cur_base);
+#undef SM_OFF0
+#undef SM_OFF1
+#undef SM_OFF2
+#undef SM_OFF3
+}
+
+} // namespace mmg

@@ -386,7 +386,7 @@ def selftest_option(option, value):
 
 
 OPT = dict(sample_kernel=_lib.OPT_SAMPLE_KERNEL, force_idx64=_lib.OPT_FORCE_IDX64, sell_waves_per_cu=_lib.OPT_SELL_WAVES_PER_CU,
-           em_kernel=_lib.OPT_EM_KERNEL, em_grid=_lib.OPT_EM_GRID)
+           em_kernel=_lib.OPT_EM_KERNEL, em_grid=_lib.OPT_EM_GRID, fuse_chains=_lib.OPT_FUSE_CHAINS)
 
 
 class options:

@@ -544,13 +544,17 @@ def _64bit_body(gpu, orc):
     assert np.array_equal(rp, q.row_ptr) and np.array_equal(ci, q.col_idx)
 
 
+@pytest.mark.parametrize("fuse", [4, 2, 1])
 @pytest.mark.parametrize("n_chains", [2, 4, 8, 11])
-def test_chains_of_one_sampler_equal_independent_single_chains(gpu, orc, n_chains):
-    """Chains advanced by one sampler are bit-identical to single-chain runs keyed with the same global chain index."""
-    p, mu0, _ = _mk(orc, 40000, 1500, 9)
-    prob = gpu.Problem.from_csr(p.row_ptr, p.col_idx, p.l)
-    s = gpu.Sampler(prob, mu0, seed=21, n_chains=n_chains, chain_base=3, gibbs_iter=16, trace_len=16)
-    s.run(16)
+def test_chains_of_one_sampler_equal_independent_single_chains(gpu, orc, n_chains, fuse):
+    """Chains advanced together by the fused walk (k_sample_sell_multi: groups of 4 / 2 / 1 chains per launch) are bit-identical
+    to single-chain runs keyed with the same global chain index -- also across window slides, a far row and a 40-hit row."""
+    p, mu0, _ = _mk(orc, 40000, 1500, 9, far_fraction=0.01)
+    with gpu.options(fuse_chains=fuse, sell_waves_per_cu=2):
+        prob, p = _dev(gpu, orc, p)
+        s = gpu.Sampler(prob, mu0, seed=21, n_chains=n_chains, chain_base=3, gibbs_iter=16, trace_len=16)
+        s.run(16)
+    assert prob.info.sample_kernel == 2
     for c in sorted({0, 1, n_chains // 2, n_chains - 1}):
         ref = orc.gibbs_keyed(p, mu0, seed=21, chain=3 + c, n_iter=16, trace_len=16)
         assert np.array_equal(s.trace(c), ref["trace"]), c

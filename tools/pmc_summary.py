@@ -58,9 +58,13 @@ try:
     bench = json.loads([l for l in open(os.path.join(ROOT, "gpurun_out", "%s_bench.json" % tag)) if l.startswith("{")][-1])
 except Exception as e:
     print("no bench line:", e, file=sys.stderr)
-h = hashlib.sha256()
+import re
+h = hashlib.sha256()           # same rule as bench.py:kernel_hash(): comments and white space do not count
 for f in KERNEL_SOURCES:
-    h.update(open(os.path.join(ROOT, "mmseq_amd", "csrc", f), "rb").read())
+    src = open(os.path.join(ROOT, "mmseq_amd", "csrc", f)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    h.update(re.sub(r"\s+", "", src).encode())
 out = {"kernel": sub, "kernel_sources_sha16": h.hexdigest()[:16],
        "workload": {"rows": 50_000_000, "transcripts": 200_000, "avg_hits": 20.0, "chains": 1},
        "hbm_read_bytes_per_launch": 2 * 1024 * g("FETCH_SIZE") if g("FETCH_SIZE") is not None else None,
