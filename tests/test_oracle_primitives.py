@@ -106,3 +106,44 @@ def test_binomial_edge_cases(orc):
     assert (x == 17).all()
     orc.lib().orc_keyed_binomial_v(1, 0, 0.5, 10, x)
     assert (x == 0).all()
+
+
+def test_row_stream_pairs_share_a_philox_block(orc):
+    """Row stream spec (mmseq_amd/csrc/mmg_math.h:Stream2): rows 2q and 2q+1 take the two output words of ONE Philox2x32-10 block
+    keyed (seed, chain, tag, q >> 32) with counter (q, iteration), as 32-bit uniforms (x + 1/2) 2^-32.  Observed through the keyed
+    Binomial(1, 1/2) hook, which is [u > 1/2] of the row's first uniform (sequential-search inversion)."""
+    import numpy as np
+    n, seed = 4000, 99
+    got = np.empty(n, np.uint32)
+    orc.lib().orc_keyed_binomial_v(seed, 1, 0.5, n, got)                    # rows 0..n-1 of stream (seed, chain 0, tag ROW = 1, iteration 0)
+    exp = np.empty(n, np.uint32)
+    for rid in range(n):
+        q = rid >> 1
+        key = ((seed & 0xffffffff) ^ (((seed >> 32) * 0x9E3779B1) & 0xffffffff) ^ ((1 << 28) & 0xffffffff) ^ (((q >> 32) * 0xC2B2AE35) & 0xffffffff))
+        w = orc.philox2x32([q & 0xffffffff, 0], key & 0xffffffff)
+        u = (float(w[rid & 1]) + 0.5) * 2.0 ** -32
+        exp[rid] = 1 if u > 0.5 else 0
+    assert np.array_equal(got, exp)
+    assert 0.45 < got.mean() < 0.55
+
+
+def test_canonical_layout_properties(orc):
+    """oracle.binding.canonical_layout (the restatement of mmseq_amd/csrc/layout.hip): keys ascend, the order is idempotent and does
+    not depend on the order the rows were given in; empty rows come first, far rows last."""
+    import numpy as np
+    p, _ = orc.synth_problem(R=8000, T=900, avg_hits=6, seed=3, sort=False, far_fraction=0.05)
+    rng = np.random.default_rng(0)
+    k = rng.choice([1, 1, 2, 9], size=p.m).astype(np.uint32)
+    rp, ci, kk, perm = orc.canonical_layout(p.row_ptr, p.col_idx, k)
+    key, h = orc.row_keys(rp, ci, kk)
+    assert (key[1:] >= key[:-1]).all()
+    same = key[1:] == key[:-1]
+    assert (h[1:][same] >= h[:-1][same]).all()
+    rp2, ci2, kk2, perm2 = orc.canonical_layout(rp, ci, kk)
+    assert np.array_equal(rp2, rp) and np.array_equal(ci2, ci) and np.array_equal(kk2, kk) and np.array_equal(perm2, np.arange(p.m))
+    sh = rng.permutation(p.m)
+    rps, cis, ks = orc.permute_rows(p.row_ptr, p.col_idx, k, sh)
+    rp3, ci3, kk3, _ = orc.canonical_layout(rps, cis, ks)
+    assert np.array_equal(rp3, rp) and np.array_equal(ci3, ci) and np.array_equal(kk3, kk)
+    far = key >> np.uint64(63)
+    assert 0 < far.sum() < p.m and (np.diff(far.astype(np.int64)) >= 0).all()
