@@ -162,6 +162,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 1 : 
         {                                                                                                    \
             const uint32_t v = bf.g##i;                                                                      \
             const double w0 = wo(SELL_OFF0(v)), w1 = wo(SELL_OFF1(v)), w2 = wo(SELL_OFF2(v)), w3 = wo(SELL_OFF3(v)); \
+            __builtin_amdgcn_sched_barrier(0); /* one wait for the four gathers instead of one per addition */ \
             if (i == 0) t = w0; else t += w0; /* 0.0 + w0 == w0 exactly */                                   \
             t += w1; t += w2; t += w3;                                                                       \
         }
@@ -200,39 +201,44 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 1 : 
         auto add = [&](uint32_t off, int32_t x) { atomicAdd((int32_t *)((char *)s_cnt + rep_off + (off >> 1)), x); };
         const uint32_t kk = HAS_K ? bf.kk : 1u;
         if (HAS_K && kk == 0) return;
-        if (L == 1) { add(SELL_OFF0(bf.g0), (int32_t)kk); return; }
+        // a single hit needs no draw; without multiplicities the general path picks it anyway (same result, one branch less)
+        if (HAS_K && L == 1) { add(SELL_OFF0(bf.g0), (int32_t)kk); return; }
         const bool degenerate = !(t > 0.0) || !(t < __builtin_huge_val());
         const uint64_t row_id = a.row_id_base + d.r0 + lane;
         // one categorical draw: the window byte offset of the selected hit (allocate_row's pick + col)
         auto draw = [&](double u) -> uint32_t {
-            if (degenerate) {
-                const uint32_t j = (uint32_t)(u * (double)L);
-                return off_of(j < L ? j : L - 1);
-            }
             const double target = u * t;
             // first cached boundary the target falls below (prefix sums never decrease): one descending sweep of
             // compares that carries the group's offsets and the prefix before it along
-            bool hit = false;
+            const bool hit = target < P7; // the boundaries never decrease: some boundary exceeds the target iff the last one does
             uint32_t v = 0;
             double acc = 0.0;
-#define SELL_FIND(i, prev) { const bool c = target < P##i; hit = c ? true : hit; v = c ? bf.g##i : v; acc = c ? (prev) : acc; asm("" : "+v"(v), "+v"(acc)); }
+#define SELL_FIND(i, prev) { const bool c = target < P##i; v = c ? bf.g##i : v; acc = c ? (prev) : acc; asm("" : "+v"(v), "+v"(acc)); }
             SELL_FIND(7, P6) SELL_FIND(6, P5) SELL_FIND(5, P4) SELL_FIND(4, P3) SELL_FIND(3, P2) SELL_FIND(2, P1) SELL_FIND(1, P0) SELL_FIND(0, 0.0)
 #undef SELL_FIND
-            if (hit) {
-                const uint32_t o0 = SELL_OFF0(v), o1 = SELL_OFF1(v), o2 = SELL_OFF2(v), o3 = SELL_OFF3(v);
-                const double p0 = acc + wo(o0), p1 = p0 + wo(o1), p2 = p1 + wo(o2);
-                return target < p0 ? o0 : (target < p1 ? o1 : (target < p2 ? o2 : o3));
-            }
-            double accl = P7;
+            // resolved inside the group without a branch; lanes without a hit (below) read slot 0 and are overridden
+            const uint32_t o0 = SELL_OFF0(v), o1 = SELL_OFF1(v), o2 = SELL_OFF2(v), o3 = SELL_OFF3(v);
+            const double p0 = acc + wo(o0), p1 = p0 + wo(o1), p2 = p1 + wo(o2);
+            uint32_t sel = target < p0 ? o0 : (target < p1 ? o1 : (target < p2 ? o2 : o3));
+            if (!hit) { // rare: a degenerate total (0, inf, NaN never compare below anything), a row of more than 32 hits, rounding
+                if (degenerate) {
+                    const uint32_t j = (uint32_t)(u * (double)L);
+                    sel = off_of(j < L ? j : L - 1);
+                } else {
+                    double accl = P7;
+                    bool found = false;
 #pragma unroll 1
-            for (uint32_t g = NGC; g < ng; ++g) {
-                const uint32_t vv = src[(size_t)g * 64];
-                const uint32_t o0 = SELL_OFF0(vv), o1 = SELL_OFF1(vv), o2 = SELL_OFF2(vv), o3 = SELL_OFF3(vv);
-                const double p0 = accl + wo(o0), p1 = p0 + wo(o1), p2 = p1 + wo(o2), p3 = p2 + wo(o3);
-                if (target < p3) return target < p0 ? o0 : (target < p1 ? o1 : (target < p2 ? o2 : o3));
-                accl = p3;
+                    for (uint32_t g = NGC; g < ng && !found; ++g) {
+                        const uint32_t vv = src[(size_t)g * 64];
+                        const uint32_t q0 = SELL_OFF0(vv), q1 = SELL_OFF1(vv), q2 = SELL_OFF2(vv), q3 = SELL_OFF3(vv);
+                        const double r0 = accl + wo(q0), r1 = r0 + wo(q1), r2 = r1 + wo(q2), r3 = r2 + wo(q3);
+                        if (target < r3) { sel = target < r0 ? q0 : (target < r1 ? q1 : (target < r2 ? q2 : q3)); found = true; }
+                        accl = r3;
+                    }
+                    if (!found) sel = off_of(L - 1); // rounding left target >= total: the last real hit
+                }
             }
-            return off_of(L - 1); // rounding left target >= total: the last real hit
+            return sel;
         };
         if (!HAS_K) { add(draw(u32_unit(xrow)), 1); return; }
         if (kk <= K_SMALL) {
