@@ -110,6 +110,7 @@ __global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict
         {                                                                                                    \
             const uint32_t v = bf.g##i;                                                                      \
             const W w0 = wo(SM_OFF0(v)), w1 = wo(SM_OFF1(v)), w2 = wo(SM_OFF2(v)), w3 = wo(SM_OFF3(v));      \
+            __builtin_amdgcn_sched_barrier(0); /* one wait for the four gathers */                           \
             _Pragma("unroll") for (int c = 0; c < NCH; ++c) {                                                \
                 if (i == 0) t[c] = w0.c[c]; else t[c] += w0.c[c]; /* 0.0 + w == w exactly */                 \
                 t[c] += w1.c[c]; t[c] += w2.c[c]; t[c] += w3.c[c];                                           \
@@ -147,49 +148,43 @@ __global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict
             return r;
         };
         auto off_of = [&](uint32_t j) -> uint32_t { return ((group_of(j >> 2) >> (8u * (j & 3u))) & 0xffu) << SH; };
-        if (L == 1) {
-            const uint32_t off = SM_OFF0(bf.g0);
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) atomicAdd((int32_t *)((char *)s_cnt + c * (WIN + 1) * 4 + (off >> (SH - 2))), 1);
-            return;
-        }
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const double tc = t[c];
             const bool degenerate = !(tc > 0.0) || !(tc < __builtin_huge_val());
             const double u = u32_unit(which ? xrowB[c] : xrowA[c]);
-            uint32_t sel; // LDS byte offset of the selected window entry
-            if (degenerate) {
-                const uint32_t j = (uint32_t)(u * (double)L);
-                sel = off_of(j < L ? j : L - 1);
-            } else {
-                const double target = u * tc;
-                bool hit = false;
-                uint32_t v = 0;
-                double acc = 0.0;
-#define SM_FIND(i, prev) { const bool cc = target < P##i[c]; hit = cc ? true : hit; v = cc ? bf.g##i : v; acc = cc ? (prev) : acc; asm("" : "+v"(v), "+v"(acc)); }
-                SM_FIND(7, P6[c]) SM_FIND(6, P5[c]) SM_FIND(5, P4[c]) SM_FIND(4, P3[c]) SM_FIND(3, P2[c]) SM_FIND(2, P1[c]) SM_FIND(1, P0[c]) SM_FIND(0, 0.0)
+            const double target = u * tc;
+            const bool hit = target < P7[c]; // the boundaries never decrease
+            uint32_t v = 0;
+            double acc = 0.0;
+#define SM_FIND(i, prev) { const bool cc = target < P##i[c]; v = cc ? bf.g##i : v; acc = cc ? (prev) : acc; asm("" : "+v"(v), "+v"(acc)); }
+            SM_FIND(7, P6[c]) SM_FIND(6, P5[c]) SM_FIND(5, P4[c]) SM_FIND(4, P3[c]) SM_FIND(3, P2[c]) SM_FIND(2, P1[c]) SM_FIND(1, P0[c]) SM_FIND(0, 0.0)
 #undef SM_FIND
-                if (hit) {
-                    const uint32_t o0 = SM_OFF0(v), o1 = SM_OFF1(v), o2 = SM_OFF2(v), o3 = SM_OFF3(v);
-                    const double *m = (const double *)((const char *)s_mu + c * 8);
-                    const double p0 = acc + *(const double *)((const char *)m + o0), p1 = p0 + *(const double *)((const char *)m + o1),
-                                 p2 = p1 + *(const double *)((const char *)m + o2);
-                    sel = target < p0 ? o0 : (target < p1 ? o1 : (target < p2 ? o2 : o3));
+            const double *m = (const double *)((const char *)s_mu + c * 8);
+            uint32_t sel; // LDS byte offset of the selected window entry
+            {
+                const uint32_t o0 = SM_OFF0(v), o1 = SM_OFF1(v), o2 = SM_OFF2(v), o3 = SM_OFF3(v);
+                const double p0 = acc + *(const double *)((const char *)m + o0), p1 = p0 + *(const double *)((const char *)m + o1),
+                             p2 = p1 + *(const double *)((const char *)m + o2);
+                sel = target < p0 ? o0 : (target < p1 ? o1 : (target < p2 ? o2 : o3));
+            }
+            if (!hit) { // rare: degenerate total, a row of more than 32 hits, rounding
+                if (degenerate) {
+                    const uint32_t j = (uint32_t)(u * (double)L);
+                    sel = off_of(j < L ? j : L - 1);
                 } else {
                     double accl = P7[c];
-                    sel = 0xffffffffu;
+                    bool found = false;
 #pragma unroll 1
-                    for (uint32_t g = 8; g < ng && sel == 0xffffffffu; ++g) {
+                    for (uint32_t g = 8; g < ng && !found; ++g) {
                         const uint32_t vv = src[(size_t)g * 64];
                         const uint32_t o0 = SM_OFF0(vv), o1 = SM_OFF1(vv), o2 = SM_OFF2(vv), o3 = SM_OFF3(vv);
-                        const double *m = (const double *)((const char *)s_mu + c * 8);
                         const double p0 = accl + *(const double *)((const char *)m + o0), p1 = p0 + *(const double *)((const char *)m + o1),
                                      p2 = p1 + *(const double *)((const char *)m + o2), p3 = p2 + *(const double *)((const char *)m + o3);
-                        if (target < p3) sel = target < p0 ? o0 : (target < p1 ? o1 : (target < p2 ? o2 : o3));
+                        if (target < p3) { sel = target < p0 ? o0 : (target < p1 ? o1 : (target < p2 ? o2 : o3)); found = true; }
                         accl = p3;
                     }
-                    if (sel == 0xffffffffu) sel = off_of(L - 1); // rounding left target >= total: the last real hit
+                    if (!found) sel = off_of(L - 1); // rounding left target >= total: the last real hit
                 }
             }
             atomicAdd((int32_t *)((char *)s_cnt + c * (WIN + 1) * 4 + (sel >> (SH - 2))), 1);
