@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmmgibbs.so")
+# MMSEQ_AMD_LIB: another build of the same library (A/B timing of kernel changes on one box, tools/k1_ab.py)
+LIB_PATH = os.environ.get("MMSEQ_AMD_LIB") or os.path.join(_HERE, "csrc", "libmmgibbs.so")
 _lib = None
 
 
