@@ -99,6 +99,8 @@ typedef struct mmg_problem_info {
     uint64_t padded_slots; /* hit slots of the sliced-ELL stream incl. padding (>= nnz of the fast tiles) */
     int32_t layout;        /* MMG_LAYOUT_* in force                                       */
     int32_t tx_renumbered; /* 1: tx_order was given                                       */
+    int32_t sample_grid;   /* workgroups of the (persistent) sample kernel: resident waves the runtime reports x CUs */
+    int32_t cu_count;
 } mmg_problem_info;
 
 /* Parameters of the Gibbs loop: alpha/beta are the Gamma prior (src/mmseq.cpp:184-185),
@@ -277,6 +279,9 @@ enum {
     MMG_OPT_COUNT_ = 6
 };
 int mmg_selftest_option(int option, int value);
+/* What the HIP runtime reports about the k == NULL sliced-ELL sample kernel on `device`: registers, LDS and scratch bytes per
+ * thread, and resident 64-thread workgroups per CU (hipOccupancyMaxActiveBlocksPerMultiprocessor). */
+int mmg_selftest_kernel_info(int device, int *vgprs, int *lds_bytes, int *scratch_bytes, int *resident_per_cu);
 /* Evaluates the library's own log / exp / sqrt / 1/x on x[0..n) (device >= 0: in a kernel
  * on that device; device == -1: the host instantiation of the same inline code). */
 int mmg_selftest_math(int device, int64_t n, const double *x, double *out_log, double *out_exp,

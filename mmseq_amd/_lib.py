@@ -40,7 +40,7 @@ class ProblemInfo(C.Structure):
                 ("n", C.c_uint32), ("max_row_len", C.c_uint32), ("n_tiles", C.c_uint64),
                 ("device_bytes", C.c_uint64), ("index_bits", C.c_int32), ("sample_kernel", C.c_int32),
                 ("stream_bytes", C.c_uint64), ("fast_tiles", C.c_uint64), ("padded_slots", C.c_uint64),
-                ("layout", C.c_int32), ("tx_renumbered", C.c_int32)]
+                ("layout", C.c_int32), ("tx_renumbered", C.c_int32), ("sample_grid", C.c_int32), ("cu_count", C.c_int32)]
 
 
 class SummaryDesc(C.Structure):
@@ -72,6 +72,7 @@ SYMBOLS = {
     "mmg_problem_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mmg_problem_tx_perm": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mmg_selftest_option": (C.c_int, [C.c_int, C.c_int]),
+    "mmg_selftest_kernel_info": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mmg_problem_get_l": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mmg_problem_start_values": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mmg_problem_em": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_int),

@@ -459,6 +459,8 @@ extern "C" int mmg_problem_info_get(const mmg_problem *p, mmg_problem_info *info
     info->padded_slots = p->padded_slots;
     info->layout = p->layout;
     info->tx_renumbered = p->renumbered() ? 1 : 0;
+    info->sample_grid = p->use_sell ? p->grid_sell : p->grid_sample;
+    info->cu_count = p->cu_count;
     return MMG_OK;
 }
 
@@ -539,6 +541,21 @@ extern "C" int mmg_host_gamma_trace(uint64_t seed, uint64_t id, double shape, do
 {
     if (n < 0 || !out || !(shape > 0.0)) return fail(MMG_ERR_ARG, "bad argument");
     host_gamma(seed, 5 /* TAG_SIMU */, id, 1, shape, scale, n, out);
+    return MMG_OK;
+}
+
+extern "C" int mmg_selftest_kernel_info(int device, int *vgprs, int *lds_bytes, int *scratch_bytes, int *resident_per_cu)
+{
+    int rc = require_device(device);
+    if (rc) return rc;
+    hipFuncAttributes fa;
+    HIP_TRY(hipFuncGetAttributes(&fa, k1_sell_kernel(false, false)));
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k1_sell_kernel(false, false), 64, 0));
+    if (vgprs) *vgprs = fa.numRegs;
+    if (lds_bytes) *lds_bytes = (int)fa.sharedSizeBytes;
+    if (scratch_bytes) *scratch_bytes = (int)fa.localSizeBytes;
+    if (resident_per_cu) *resident_per_cu = per_cu;
     return MMG_OK;
 }
 

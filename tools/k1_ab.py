@@ -9,7 +9,12 @@ import sys, json
 sys.path.insert(0, %r)
 from mmseq_amd import _lib
 _lib.LIB_PATH = sys.argv[1]
-import ctypes
+import ctypes, os
+if os.environ.get("K1_AB_RUNTIME", "torch") == "torch":
+    _lib._share_hip_runtime_with_torch()     # the HIP runtime bench.py and the tests run on (PyTorch's bundled libamdhip64)
+else:
+    _lib._share_hip_runtime_with_torch = lambda: None   # K1_AB_RUNTIME=system: /opt/rocm's only, what the C++ CLI binds.  NEVER both
+                                             # in one process: the library then sees 12 resident waves per CU instead of 28
 _probe = ctypes.CDLL(sys.argv[1])
 for _name in list(_lib.SYMBOLS):          # older builds export fewer entry points: bind what is there
     if not hasattr(_probe, _name):
@@ -22,7 +27,8 @@ s = Sampler(prob, mu0, n_chains=C, gibbs_iter=1024, trace_len=1024, keep_trace=F
 s.run(300); s.sync(); s.reset_timing()
 s.run(200); s.sync()
 tm = s.timing()
-print(json.dumps({"k1_ms": tm["sample_ms"] / tm["sample_launches"] / C, "k2_ms": tm["update_ms"] / tm["update_launches"],
+print("grid", prob.info.sample_grid, "CUs", prob.info.cu_count, file=sys.stderr)
+print(json.dumps({"k1_ms": tm["sample_ms"] / tm["sample_launches"] / C, "grid": prob.info.sample_grid, "cus": prob.info.cu_count, "k2_ms": tm["update_ms"] / tm["update_launches"],
                   "stream": prob.info.stream_bytes}))
 ''' % ROOT
 
@@ -45,7 +51,8 @@ for r in range(a.rounds):
             continue
         d = json.loads(line[-1])
         res[l].append(d["k1_ms"])
-        print("round %d %-40s K1 %.4f ms  K2 %.4f ms  stream %.3f GB" % (r, os.path.basename(l), d["k1_ms"], d["k2_ms"], d["stream"] / 1e9), flush=True)
+        print("round %d %-40s K1 %.4f ms  K2 %.4f ms  stream %.3f GB  grid %s on %s CUs" % (r, os.path.basename(l), d["k1_ms"], d["k2_ms"], d["stream"] / 1e9,
+                                                                                       d.get("grid"), d.get("cus")), flush=True)
 for l in a.libs:
     if res[l]:
         print("%-40s mean K1 %.4f ms over %d rounds" % (os.path.basename(l), sum(res[l]) / len(res[l]), len(res[l])))
