@@ -267,10 +267,10 @@ __global__ __launch_bounds__(64 * W) void k_em_sell(const IdxT *__restrict__ row
     // unconditional, like k_sample_sell::issue (the number of loads per tile must not depend on the path)
     auto issue = [&](const SellTile &d, Buf &bf) {
         const bool fast = d.flags() & SELL_FAST; // uniform
-        const uint8_t *__restrict__ blk = stream + (fast ? d.off16 * 16 : 0);
-        bf.len = blk[lane];
+        const SellBlock blk(stream + (fast ? d.off16 * 16 : 0), d.meta);
+        bf.len = blk.len(lane);
         if (HAS_K) bf.kk = kmult[(fast ? d.r0 : 0) + min(lane, (fast ? d.nrows() : 1u) - 1u)];
-#define EMS_ISSUE(i) bf.g##i = __builtin_nontemporal_load((const uint32_t *)(blk + 64 + (size_t)i * 256) + lane);
+#define EMS_ISSUE(i) bf.g##i = blk.template group<i>(lane);
         EMS_GROUPS(EMS_ISSUE)
 #undef EMS_ISSUE
     };

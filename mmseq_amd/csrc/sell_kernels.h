@@ -18,6 +18,23 @@ namespace mmg {
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
+// A tile's block seen through a raw buffer descriptor of exactly its size (64 length bytes + ng groups of 256 bytes).  The sampler and
+// EM kernels request NGC groups per tile whatever its ng (loads retire in order and are waited for by count, so the number issued
+// must not depend on the tile): through the descriptor a request past the block's end returns 0 WITHOUT a memory access -- the
+// hardware's range check is the clamp, at no instruction per group (clamped scalar addresses cost 10 % of the kernel's time, plain
+// over-reads a quarter more HBM traffic).  Descriptor words, offsets and the block are wave-uniform: everything stays in SGPRs.
+struct SellBlock {
+    __amdgpu_buffer_rsrc_t rs;
+    __device__ SellBlock(const uint8_t *blk, uint32_t meta)
+        : rs(__builtin_amdgcn_make_buffer_rsrc((void *)blk, 0, (int)((meta & 0xff00u) + 64u), 0x00020000)) {} // 0x00020000: gfx9 raw dword buffer
+    __device__ uint32_t len(uint32_t lane) const { return __builtin_amdgcn_raw_buffer_load_b8(rs, (int)lane, 0, 0); }
+    // group i of the lane's row; the constant part of the offset folds into the instruction, aux 2 = nontemporal (streamed once)
+    template <int I> __device__ uint32_t group(uint32_t lane) const
+    {
+        return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(lane * 4u + 64u + (uint32_t)I * 256u), 0, 2);
+    }
+};
+
 // Block of a fast tile: 64 length bytes, then ng groups of 64 lanes x 4 u8 window indices (col - wbase), 255 = pad.
 template <typename IdxT>
 __global__ __launch_bounds__(64) void k_encode_sell(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
@@ -102,17 +119,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 1 : 
         uint32_t kk; // multiplicity of the lane's row (HAS_K)
     };
     // request a tile's block: the lane's length byte and NGC groups, UNCONDITIONALLY (tiles without a block -- empty, slow, past
-    // the end of the range -- read the head of the stream instead).  Loads retire in order and are waited for by count, so the
+    // the end of the range -- ask for the head of the stream instead).  Loads retire in order and are waited for by count, so the
     // number issued per tile must not depend on the path -- otherwise the compiler has to assume the fewest, and every walk
-    // waits for the prefetch issued just before it.  Groups beyond the tile's ng are simply the first groups of the NEXT block
-    // (the stream has NGC groups of head room behind its last block): one base address and immediate offsets, no scalar
-    // arithmetic per group.  Clamping them to the last group saved a quarter of the HBM traffic and cost 10 % of the time.
+    // waits for the prefetch issued just before it.  Groups beyond the tile's ng fail the descriptor's range check: no memory access.
     auto issue = [&](const SellTile &d, Buf &bf) {
         const bool fast = d.flags() & SELL_FAST; // uniform
-        const uint8_t *__restrict__ blk = stream + (fast ? d.off16 * 16 : 0);
-        bf.len = blk[lane];
+        const SellBlock blk(stream + (fast ? d.off16 * 16 : 0), d.meta);
+        bf.len = blk.len(lane);
         if (HAS_K) bf.kk = kmult[(fast ? d.r0 : 0) + min(lane, (fast ? d.nrows() : 1u) - 1u)];
-#define SELL_ISSUE(i) bf.g##i = __builtin_nontemporal_load((const uint32_t *)(blk + 64 + (size_t)i * 256) + lane);
+#define SELL_ISSUE(i) bf.g##i = blk.template group<i>(lane);
         SELL_GROUPS(SELL_ISSUE)
 #undef SELL_ISSUE
     };

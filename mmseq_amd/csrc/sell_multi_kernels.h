@@ -70,9 +70,9 @@ __global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict
     };
     auto issue = [&](const SellTile &d, Buf &bf) {
         const bool fast = d.flags() & SELL_FAST; // uniform
-        const uint8_t *__restrict__ blk = stream + (fast ? d.off16 * 16 : 0);
-        bf.len = blk[lane];
-#define SM_ISSUE(i) bf.g##i = __builtin_nontemporal_load((const uint32_t *)(blk + 64 + (size_t)i * 256) + lane);
+        const SellBlock blk(stream + (fast ? d.off16 * 16 : 0), d.meta);
+        bf.len = blk.len(lane);
+#define SM_ISSUE(i) bf.g##i = blk.template group<i>(lane);
         SM_GROUPS(SM_ISSUE)
 #undef SM_ISSUE
     };
