@@ -128,6 +128,7 @@ def side_measurement(name, rows, transcripts, avg_hits, chains=1, uniform=False,
            "k2_avg_launch_ms": tm["update_ms"] / max(tm["update_launches"], 1),
            "sample_kernel": {0: "k_sample (CSR tiles)", 2: "k_sample_sell"}[inf.sample_kernel],
            "fast_tile_fraction": (inf.fast_tiles / inf.n_tiles) if inf.sample_kernel == 2 and inf.n_tiles else 0.0,
+           "far_tile_fraction": (inf.far_tiles / inf.n_tiles) if inf.sample_kernel == 2 and inf.n_tiles else 0.0,
            "stream_bytes": inf.stream_bytes, "problem_build_s": build_s}
     if note:
         out["note"] = note

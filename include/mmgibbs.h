@@ -95,7 +95,9 @@ typedef struct mmg_problem_info {
     int32_t sample_kernel; /* what mmg_sampler_sample launches: 2 k_sample_sell (sliced-ELL 8-bit stream; the default),
                               0 k_sample (32-bit CSR tiles: problems whose rows mostly span more than an LDS window) */
     uint64_t stream_bytes; /* bytes of the tile stream that kernel reads per launch (0 for kernel 0) */
-    uint64_t fast_tiles;   /* sliced-ELL tiles walked from the register stream (the rest: from the CSR) */
+    uint64_t fast_tiles;   /* sliced-ELL tiles walked from the register stream                               */
+    uint64_t far_tiles;    /* sliced-ELL tiles with a far list (rows with hits outside the window); the rest
+                              (n_tiles - fast - far - empty) are walked from the CSR                         */
     uint64_t padded_slots; /* hit slots of the sliced-ELL stream incl. padding (>= nnz of the fast tiles) */
     int32_t layout;        /* MMG_LAYOUT_* in force                                       */
     int32_t tx_renumbered; /* 1: tx_order was given                                       */

@@ -39,7 +39,7 @@ class ProblemInfo(C.Structure):
     _fields_ = [("m", C.c_uint64), ("nnz", C.c_uint64), ("total_k", C.c_uint64), ("row_id_base", C.c_uint64),
                 ("n", C.c_uint32), ("max_row_len", C.c_uint32), ("n_tiles", C.c_uint64),
                 ("device_bytes", C.c_uint64), ("index_bits", C.c_int32), ("sample_kernel", C.c_int32),
-                ("stream_bytes", C.c_uint64), ("fast_tiles", C.c_uint64), ("padded_slots", C.c_uint64),
+                ("stream_bytes", C.c_uint64), ("fast_tiles", C.c_uint64), ("far_tiles", C.c_uint64), ("padded_slots", C.c_uint64),
                 ("layout", C.c_int32), ("tx_renumbered", C.c_int32), ("sample_grid", C.c_int32), ("cu_count", C.c_int32)]
 
 

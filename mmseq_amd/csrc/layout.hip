@@ -34,8 +34,12 @@ __global__ __launch_bounds__(256) void k_row_keys(uint64_t m, const uint64_t *__
     }
     uint64_t kv = 0;
     if (L) {
-        const uint64_t band = lo >> LAYOUT_BAND_SHIFT;
+        uint64_t band = lo >> LAYOUT_BAND_SHIFT;
         const bool near = L <= 255 && (uint64_t)hi - (band << LAYOUT_BAND_SHIFT) < LAYOUT_NEAR_SPAN;
+        if (!near) { // home band: one below the band of the row's middle hit
+            const uint64_t mid = col[b + (L - 1) / 2] >> LAYOUT_BAND_SHIFT;
+            band = (mid > 1 ? mid : 1) - 1;
+        }
         const uint64_t kclass = kk <= 1 ? 0 : (kk <= K_SMALL ? 1 : 2);
         kv = ((uint64_t)(near ? 0 : 1) << 63) | (band << 18) | (kclass << 16) | (L < 0xffff ? L : 0xffff);
     }

@@ -25,7 +25,7 @@ struct mmg_problem {
     uint32_t *d_int_of_ext = nullptr, *d_ext_of_int = nullptr;
     // sliced-ELL stream of k_sample_sell / k_em_sell
     uint8_t *d_sell = nullptr;
-    uint64_t sell_bytes = 0, n_sell_tiles = 0, n_fast_tiles = 0, padded_slots = 0;
+    uint64_t sell_bytes = 0, n_sell_tiles = 0, n_fast_tiles = 0, n_far_tiles = 0, padded_slots = 0;
     mmg::SellTile *d_sell_tiles = nullptr;
     uint64_t *d_sell_chunk = nullptr;
     int grid_sell = 0;

@@ -18,15 +18,20 @@ constexpr uint32_t K_SMALL = MMG_K_SMALL;   // rows with k <= K_SMALL draw k cat
 // ---- canonical layout (restated in oracle/host_oracle.py:canonical_layout) -----------------------
 // Rows are exchangeable in the model (src/mmseq.cpp:857-891 visits them in file order only because that is how they were
 // read); the library stores them sorted by row_key, ties by row_hash, then by the caller's position.
-//   band    = leading transcript >> LAYOUT_BAND_SHIFT         (64 consecutive transcripts)
-//   near    = every hit of the row lies in [band * 64, band * 64 + LAYOUT_NEAR_SPAN) and the row has <= 255 hits
+//   lead    = smallest transcript of the row >> LAYOUT_BAND_SHIFT       (bands of 64 consecutive transcripts)
+//   near    = every hit of the row lies in [lead * 64, lead * 64 + LAYOUT_NEAR_SPAN) and the row has <= 255 hits
+//   band    = lead for a near row; for a far row its HOME band: max(hit[(len - 1) / 2] >> LAYOUT_BAND_SHIFT, 1) - 1, one band below
+//             the row's middle hit -- the window starting there holds the bulk of a row whose other hits lie anywhere
 //   kclass  = 0 (k <= 1), 1 (k <= K_SMALL), 2 (conditional-binomial chain)
 //   key     = !near << 63 | band << 18 | kclass << 16 | min(len, 0xffff)          (an empty row: key 0)
-// A tile of the sliced-ELL stream never crosses a (near, band) boundary, so all its hits fall into ONE 255-wide LDS window
-// starting at band * 64, and its rows have (nearly) equal lengths.
+// A tile of the sliced-ELL stream never crosses a (near, band) boundary.  Near tiles: all hits fall into ONE 255-wide LDS window
+// starting at band * 64, rows of (nearly) equal lengths.  Far tiles: the hits inside [band * 64, band * 64 + SELL_FAR_ESC) are window
+// bytes like a near tile's, every other hit is the escape byte SELL_FAR_ESC and takes its transcript id from the tile's far list.
 constexpr uint32_t LAYOUT_BAND_SHIFT = 6;
 constexpr uint32_t LAYOUT_NEAR_SPAN = 240;
 constexpr uint32_t SELL_WIN = 255;          // transcripts per window; slot 255 holds 0.0
+constexpr uint32_t SELL_FAR_ESC = 254;      // far tiles: this byte = "the next entry of the lane's far list"
+constexpr uint64_t LAYOUT_KEY_BAND_MASK = (1ull << 45) - 1; // key >> 18 & mask = band
 
 // One tile of consecutive rows (k_tile_desc)
 struct TileDesc {
@@ -43,18 +48,22 @@ struct TileDesc {
 };
 
 // tile flags of the sliced-ELL sample and EM kernels
-enum : uint32_t { SELL_FAST = 1, SELL_EMPTY = 4 };
+// FAST: register path (all hits in the window).  FAR: block = 64 length bytes, ng groups of window bytes / escapes, then nf groups of
+// 64 lanes x u32 transcript ids (the lane's far hits in row order), walked by the same kernel through RowViewFarTile.  Neither: the
+// rows are walked from the CSR (rows of more than 255 hits, more than 255 far hits).
+enum : uint32_t { SELL_FAST = 1, SELL_FAR = 2, SELL_EMPTY = 4 };
 
 struct SellTile {
     uint64_t off16;   // 16-byte-unit offset of the tile's block in the stream
     uint64_t r0;      // first row
     uint32_t wbase;   // LDS window base in force while this tile is walked
-    uint32_t meta;    // nrows (<= 64) | ng << 8 (groups of 4 hits stored for every lane: longest row of the tile) | flags << 16
+    uint32_t meta;    // nrows (<= 64) | ng << 8 (groups of 4 hits stored for every lane: longest row of the tile) | flags << 16 | nf << 24
     MMG_TYPES_HD uint32_t nrows() const { return meta & 0xffu; }
     MMG_TYPES_HD uint32_t ng() const { return (meta >> 8) & 0xffu; }
-    MMG_TYPES_HD uint32_t flags() const { return meta >> 16; }
+    MMG_TYPES_HD uint32_t flags() const { return (meta >> 16) & 0xffu; }
+    MMG_TYPES_HD uint32_t nf() const { return meta >> 24; } // far tiles: entries per lane in the far list (most far hits of a row)
 };  // dwords only: the descriptors are fetched with scalar loads
-MMG_TYPES_HD inline uint32_t sell_meta(uint32_t nrows, uint32_t ng, uint32_t flags) { return nrows | (ng << 8) | (flags << 16); }
+MMG_TYPES_HD inline uint32_t sell_meta(uint32_t nrows, uint32_t ng, uint32_t flags, uint32_t nf = 0) { return nrows | (ng << 8) | (flags << 16) | (nf << 24); }
 
 struct SampleArgs {
     uint64_t seed;

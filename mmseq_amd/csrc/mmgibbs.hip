@@ -103,9 +103,10 @@ void mmg::weighted_chunks(const std::vector<uint64_t> &cum, uint64_t grid, std::
     chunk[grid] = nt;
 }
 constexpr uint64_t SELL_SLOW_TILE_COST = 24; // measured: a CSR-walked tile against a register-path tile
+constexpr uint64_t SELL_FAR_TILE_COST = 3;   // a far tile with an empty far list; plus one per far-list entry
 
 // Sliced-ELL stream: tiles of <= 64 rows that never cross a (near, band) boundary of the canonical order, one window per tile.
-static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_starts)
+static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_starts, const uint64_t *d_key)
 {
     if (p->m == 0 || opt(MMG_OPT_SAMPLE_KERNEL) == 0) return MMG_OK;
     // Tiles of <= 64 rows inside the runs of equal (near, band).  The rows of a tile must lie within 32 consecutive Philox
@@ -132,6 +133,36 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
     SELL_TRY(hipGetLastError());
     std::vector<TileDesc> td(nt);
     SELL_TRY(hipMemcpy(td.data(), d_td, nt * sizeof(TileDesc), hipMemcpyDeviceToHost));
+    const uint32_t WIN = SELL_WIN, BAND_MASK = ~((1u << LAYOUT_BAND_SHIFT) - 1u);
+    // a tile qualifies for the register path iff its hits fit one window whose base is a band start and no row exceeds 255 hits
+    auto qualifies = [&](const TileDesc &d) {
+        return d.nnz > 0 && d.maxlen <= 255 && d.nrows <= 64 && (uint64_t)d.cmax < (uint64_t)(d.call & BAND_MASK) + WIN;
+    };
+    // the others become far tiles (window bytes + a far list) when their rows are short enough: ask the device for the window base
+    // their rows were sorted for and the longest far list
+    std::vector<uint32_t> far_wbase(nt, 0), far_nf(nt, 0xffffffffu);
+    {
+        std::vector<uint32_t> cand;
+        for (uint64_t t = 0; t < nt; ++t)
+            if (td[t].nnz > 0 && !qualifies(td[t]) && td[t].maxlen <= 255 && td[t].nrows <= 64) cand.push_back((uint32_t)t);
+        if (!cand.empty() && d_key) {
+            uint32_t *d_cand = nullptr, *d_out = nullptr;
+            auto cleanup2 = [&]() { if (d_cand) (void)hipFree(d_cand); if (d_out) (void)hipFree(d_out); };
+            hipError_t e = hipMalloc((void **)&d_cand, cand.size() * 4);
+            if (e == hipSuccess) e = hipMalloc((void **)&d_out, cand.size() * 8);
+            if (e == hipSuccess) e = hipMemcpy(d_cand, cand.data(), cand.size() * 4, hipMemcpyHostToDevice);
+            std::vector<uint32_t> out(cand.size() * 2);
+            if (e == hipSuccess) {
+                launch_tile_far(p->idx64, p->d_row_ptr, p->d_col, d_key, d_tile_row, d_cand, cand.size(), d_out, d_out + cand.size(), 0);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipMemcpy(out.data(), d_out, out.size() * 4, hipMemcpyDeviceToHost);
+            cleanup2();
+            if (e != hipSuccess) { cleanup(); return fail(MMG_ERR_HIP, std::string("far tiles: ") + hipGetErrorString(e)); }
+            for (size_t i = 0; i < cand.size(); ++i) { far_wbase[cand[i]] = out[i]; far_nf[cand[i]] = out[cand.size() + i]; }
+        }
+    }
+    auto is_far = [&](uint64_t t) { return far_nf[t] <= 255u; };
     cleanup();
 #undef SELL_TRY
     int per_cu = 0;
@@ -139,27 +170,33 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
     if (per_cu > 32) per_cu = 32;
     if (opt(MMG_OPT_SELL_WAVES_PER_CU) >= 1 && opt(MMG_OPT_SELL_WAVES_PER_CU) < per_cu) per_cu = opt(MMG_OPT_SELL_WAVES_PER_CU);
     const uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>(nt, (uint64_t)p->cu_count * per_cu));
-    const uint32_t WIN = SELL_WIN, BAND_MASK = ~((1u << LAYOUT_BAND_SHIFT) - 1u);
-    // a tile qualifies for the register path iff its hits fit one window whose base is a band start and no row exceeds 255 hits
-    auto qualifies = [&](const TileDesc &d) {
-        return d.nnz > 0 && d.maxlen <= 255 && d.nrows <= 64 && (uint64_t)d.cmax < (uint64_t)(d.call & BAND_MASK) + WIN;
-    };
     p->h_sell_cum.assign(nt + 1, 0);
     for (uint64_t t = 0; t < nt; ++t)
-        p->h_sell_cum[t + 1] = p->h_sell_cum[t] + (td[t].nnz == 0 ? 0 : qualifies(td[t]) ? 1 : SELL_SLOW_TILE_COST);
+        p->h_sell_cum[t + 1] = p->h_sell_cum[t] + (td[t].nnz == 0 ? 0 : qualifies(td[t]) ? 1 : is_far(t) ? SELL_FAR_TILE_COST + far_nf[t] : SELL_SLOW_TILE_COST);
     std::vector<uint64_t> chunk;
     weighted_chunks(p->h_sell_cum, grid, chunk);
     std::vector<SellTile> st(nt);
-    uint64_t n_fast = 0, n_live = 0, pos = 0, slots = 0;
+    uint64_t n_fast = 0, n_far = 0, n_live = 0, pos = 0, slots = 0;
     for (uint64_t c = 0; c < grid; ++c) {
         bool have = false;
         uint32_t cur = 0;
-        for (uint64_t t = chunk[c]; t < chunk[c + 1]; ++t) if (td[t].nnz) { cur = td[t].call & BAND_MASK; break; }
+        for (uint64_t t = chunk[c]; t < chunk[c + 1]; ++t) if (td[t].nnz) { cur = is_far(t) ? far_wbase[t] : td[t].call & BAND_MASK; break; }
         for (uint64_t t = chunk[c]; t < chunk[c + 1]; ++t) {
             const TileDesc &d = td[t];
             SellTile &q = st[t];
             q.off16 = 0; q.r0 = d.r0;
             if (d.nnz == 0) { q.meta = sell_meta(d.nrows, 0, SELL_EMPTY); q.wbase = cur; continue; }
+            if (is_far(t)) { // its own window: the one its bytes are relative to
+                cur = far_wbase[t]; have = true;
+                q.wbase = cur;
+                const uint32_t ng = (d.maxlen + 3) / 4;
+                q.meta = sell_meta(d.nrows, ng, SELL_FAR, far_nf[t]);
+                q.off16 = pos;
+                pos += 4 + 16 * (uint64_t)ng + 16 * (uint64_t)far_nf[t];
+                ++n_far;
+                ++n_live;
+                continue;
+            }
             // keep the window in force when the whole tile lies inside it; otherwise slide to the band start of its smallest id
             const bool inside = have && d.call >= cur && (uint64_t)d.cmax < (uint64_t)cur + WIN;
             if (!inside) { cur = d.call & BAND_MASK; have = true; }
@@ -186,6 +223,7 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
     p->sell_bytes = pos * 16;
     p->n_sell_tiles = nt;
     p->n_fast_tiles = n_fast;
+    p->n_far_tiles = n_far;
     p->padded_slots = slots;
     const size_t alloc = p->sell_bytes + 64 + 8 * 256; // head room: tiles without a block prefetch the head of the stream
     HIP_TRY(hipMalloc((void **)&p->d_sell, alloc));
@@ -287,7 +325,6 @@ static int problem_build(mmg_problem *p, uint64_t *d_rp64)
         const uint64_t max_seg = p->layout == (int)MMG_LAYOUT_CANONICAL ? std::min<uint64_t>(p->m, 2 * ((uint64_t)p->n >> LAYOUT_BAND_SHIFT) + 4)
                                                                           : std::max<uint64_t>(1024, p->m / 32);
         B_TRY(layout_segments(p->m, d_key, max_seg, seg, 0));
-        (void)hipFree(d_key); d_key = nullptr;
         B_TRY(layout_max_row_len(p->m, d_rp64, &p->max_row_len, 0));
     }
     p->idx64 = p->nnz >= 0xffffffffull || opt(MMG_OPT_FORCE_IDX64) == 1;
@@ -301,7 +338,8 @@ static int problem_build(mmg_problem *p, uint64_t *d_rp64)
         p->device_bytes += (p->m + 1) * 4;
     }
 #undef B_TRY
-    int rc = problem_build_sell(p, seg);
+    int rc = problem_build_sell(p, seg, d_key);
+    if (d_key) { (void)hipFree(d_key); d_key = nullptr; }
     if (rc == MMG_OK && !p->use_sell) rc = problem_build_csr_tiles(p, d_rp64);
     if (!p->idx64) (void)hipFree(d_rp64);
     return rc;
@@ -456,6 +494,7 @@ extern "C" int mmg_problem_info_get(const mmg_problem *p, mmg_problem_info *info
     info->sample_kernel = p->use_sell ? 2 : 0;
     info->stream_bytes = p->use_sell ? p->sell_bytes : 0;
     info->fast_tiles = p->n_fast_tiles;
+    info->far_tiles = p->n_far_tiles;
     info->padded_slots = p->padded_slots;
     info->layout = p->layout;
     info->tx_renumbered = p->renumbered() ? 1 : 0;

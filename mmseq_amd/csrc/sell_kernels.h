@@ -35,7 +35,41 @@ struct SellBlock {
     }
 };
 
+// Far-tile facts the host needs before it can lay the stream out: the window base a tile's rows were sorted for (the band field of
+// the first non-empty row's key, mmg_types.h) and the most hits a row of the tile has outside [base, base + SELL_FAR_ESC).
+template <typename IdxT>
+__global__ __launch_bounds__(64) void k_tile_far(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
+                                                 const uint64_t *__restrict__ key, const uint64_t *__restrict__ tile_row,
+                                                 const uint32_t *__restrict__ cand, uint64_t n_cand,
+                                                 uint32_t *__restrict__ out_wbase, uint32_t *__restrict__ out_nf)
+{
+    if (blockIdx.x >= n_cand) return;
+    const uint64_t tile = cand[blockIdx.x]; // the host asks only about tiles that missed the register path
+    const uint64_t r0 = tile_row[tile], r1 = tile_row[tile + 1];
+    const uint32_t lane = threadIdx.x;
+    uint64_t first = ~0ull; // first non-empty row of the tile
+    for (uint64_t r = r0 + lane; r < r1; r += 64)
+        if (key[r] != 0) { first = r; break; }
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint64_t o = ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(first >> 32), off) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)first, off);
+        first = o < first ? o : first;
+    }
+    uint32_t wbase = 0, nf = 0;
+    if (first != ~0ull) {
+        wbase = (uint32_t)(((key[first] >> 18) & LAYOUT_KEY_BAND_MASK) << LAYOUT_BAND_SHIFT);
+        for (uint64_t r = r0 + lane; r < r1; r += 64) {
+            uint32_t f = 0;
+            for (uint64_t j = row_ptr[r], e = row_ptr[r + 1]; j < e; ++j) f += (col_idx[j] - wbase) >= SELL_FAR_ESC;
+            nf = max(nf, f);
+        }
+        for (int off = 32; off > 0; off >>= 1) nf = max(nf, (uint32_t)__shfl_xor((int)nf, off));
+    }
+    if (lane == 0) { out_wbase[blockIdx.x] = wbase; out_nf[blockIdx.x] = nf; }
+}
+
 // Block of a fast tile: 64 length bytes, then ng groups of 64 lanes x 4 u8 window indices (col - wbase), 255 = pad.
+// Block of a far tile: the same, a hit outside [wbase, wbase + SELL_FAR_ESC) is the byte SELL_FAR_ESC; then nf groups of 64 lanes x u32:
+// the transcript ids of the lane's escapes in row order (0 beyond the row's own count).
 template <typename IdxT>
 __global__ __launch_bounds__(64) void k_encode_sell(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
                                                     const SellTile *__restrict__ tiles, uint64_t n_tiles, uint8_t *stream)
@@ -43,7 +77,8 @@ __global__ __launch_bounds__(64) void k_encode_sell(const IdxT *__restrict__ row
     const uint64_t tile = blockIdx.x;
     if (tile >= n_tiles) return;
     const SellTile d = tiles[tile];
-    if (!(d.flags() & SELL_FAST)) return;
+    if (!(d.flags() & (SELL_FAST | SELL_FAR))) return;
+    const bool far_tile = d.flags() & SELL_FAR;
     uint8_t *blk = stream + d.off16 * 16;
     const uint32_t lane = threadIdx.x;
     uint64_t b = 0;
@@ -52,18 +87,98 @@ __global__ __launch_bounds__(64) void k_encode_sell(const IdxT *__restrict__ row
         b = row_ptr[d.r0 + lane];
         L = (uint32_t)((uint64_t)row_ptr[d.r0 + lane + 1] - b);
     }
-    blk[lane] = (uint8_t)L; // fast tiles hold rows of at most 255 hits
+    blk[lane] = (uint8_t)L; // these tiles hold rows of at most 255 hits
     uint32_t *grp = (uint32_t *)(blk + 64) + lane;
+    uint32_t *far = (uint32_t *)(blk + 64 + (size_t)d.ng() * 256) + lane;
+    uint32_t nfar = 0;
     for (uint32_t g = 0; g < d.ng(); ++g) {
         uint32_t w = 0;
         for (uint32_t j = 0; j < 4; ++j) {
             const uint32_t idx = 4 * g + j;
-            const uint32_t o = idx < L ? col_idx[b + idx] - d.wbase : SELL_WIN;
+            uint32_t o = SELL_WIN;
+            if (idx < L) {
+                const uint32_t c = col_idx[b + idx];
+                o = c - d.wbase;
+                if (far_tile && o >= SELL_FAR_ESC) { far[(size_t)nfar * 64] = c; ++nfar; o = SELL_FAR_ESC; }
+            }
             w |= o << (8 * j);
         }
         grp[(size_t)g * 64] = w;
     }
+    if (far_tile)
+        for (; nfar < d.nf(); ++nfar) far[(size_t)nfar * 64] = 0;
 }
+
+// One row of a far tile (k_encode_sell): window bytes and escapes in row order, the escapes' transcripts in the lane's far list.
+// total() / pick() add the weights in row order like every other view (pads read the window's 0.0 slot), so the draw equals the
+// oracle's sequential walk; col() / w() serve the multiplicity paths through a cursor that counts the escapes before a position.
+struct RowViewFarTile {
+    const uint32_t *grp; // group words of this lane: grp[g * 64]
+    const uint32_t *far; // far list of this lane: far[f * 64]
+    uint32_t L;
+    uint32_t wbase;
+    const double *s_mu;
+    const double *gmu;
+    mutable uint32_t cj = 0, cf = 0;                  // cursor: cf escapes among the bytes [0, cj)
+    mutable uint32_t pj = 0xffffffffu, pcol = 0;      // the hit pick() returned last
+    __device__ __forceinline__ uint32_t byte(uint32_t j) const { return (grp[(size_t)(j >> 2) * 64] >> (8u * (j & 3u))) & 0xffu; }
+    __device__ __forceinline__ uint32_t col(uint32_t j) const
+    {
+        if (j == pj) return pcol;
+        if (j < cj) { cj = 0; cf = 0; }
+        while (cj < j) { cf += byte(cj) == SELL_FAR_ESC; ++cj; }
+        const uint32_t o = byte(j);
+        return o == SELL_FAR_ESC ? far[(size_t)cf * 64] : wbase + o;
+    }
+    __device__ __forceinline__ double wc(uint32_t c) const
+    {
+        const uint32_t d = c - wbase;
+        return d < SELL_WIN ? s_mu[d] : gmu[c];
+    }
+    __device__ __forceinline__ double w(uint32_t j) const { return wc(col(j)); }
+    __device__ __forceinline__ double total() const
+    {
+        double t = 0.0;
+        uint32_t f = 0;
+        const uint32_t ng = (L + 3u) >> 2;
+        for (uint32_t g = 0; g < ng; ++g) {
+            const uint32_t v = grp[(size_t)g * 64];
+#pragma unroll
+            for (uint32_t b = 0; b < 4; ++b) {
+                const uint32_t o = (v >> (8u * b)) & 0xffu;
+                double wv;
+                if (o == SELL_FAR_ESC) { wv = gmu[far[(size_t)f * 64]]; ++f; }
+                else wv = s_mu[o]; // a pad reads slot 255 = 0.0
+                t += wv;
+            }
+        }
+        return t;
+    }
+    __device__ __forceinline__ uint32_t pick(double target) const
+    {
+        double acc = 0.0;
+        uint32_t f = 0, last = 0;
+        const uint32_t ng = (L + 3u) >> 2;
+        for (uint32_t g = 0; g < ng; ++g) {
+            const uint32_t v = grp[(size_t)g * 64];
+#pragma unroll
+            for (uint32_t b = 0; b < 4; ++b) {
+                const uint32_t o = (v >> (8u * b)) & 0xffu, j = 4u * g + b;
+                uint32_t c = wbase + o;
+                double wv;
+                if (o == SELL_FAR_ESC) { c = far[(size_t)f * 64]; wv = gmu[c]; ++f; }
+                else wv = s_mu[o];
+                acc += wv;
+                if (j < L) {
+                    last = c;
+                    if (target < acc) { pj = j; pcol = c; return j; }
+                }
+            }
+        }
+        pj = L - 1; pcol = last; // rounding left target >= total: the last hit
+        return L - 1;
+    }
+};
 
 template <typename IdxT, bool HAS_K, int NGC, int REP = 1>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 1 : 7, HAS_K ? 8 : 7))) void k_sample_sell(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
@@ -303,6 +418,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 1 : 
         }
     };
 
+    auto far_tile = [&](const SellTile &d) {
+        if (lane < d.nrows()) {
+            const uint8_t *__restrict__ blk = stream + d.off16 * 16;
+            const uint32_t wbase = d.wbase;
+            auto add = [&](uint32_t col, int32_t x) {
+                const uint32_t dd = col - wbase;
+                if (dd < (uint32_t)WIN) atomicAdd(&s_cnt[dd], x);
+                else global_count_add(gcnt, col, x);
+            };
+            RowViewFarTile v{(const uint32_t *)(blk + 64) + lane, (const uint32_t *)(blk + 64 + (size_t)d.ng() * 256) + lane, blk[lane], wbase,
+                             s_mu, gmu};
+            allocate_row<HAS_K>(v, add, HAS_K ? kmult[d.r0 + lane] : 1u, a, a.row_id_base + d.r0 + lane);
+        }
+    };
+
     auto process = [&](const SellTile &d, uint32_t &cur_base, const SellTile &refill, Buf &bf, uint32_t which) {
         if (d.flags() & SELL_EMPTY) { issue(refill, bf); return; }
         if (d.wbase != cur_base) {
@@ -313,6 +443,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 1 : 
             __syncthreads();
         }
         if (d.flags() & SELL_FAST) walk(d, bf, which);
+        else if (d.flags() & SELL_FAR) far_tile(d);
         else slow_tile(d);
         issue(refill, bf); // the registers are free again only now: tile i+2 travels while tile i+1 is walked
     };

@@ -276,8 +276,9 @@ K_SMALL = 8
 
 
 def row_keys(row_ptr, col_idx, k=None):
-    """(key, hash) per row: key = !near << 63 | band << 18 | kclass << 16 | min(len, 0xffff) (0 for an empty row);
-    hash = fold of (len, k, hits in stored order)."""
+    """(key, hash) per row: key = !near << 63 | band << 18 | kclass << 16 | min(len, 0xffff) (0 for an empty row), band = the band
+    of the smallest hit for a near row, the home band (one below the band of hit[(len - 1) // 2]) for a far row;
+    hash = fold of (len, k, hits in stored order).  Spec: mmseq_amd/csrc/mmg_types.h."""
     rp = np.asarray(row_ptr).astype(np.int64)
     col = np.asarray(col_idx, np.uint32)
     L = np.diff(rp)
@@ -292,6 +293,8 @@ def row_keys(row_ptr, col_idx, k=None):
         band = lo >> np.uint64(LAYOUT_BAND_SHIFT)
         Ln = L[ne].astype(np.uint64)
         near = (Ln <= 255) & (hi - (band << np.uint64(LAYOUT_BAND_SHIFT)) < LAYOUT_NEAR_SPAN)
+        mid = col[starts + (L[ne] - 1) // 2].astype(np.uint64) >> np.uint64(LAYOUT_BAND_SHIFT)
+        band = np.where(near, band, np.maximum(mid, np.uint64(1)) - np.uint64(1))
         kn = kk[ne]
         kclass = np.where(kn <= 1, 0, np.where(kn <= K_SMALL, 1, 2)).astype(np.uint64)
         key[ne] = ((~near).astype(np.uint64) << np.uint64(63)) | (band << np.uint64(18)) | (kclass << np.uint64(16)) | \

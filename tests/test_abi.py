@@ -34,7 +34,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.SynthDesc) == 64
     assert C.sizeof(_lib.Config) == 48
     assert C.sizeof(_lib.Timing) == 32
-    assert C.sizeof(_lib.ProblemInfo) == 104
+    assert C.sizeof(_lib.ProblemInfo) == 112
 
 
 def test_no_cpu_fallback_without_device():

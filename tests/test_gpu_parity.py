@@ -282,6 +282,46 @@ def test_sliced_ell_kernel_edge_rows(gpu, orc, with_k, keep_rows):
     assert np.array_equal(s.trace(0), ref["trace"])
 
 
+@pytest.mark.parametrize("with_k", [False, True])
+def test_far_tiles_bit_exact(gpu, orc, with_k):
+    """Rows with hits outside their window (reads that also hit a paralogue elsewhere in the transcriptome) sort by their HOME band
+    and are walked from far tiles: window bytes, escapes, a far list per lane.  Far hits below and above the window, rows that are
+    mostly far, multiplicities up to the binomial chain, EM and fused chains (which still walk these rows from the CSR)."""
+    rng = np.random.default_rng(21)
+    p, _ = orc.synth_problem(R=60000, T=20000, avg_hits=9, seed=77, sort=False, far_fraction=0.3)
+    rp, ci = p.row_ptr.astype(np.int64), p.col_idx.copy()
+    rows = [ci[rp[i]:rp[i + 1]].tolist() for i in range(0, 3000)]
+    # hand-made shapes: a row scattered over the whole range, one far hit in front / behind, exactly 254 / 255 apart, a far-only pair
+    rows += [sorted(rng.choice(20000, size=40, replace=False).tolist()) for _ in range(100)]
+    rows += [[3, 9000, 9001, 9002, 9050], [9000, 9001, 9050, 19999], [6400, 6400 + 253], [6400, 6400 + 254], [6400, 6400 + 255],
+             [0, 19999], [64, 5000, 5001], []]
+    ci = np.concatenate([p.col_idx[rp[3000]:], np.concatenate([np.asarray(r, np.uint32) for r in rows if r])]).astype(np.uint32)
+    lens = np.concatenate([np.diff(rp)[3000:], [len(r) for r in rows]])
+    rp2 = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    k = rng.choice([1, 1, 1, 2, 8, 9, 300], size=lens.size).astype(np.uint32) if with_k else None
+    q = orc.Problem(rp2, ci, p.l, k=k)
+    mu0, _ = orc.start_values(q)
+    mu0[::7] = 1e-200
+    prob, qs = _dev(gpu, orc, q)
+    inf = prob.info
+    assert inf.sample_kernel == 2 and inf.far_tiles > 0.2 * inf.n_tiles and inf.fast_tiles + inf.far_tiles >= inf.n_tiles - 2
+    s = gpu.Sampler(prob, mu0, seed=5, gibbs_iter=8, trace_len=8)
+    s.sample()
+    assert np.array_equal(s.counts(0), orc.sample_counts(qs, mu0, seed=5, chain=0, it=0))
+    s.update()
+    s.run(7)
+    ref = orc.gibbs_keyed(qs, mu0, seed=5, n_iter=8, trace_len=8)
+    assert np.array_equal(s.counts(0), ref["cnt"]) and np.array_equal(s.trace(0), ref["trace"])
+    g_mu, g_it, g_ll = prob.em(mu0, max_iter=5, epsilon=-1e308)
+    o_mu, o_it, o_ll = orc.em(qs, mu0, max_iter=5, epsilon=-1e308)
+    assert np.array_equal(g_mu, o_mu) and g_ll == o_ll
+    if not with_k:
+        m2 = gpu.Sampler(prob, mu0, seed=5, n_chains=2, gibbs_iter=4, trace_len=4)
+        m2.run(4)
+        for c in range(2):
+            assert np.array_equal(m2.trace(c), orc.gibbs_keyed(qs, mu0, seed=5, chain=c, n_iter=4, trace_len=4)["trace"])
+
+
 def test_chains_and_shards_reproduce_single_chain(gpu, orc):
     """(a) chain c of a multi-chain sampler == a single-chain sampler with chain_base=c;
     (b) read-sharding: two shards' counts summed (the all-reduce) == the unsharded chain."""
