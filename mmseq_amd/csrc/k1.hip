@@ -36,11 +36,11 @@ void launch_tile_desc(bool idx64, const void *row_ptr, const uint32_t *col, cons
 }
 
 void launch_tile_far(bool idx64, const void *row_ptr, const uint32_t *col, const uint64_t *key, const uint64_t *tile_row,
-                     const uint32_t *cand, uint64_t n_cand, uint32_t *out_wbase, uint32_t *out_nf, hipStream_t s)
+                     const uint32_t *cand, uint64_t n_cand, uint32_t *out /* [3][n_cand] */, hipStream_t s)
 {
     if (!n_cand) return;
-    if (idx64) hipLaunchKernelGGL(k_tile_far<uint64_t>, dim3((unsigned)n_cand), dim3(64), 0, s, (const uint64_t *)row_ptr, col, key, tile_row, cand, n_cand, out_wbase, out_nf);
-    else hipLaunchKernelGGL(k_tile_far<uint32_t>, dim3((unsigned)n_cand), dim3(64), 0, s, (const uint32_t *)row_ptr, col, key, tile_row, cand, n_cand, out_wbase, out_nf);
+    if (idx64) hipLaunchKernelGGL(k_tile_far<uint64_t>, dim3((unsigned)n_cand), dim3(64), 0, s, (const uint64_t *)row_ptr, col, key, tile_row, cand, n_cand, out);
+    else hipLaunchKernelGGL(k_tile_far<uint32_t>, dim3((unsigned)n_cand), dim3(64), 0, s, (const uint32_t *)row_ptr, col, key, tile_row, cand, n_cand, out);
 }
 
 void launch_encode_sell(bool idx64, const void *row_ptr, const uint32_t *col, const SellTile *tiles, uint64_t n_tiles,

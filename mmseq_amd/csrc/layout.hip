@@ -14,7 +14,10 @@
 
 namespace mmg {
 
-__global__ __launch_bounds__(256) void k_row_keys(uint64_t m, const uint64_t *__restrict__ rp, const uint32_t *__restrict__ col,
+// SORT_HITS (canonical layout): a row's hits are put in ascending order first -- the order the reference's compressed_matrix
+// iterates them in whatever order they were inserted (src/mmseq.cpp:871) -- so that key and hash are functions of the SET of hits.
+template <bool SORT_HITS>
+__global__ __launch_bounds__(256) void k_row_keys(uint64_t m, const uint64_t *__restrict__ rp, uint32_t *col,
                                                   const uint32_t *__restrict__ k, uint64_t *__restrict__ key,
                                                   uint64_t *__restrict__ hash, uint32_t *__restrict__ len)
 {
@@ -23,6 +26,17 @@ __global__ __launch_bounds__(256) void k_row_keys(uint64_t m, const uint64_t *__
     const uint64_t b = rp[r], e = rp[r + 1];
     const uint64_t L = e - b;
     const uint32_t kk = k ? k[r] : 1u;
+    if (SORT_HITS) {
+        bool ascending = true;
+        for (uint64_t j = b + 1; j < e; ++j) ascending = ascending && col[j - 1] <= col[j];
+        if (!ascending) // rare (hits files list them sorted, src/bam2hits.cpp:271-300): insertion sort by the row's own thread
+            for (uint64_t j = b + 1; j < e; ++j) {
+                const uint32_t c = col[j];
+                uint64_t q = j;
+                while (q > b && col[q - 1] > c) { col[q] = col[q - 1]; --q; }
+                col[q] = c;
+            }
+    }
     uint64_t h = 0x9E3779B97F4A7C15ull + L + ((uint64_t)kk << 32);
     uint32_t lo = 0xffffffffu, hi = 0;
     for (uint64_t j = b; j < e; ++j) {
@@ -36,8 +50,18 @@ __global__ __launch_bounds__(256) void k_row_keys(uint64_t m, const uint64_t *__
     if (L) {
         uint64_t band = lo >> LAYOUT_BAND_SHIFT;
         const bool near = L <= 255 && (uint64_t)hi - (band << LAYOUT_BAND_SHIFT) < LAYOUT_NEAR_SPAN;
-        if (!near) { // home band: one below the band of the row's middle hit
-            const uint64_t mid = col[b + (L - 1) / 2] >> LAYOUT_BAND_SHIFT;
+        if (!near) { // home band: one below the band of the row's (lower) median hit
+            uint32_t med = col[b + (L - 1) / 2];
+            if (!SORT_HITS) { // rows kept as given (e.g. a stored far row: window hits first): the median by rank, not by position
+                const uint64_t want = (L - 1) / 2;
+                for (uint64_t i = b; i < e; ++i) {
+                    const uint32_t c = col[i];
+                    uint64_t less = 0, equal = 0;
+                    for (uint64_t j = b; j < e; ++j) { less += col[j] < c; equal += col[j] == c; }
+                    if (less <= want && want < less + equal) { med = c; break; }
+                }
+            }
+            const uint64_t mid = med >> LAYOUT_BAND_SHIFT;
             band = (mid > 1 ? mid : 1) - 1;
         }
         const uint64_t kclass = kk <= 1 ? 0 : (kk <= K_SMALL ? 1 : 2);
@@ -61,15 +85,24 @@ __global__ __launch_bounds__(256) void k_gather(uint64_t m, const T *__restrict_
     if (r < m) out[r] = in[idx[r]];
 }
 
-// stored row r <- caller row idx[r]
+// stored row r <- caller row idx[r].  A far row (key bit 63) is stored with the hits inside its home window
+// [band * 64, band * 64 + SELL_WIN) first and the others behind them, both in ascending order (mmg_types.h).
 __global__ __launch_bounds__(256) void k_gather_csr(uint64_t m, const uint64_t *__restrict__ rp_old, const uint32_t *__restrict__ col_old,
                                                     const uint32_t *__restrict__ idx, const uint64_t *__restrict__ rp_new,
-                                                    uint32_t *__restrict__ col_new)
+                                                    const uint64_t *__restrict__ key, uint32_t *__restrict__ col_new)
 {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= m) return;
     const uint64_t s = rp_old[idx[r]], d = rp_new[r], L = rp_new[r + 1] - d;
-    for (uint64_t j = 0; j < L; ++j) col_new[d + j] = col_old[s + j];
+    const uint64_t kv = key[r];
+    if (!(kv >> 63)) {
+        for (uint64_t j = 0; j < L; ++j) col_new[d + j] = col_old[s + j];
+        return;
+    }
+    const uint32_t wbase = (uint32_t)(((kv >> 18) & LAYOUT_KEY_BAND_MASK) << LAYOUT_BAND_SHIFT);
+    uint64_t o = d;
+    for (uint64_t j = 0; j < L; ++j) { const uint32_t c = col_old[s + j]; if (c - wbase < SELL_WIN) col_new[o++] = c; }
+    for (uint64_t j = 0; j < L; ++j) { const uint32_t c = col_old[s + j]; if (c - wbase >= SELL_WIN) col_new[o++] = c; }
 }
 
 __global__ __launch_bounds__(256) void k_segment_starts(uint64_t m, const uint64_t *__restrict__ key, uint64_t cap, uint64_t *out,
@@ -109,7 +142,7 @@ static inline unsigned blocks_of(uint64_t n) { return (unsigned)((n + 255) / 256
 
 hipError_t layout_row_keys(uint64_t m, const uint64_t *d_rp, const uint32_t *d_col, const uint32_t *d_k, uint64_t *d_key, hipStream_t s)
 {
-    if (m) hipLaunchKernelGGL(k_row_keys, dim3(blocks_of(m)), dim3(256), 0, s, m, d_rp, d_col, d_k, d_key, (uint64_t *)nullptr, (uint32_t *)nullptr);
+    if (m) hipLaunchKernelGGL(k_row_keys<false>, dim3(blocks_of(m)), dim3(256), 0, s, m, d_rp, const_cast<uint32_t *>(d_col), d_k, d_key, (uint64_t *)nullptr, (uint32_t *)nullptr);
     return hipGetLastError();
 }
 
@@ -162,7 +195,7 @@ hipError_t layout_canonical_sort(uint64_t m, uint64_t nnz, uint64_t **d_rp, uint
     L_TRY(hipMalloc((void **)&idx, m * 4));
     L_TRY(hipMalloc((void **)&idx2, m * 4));
     const unsigned g = blocks_of(m);
-    hipLaunchKernelGGL(k_row_keys, dim3(g), dim3(256), 0, s, m, *d_rp, *d_col, d_k ? *d_k : (uint32_t *)nullptr, d_key, hash, len);
+    hipLaunchKernelGGL(k_row_keys<true>, dim3(g), dim3(256), 0, s, m, (const uint64_t *)*d_rp, *d_col, d_k ? (const uint32_t *)*d_k : (const uint32_t *)nullptr, d_key, hash, len);
     hipLaunchKernelGGL(k_iota, dim3(g), dim3(256), 0, s, m, idx);
     L_TRY(hipGetLastError());
     // least significant first: content hash, then the key; both sorts are stable, so equal (key, hash) keep the caller's order
@@ -183,7 +216,7 @@ hipError_t layout_canonical_sort(uint64_t m, uint64_t nnz, uint64_t **d_rp, uint
     L_TRY(hipMalloc((void **)&col_new, (nnz + col_pad) * 4));
     L_TRY(hipMemsetAsync(col_new + nnz, 0, col_pad * 4, s));
     hipLaunchKernelGGL(k_gather_csr, dim3(g), dim3(256), 0, s, m, (const uint64_t *)*d_rp, (const uint32_t *)*d_col, (const uint32_t *)idx,
-                       (const uint64_t *)rp_new, col_new);
+                       (const uint64_t *)rp_new, (const uint64_t *)d_key, col_new);
     if (d_k && *d_k) {
         L_TRY(hipMalloc((void **)&kk_new, m * 4));
         hipLaunchKernelGGL(k_gather<uint32_t>, dim3(g), dim3(256), 0, s, m, (const uint32_t *)*d_k, (const uint32_t *)idx, kk_new);

@@ -15,7 +15,7 @@ const void *k1_csr_kernel(bool idx64, bool has_k);    // k_sample, K1C_BS thread
 void launch_tile_desc(bool idx64, const void *row_ptr, const uint32_t *col, const uint64_t *tile_row, uint64_t n_tiles,
                       TileDesc *out, hipStream_t s);
 void launch_tile_far(bool idx64, const void *row_ptr, const uint32_t *col, const uint64_t *key, const uint64_t *tile_row,
-                     const uint32_t *cand, uint64_t n_cand, uint32_t *out_wbase, uint32_t *out_nf, hipStream_t s);
+                     const uint32_t *cand, uint64_t n_cand, uint32_t *out /* [3][n_cand] */, hipStream_t s);
 void launch_encode_sell(bool idx64, const void *row_ptr, const uint32_t *col, const SellTile *tiles, uint64_t n_tiles,
                         uint8_t *stream, hipStream_t s);
 

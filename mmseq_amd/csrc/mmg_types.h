@@ -15,22 +15,25 @@ namespace mmg {
 
 constexpr uint32_t K_SMALL = MMG_K_SMALL;   // rows with k <= K_SMALL draw k categoricals; above, a conditional-binomial chain
 
-// ---- canonical layout (restated in oracle/host_oracle.py:canonical_layout) -----------------------
+// ---- canonical layout (restated in oracle/binding.py:canonical_layout) -----------------------------
 // Rows are exchangeable in the model (src/mmseq.cpp:857-891 visits them in file order only because that is how they were
-// read); the library stores them sorted by row_key, ties by row_hash, then by the caller's position.
+// read), and a row is a SET of transcripts (the reference walks it in ascending order, :871).  The library puts every row's hits in
+// ascending order and stores the rows sorted by row_key, ties by row_hash, then by the caller's position.
 //   lead    = smallest transcript of the row >> LAYOUT_BAND_SHIFT       (bands of 64 consecutive transcripts)
 //   near    = every hit of the row lies in [lead * 64, lead * 64 + LAYOUT_NEAR_SPAN) and the row has <= 255 hits
-//   band    = lead for a near row; for a far row its HOME band: max(hit[(len - 1) / 2] >> LAYOUT_BAND_SHIFT, 1) - 1, one band below
-//             the row's middle hit -- the window starting there holds the bulk of a row whose other hits lie anywhere
+//   band    = lead for a near row; for a far row its HOME band: max(median hit >> LAYOUT_BAND_SHIFT, 1) - 1 (lower median,
+//             hit[(len - 1) / 2] of the ascending row): the window starting one band below the row's middle holds its bulk
 //   kclass  = 0 (k <= 1), 1 (k <= K_SMALL), 2 (conditional-binomial chain)
 //   key     = !near << 63 | band << 18 | kclass << 16 | min(len, 0xffff)          (an empty row: key 0)
+//   hash    = fold of (len, k, the ascending hits)
+// A FAR row is stored with the hits inside its home window [band * 64, band * 64 + SELL_WIN) first and the others behind them, each part
+// ascending: the stored order of a row's hits is the order every kernel and the oracle add its weights in.
 // A tile of the sliced-ELL stream never crosses a (near, band) boundary.  Near tiles: all hits fall into ONE 255-wide LDS window
-// starting at band * 64, rows of (nearly) equal lengths.  Far tiles: the hits inside [band * 64, band * 64 + SELL_FAR_ESC) are window
-// bytes like a near tile's, every other hit is the escape byte SELL_FAR_ESC and takes its transcript id from the tile's far list.
+// starting at band * 64, rows of (nearly) equal lengths.  Far tiles: the window part of every row is encoded exactly like a near
+// tile, the other hits are transcript ids in a per-lane far list behind it.
 constexpr uint32_t LAYOUT_BAND_SHIFT = 6;
 constexpr uint32_t LAYOUT_NEAR_SPAN = 240;
 constexpr uint32_t SELL_WIN = 255;          // transcripts per window; slot 255 holds 0.0
-constexpr uint32_t SELL_FAR_ESC = 254;      // far tiles: this byte = "the next entry of the lane's far list"
 constexpr uint64_t LAYOUT_KEY_BAND_MASK = (1ull << 45) - 1; // key >> 18 & mask = band
 
 // One tile of consecutive rows (k_tile_desc)
@@ -48,9 +51,10 @@ struct TileDesc {
 };
 
 // tile flags of the sliced-ELL sample and EM kernels
-// FAST: register path (all hits in the window).  FAR: block = 64 length bytes, ng groups of window bytes / escapes, then nf groups of
-// 64 lanes x u32 transcript ids (the lane's far hits in row order), walked by the same kernel through RowViewFarTile.  Neither: the
-// rows are walked from the CSR (rows of more than 255 hits, more than 255 far hits).
+// FAST: register path (all hits in the window).  FAR: the block of a fast tile for the rows' window hits (64 count bytes, ng groups),
+// then 64 far-count bytes and nf groups of 64 lanes x u32 transcript ids (the lane's hits outside the window, in stored order); the
+// sample kernel walks the window part on the register path and adds the far list behind it.  Neither: the rows are walked from the
+// CSR (rows of more than 255 hits, rows kept in an order that is not "window hits first").
 enum : uint32_t { SELL_FAST = 1, SELL_FAR = 2, SELL_EMPTY = 4 };
 
 struct SellTile {

@@ -103,7 +103,7 @@ void mmg::weighted_chunks(const std::vector<uint64_t> &cum, uint64_t grid, std::
     chunk[grid] = nt;
 }
 constexpr uint64_t SELL_SLOW_TILE_COST = 24; // measured: a CSR-walked tile against a register-path tile
-constexpr uint64_t SELL_FAR_TILE_COST = 3;   // a far tile with an empty far list; plus one per far-list entry
+constexpr uint64_t SELL_FAR_TILE_COST = 1;   // a far tile: a register-path tile plus one per far-list entry
 
 // Sliced-ELL stream: tiles of <= 64 rows that never cross a (near, band) boundary of the canonical order, one window per tile.
 static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_starts, const uint64_t *d_key)
@@ -138,9 +138,9 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
     auto qualifies = [&](const TileDesc &d) {
         return d.nnz > 0 && d.maxlen <= 255 && d.nrows <= 64 && (uint64_t)d.cmax < (uint64_t)(d.call & BAND_MASK) + WIN;
     };
-    // the others become far tiles (window bytes + a far list) when their rows are short enough: ask the device for the window base
-    // their rows were sorted for and the longest far list
-    std::vector<uint32_t> far_wbase(nt, 0), far_nf(nt, 0xffffffffu);
+    // the others become far tiles (a fast tile's block for the window hits + a far list) when their rows are short enough and stored
+    // window-hits-first: ask the device for the window base their rows were sorted for and the sizes of the two parts
+    std::vector<uint32_t> far_wbase(nt, 0), far_nn(nt, 0), far_nf(nt, 0xffffffffu);
     {
         std::vector<uint32_t> cand;
         for (uint64_t t = 0; t < nt; ++t)
@@ -148,18 +148,19 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
         if (!cand.empty() && d_key) {
             uint32_t *d_cand = nullptr, *d_out = nullptr;
             auto cleanup2 = [&]() { if (d_cand) (void)hipFree(d_cand); if (d_out) (void)hipFree(d_out); };
-            hipError_t e = hipMalloc((void **)&d_cand, cand.size() * 4);
-            if (e == hipSuccess) e = hipMalloc((void **)&d_out, cand.size() * 8);
-            if (e == hipSuccess) e = hipMemcpy(d_cand, cand.data(), cand.size() * 4, hipMemcpyHostToDevice);
-            std::vector<uint32_t> out(cand.size() * 2);
+            const size_t nc = cand.size();
+            hipError_t e = hipMalloc((void **)&d_cand, nc * 4);
+            if (e == hipSuccess) e = hipMalloc((void **)&d_out, nc * 12);
+            if (e == hipSuccess) e = hipMemcpy(d_cand, cand.data(), nc * 4, hipMemcpyHostToDevice);
+            std::vector<uint32_t> out(nc * 3);
             if (e == hipSuccess) {
-                launch_tile_far(p->idx64, p->d_row_ptr, p->d_col, d_key, d_tile_row, d_cand, cand.size(), d_out, d_out + cand.size(), 0);
+                launch_tile_far(p->idx64, p->d_row_ptr, p->d_col, d_key, d_tile_row, d_cand, nc, d_out, 0);
                 e = hipGetLastError();
             }
             if (e == hipSuccess) e = hipMemcpy(out.data(), d_out, out.size() * 4, hipMemcpyDeviceToHost);
             cleanup2();
             if (e != hipSuccess) { cleanup(); return fail(MMG_ERR_HIP, std::string("far tiles: ") + hipGetErrorString(e)); }
-            for (size_t i = 0; i < cand.size(); ++i) { far_wbase[cand[i]] = out[i]; far_nf[cand[i]] = out[cand.size() + i]; }
+            for (size_t i = 0; i < nc; ++i) { far_wbase[cand[i]] = out[i]; far_nn[cand[i]] = out[nc + i]; far_nf[cand[i]] = out[2 * nc + i]; }
         }
     }
     auto is_far = [&](uint64_t t) { return far_nf[t] <= 255u; };
@@ -189,10 +190,11 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
             if (is_far(t)) { // its own window: the one its bytes are relative to
                 cur = far_wbase[t]; have = true;
                 q.wbase = cur;
-                const uint32_t ng = (d.maxlen + 3) / 4;
+                const uint32_t ng = (far_nn[t] + 3) / 4;
                 q.meta = sell_meta(d.nrows, ng, SELL_FAR, far_nf[t]);
                 q.off16 = pos;
-                pos += 4 + 16 * (uint64_t)ng + 16 * (uint64_t)far_nf[t];
+                pos += 4 + 16 * (uint64_t)ng + 4 + 16 * (uint64_t)far_nf[t];
+                slots += 256 * (uint64_t)ng + 64 * (uint64_t)far_nf[t];
                 ++n_far;
                 ++n_live;
                 continue;

@@ -36,12 +36,13 @@ struct SellBlock {
 };
 
 // Far-tile facts the host needs before it can lay the stream out: the window base a tile's rows were sorted for (the band field of
-// the first non-empty row's key, mmg_types.h) and the most hits a row of the tile has outside [base, base + SELL_FAR_ESC).
+// the first non-empty row's key, mmg_types.h), the most window hits and the most other hits a row of the tile has -- or "not a far
+// tile" (nf = ~0) when some row is not stored window-hits-first (rows kept in the caller's order).
 template <typename IdxT>
 __global__ __launch_bounds__(64) void k_tile_far(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
                                                  const uint64_t *__restrict__ key, const uint64_t *__restrict__ tile_row,
                                                  const uint32_t *__restrict__ cand, uint64_t n_cand,
-                                                 uint32_t *__restrict__ out_wbase, uint32_t *__restrict__ out_nf)
+                                                 uint32_t *__restrict__ out /* [3][n_cand]: wbase, most window hits, nf */)
 {
     if (blockIdx.x >= n_cand) return;
     const uint64_t tile = cand[blockIdx.x]; // the host asks only about tiles that missed the register path
@@ -54,22 +55,32 @@ __global__ __launch_bounds__(64) void k_tile_far(const IdxT *__restrict__ row_pt
         const uint64_t o = ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(first >> 32), off) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)first, off);
         first = o < first ? o : first;
     }
-    uint32_t wbase = 0, nf = 0;
+    uint32_t wbase = 0, nn = 0, nf = 0;
     if (first != ~0ull) {
         wbase = (uint32_t)(((key[first] >> 18) & LAYOUT_KEY_BAND_MASK) << LAYOUT_BAND_SHIFT);
         for (uint64_t r = r0 + lane; r < r1; r += 64) {
-            uint32_t f = 0;
-            for (uint64_t j = row_ptr[r], e = row_ptr[r + 1]; j < e; ++j) f += (col_idx[j] - wbase) >= SELL_FAR_ESC;
-            nf = max(nf, f);
+            uint32_t n = 0, f = 0;
+            bool ordered = true;
+            for (uint64_t j = row_ptr[r], e = row_ptr[r + 1]; j < e; ++j) {
+                const bool in = (col_idx[j] - wbase) < SELL_WIN;
+                ordered = ordered && !(in && f > 0); // a window hit behind a far one
+                n += in;
+                f += !in;
+            }
+            nn = max(nn, n);
+            nf = max(nf, ordered ? f : 0xffffffffu);
         }
-        for (int off = 32; off > 0; off >>= 1) nf = max(nf, (uint32_t)__shfl_xor((int)nf, off));
+        for (int off = 32; off > 0; off >>= 1) {
+            nn = max(nn, (uint32_t)__shfl_xor((int)nn, off));
+            nf = max(nf, (uint32_t)__shfl_xor((int)nf, off));
+        }
     }
-    if (lane == 0) { out_wbase[blockIdx.x] = wbase; out_nf[blockIdx.x] = nf; }
+    if (lane == 0) { out[blockIdx.x] = wbase; out[n_cand + blockIdx.x] = nn; out[2 * n_cand + blockIdx.x] = nf; }
 }
 
 // Block of a fast tile: 64 length bytes, then ng groups of 64 lanes x 4 u8 window indices (col - wbase), 255 = pad.
-// Block of a far tile: the same, a hit outside [wbase, wbase + SELL_FAR_ESC) is the byte SELL_FAR_ESC; then nf groups of 64 lanes x u32:
-// the transcript ids of the lane's escapes in row order (0 beyond the row's own count).
+// Block of a far tile: the same for the window hits at the head of every row (the length byte counts those), then 64 far-count bytes
+// and nf groups of 64 lanes x u32: the transcript ids of the lane's other hits in stored order (0 beyond the row's own count).
 template <typename IdxT>
 __global__ __launch_bounds__(64) void k_encode_sell(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
                                                     const SellTile *__restrict__ tiles, uint64_t n_tiles, uint8_t *stream)
@@ -78,104 +89,67 @@ __global__ __launch_bounds__(64) void k_encode_sell(const IdxT *__restrict__ row
     if (tile >= n_tiles) return;
     const SellTile d = tiles[tile];
     if (!(d.flags() & (SELL_FAST | SELL_FAR))) return;
-    const bool far_tile = d.flags() & SELL_FAR;
     uint8_t *blk = stream + d.off16 * 16;
     const uint32_t lane = threadIdx.x;
     uint64_t b = 0;
-    uint32_t L = 0;
+    uint32_t L = 0, Ln = 0;
     if (lane < d.nrows()) {
         b = row_ptr[d.r0 + lane];
         L = (uint32_t)((uint64_t)row_ptr[d.r0 + lane + 1] - b);
+        Ln = L;
+        if (d.flags() & SELL_FAR)
+            for (Ln = 0; Ln < L && (col_idx[b + Ln] - d.wbase) < SELL_WIN; ++Ln) {}
     }
-    blk[lane] = (uint8_t)L; // these tiles hold rows of at most 255 hits
+    blk[lane] = (uint8_t)Ln; // these tiles hold rows of at most 255 hits
     uint32_t *grp = (uint32_t *)(blk + 64) + lane;
-    uint32_t *far = (uint32_t *)(blk + 64 + (size_t)d.ng() * 256) + lane;
-    uint32_t nfar = 0;
     for (uint32_t g = 0; g < d.ng(); ++g) {
         uint32_t w = 0;
         for (uint32_t j = 0; j < 4; ++j) {
             const uint32_t idx = 4 * g + j;
-            uint32_t o = SELL_WIN;
-            if (idx < L) {
-                const uint32_t c = col_idx[b + idx];
-                o = c - d.wbase;
-                if (far_tile && o >= SELL_FAR_ESC) { far[(size_t)nfar * 64] = c; ++nfar; o = SELL_FAR_ESC; }
-            }
+            const uint32_t o = idx < Ln ? col_idx[b + idx] - d.wbase : SELL_WIN;
             w |= o << (8 * j);
         }
         grp[(size_t)g * 64] = w;
     }
-    if (far_tile)
-        for (; nfar < d.nf(); ++nfar) far[(size_t)nfar * 64] = 0;
+    if (d.flags() & SELL_FAR) {
+        uint8_t *fb = blk + 64 + (size_t)d.ng() * 256;
+        fb[lane] = (uint8_t)(L - Ln);
+        uint32_t *far = (uint32_t *)(fb + 64) + lane;
+        for (uint32_t f = 0; f < d.nf(); ++f) far[(size_t)f * 64] = f < L - Ln ? col_idx[b + Ln + f] : 0u;
+    }
 }
 
-// One row of a far tile (k_encode_sell): window bytes and escapes in row order, the escapes' transcripts in the lane's far list.
-// total() / pick() add the weights in row order like every other view (pads read the window's 0.0 slot), so the draw equals the
-// oracle's sequential walk; col() / w() serve the multiplicity paths through a cursor that counts the escapes before a position.
+// One row of a far tile for the multiplicity kernel: hit j is window byte j of the lane for j < Ln, entry j - Ln of its far list
+// beyond.  Plain sequential loops (rows with multiplicities AND far hits are rare); the additions happen in stored order.
 struct RowViewFarTile {
     const uint32_t *grp; // group words of this lane: grp[g * 64]
     const uint32_t *far; // far list of this lane: far[f * 64]
-    uint32_t L;
+    uint32_t Ln, L;      // window hits, all hits
     uint32_t wbase;
     const double *s_mu;
     const double *gmu;
-    mutable uint32_t cj = 0, cf = 0;                  // cursor: cf escapes among the bytes [0, cj)
-    mutable uint32_t pj = 0xffffffffu, pcol = 0;      // the hit pick() returned last
-    __device__ __forceinline__ uint32_t byte(uint32_t j) const { return (grp[(size_t)(j >> 2) * 64] >> (8u * (j & 3u))) & 0xffu; }
     __device__ __forceinline__ uint32_t col(uint32_t j) const
     {
-        if (j == pj) return pcol;
-        if (j < cj) { cj = 0; cf = 0; }
-        while (cj < j) { cf += byte(cj) == SELL_FAR_ESC; ++cj; }
-        const uint32_t o = byte(j);
-        return o == SELL_FAR_ESC ? far[(size_t)cf * 64] : wbase + o;
+        return j < Ln ? wbase + ((grp[(size_t)(j >> 2) * 64] >> (8u * (j & 3u))) & 0xffu) : far[(size_t)(j - Ln) * 64];
     }
-    __device__ __forceinline__ double wc(uint32_t c) const
+    __device__ __forceinline__ double w(uint32_t j) const
     {
-        const uint32_t d = c - wbase;
-        return d < SELL_WIN ? s_mu[d] : gmu[c];
+        const uint32_t c = col(j);
+        return j < Ln ? s_mu[c - wbase] : gmu[c];
     }
-    __device__ __forceinline__ double w(uint32_t j) const { return wc(col(j)); }
     __device__ __forceinline__ double total() const
     {
         double t = 0.0;
-        uint32_t f = 0;
-        const uint32_t ng = (L + 3u) >> 2;
-        for (uint32_t g = 0; g < ng; ++g) {
-            const uint32_t v = grp[(size_t)g * 64];
-#pragma unroll
-            for (uint32_t b = 0; b < 4; ++b) {
-                const uint32_t o = (v >> (8u * b)) & 0xffu;
-                double wv;
-                if (o == SELL_FAR_ESC) { wv = gmu[far[(size_t)f * 64]]; ++f; }
-                else wv = s_mu[o]; // a pad reads slot 255 = 0.0
-                t += wv;
-            }
-        }
+        for (uint32_t j = 0; j < L; ++j) t += w(j);
         return t;
     }
     __device__ __forceinline__ uint32_t pick(double target) const
     {
         double acc = 0.0;
-        uint32_t f = 0, last = 0;
-        const uint32_t ng = (L + 3u) >> 2;
-        for (uint32_t g = 0; g < ng; ++g) {
-            const uint32_t v = grp[(size_t)g * 64];
-#pragma unroll
-            for (uint32_t b = 0; b < 4; ++b) {
-                const uint32_t o = (v >> (8u * b)) & 0xffu, j = 4u * g + b;
-                uint32_t c = wbase + o;
-                double wv;
-                if (o == SELL_FAR_ESC) { c = far[(size_t)f * 64]; wv = gmu[c]; ++f; }
-                else wv = s_mu[o];
-                acc += wv;
-                if (j < L) {
-                    last = c;
-                    if (target < acc) { pj = j; pcol = c; return j; }
-                }
-            }
+        for (uint32_t j = 0; j < L; ++j) {
+            acc += w(j);
+            if (target < acc) return j;
         }
-        pj = L - 1; pcol = last; // rounding left target >= total: the last hit
         return L - 1;
     }
 };
@@ -238,7 +212,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 1 : 
     // number issued per tile must not depend on the path -- otherwise the compiler has to assume the fewest, and every walk
     // waits for the prefetch issued just before it.  Groups beyond the tile's ng fail the descriptor's range check: no memory access.
     auto issue = [&](const SellTile &d, Buf &bf) {
-        const bool fast = d.flags() & SELL_FAST; // uniform
+        const bool fast = d.flags() & (SELL_FAST | SELL_FAR); // uniform: the tile has a block (a far tile's window part is a fast tile's)
         const SellBlock blk(stream + (fast ? d.off16 * 16 : 0), d.meta);
         bf.len = blk.len(lane);
         if (HAS_K) bf.kk = kmult[(fast ? d.r0 : 0) + min(lane, (fast ? d.nrows() : 1u) - 1u)];
@@ -314,7 +288,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 1 : 
             const double w0 = wo(SELL_OFF0(v)), w1 = wo(SELL_OFF1(v)), w2 = wo(SELL_OFF2(v)), w3 = wo(SELL_OFF3(v));
             t += w0; t += w1; t += w2; t += w3;
         }
-        if (L == 0) return;
+        // far tile: the lane's hits outside the window follow in its far list (stored order: window hits first, mmg_types.h)
+        uint32_t Lf = 0;
+        const uint32_t *__restrict__ farp = nullptr;
+        if (!HAS_K && (d.flags() & SELL_FAR)) { // uniform
+            const uint8_t *__restrict__ fb = stream + d.off16 * 16 + 64 + (size_t)ng * 256;
+            Lf = fb[lane];
+            farp = (const uint32_t *)(fb + 64) + lane;
+            for (uint32_t f = 0; f < Lf; ++f) t += gmu[farp[(size_t)f * 64]];
+        }
+        if (L + Lf == 0) return;
+        uint32_t farc = 0; // the transcript of a pick from the far list (draw() then returns FAR_PICK)
+        constexpr uint32_t FAR_PICK = 0xffffffffu;
         // offsets of group g of this lane's row
         // 8-way selections: one compare-and-select per candidate with an empty asm between the steps (a visible chain or
         // tree of selects is rewritten into a dynamically indexed stack table, i.e. scratch memory traffic per row)
@@ -328,7 +313,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 1 : 
             return r;
         };
         auto off_of = [&](uint32_t j) -> uint32_t { return ((group_of(j >> 2) >> (8u * (j & 3u))) & 0xffu) << 3; };
-        auto add = [&](uint32_t off, int32_t x) { atomicAdd((int32_t *)((char *)s_cnt + rep_off + (off >> 1)), x); };
+        auto add = [&](uint32_t off, int32_t x) {
+            if (!HAS_K && off == FAR_PICK) global_count_add(gcnt, farc, x);
+            else atomicAdd((int32_t *)((char *)s_cnt + rep_off + (off >> 1)), x);
+        };
         const uint32_t kk = HAS_K ? bf.kk : 1u;
         if (HAS_K && kk == 0) return;
         // a single hit needs no draw; without multiplicities the general path picks it anyway (same result, one branch less)
@@ -352,8 +340,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 1 : 
             uint32_t sel = target < p0 ? o0 : (target < p1 ? o1 : (target < p2 ? o2 : o3));
             if (!hit) { // rare: a degenerate total (0, inf, NaN never compare below anything), a row of more than 32 hits, rounding
                 if (degenerate) {
-                    const uint32_t j = (uint32_t)(u * (double)L);
-                    sel = off_of(j < L ? j : L - 1);
+                    const uint32_t Lt = L + Lf;
+                    uint32_t j = (uint32_t)(u * (double)Lt);
+                    j = j < Lt ? j : Lt - 1;
+                    if (j < L) sel = off_of(j);
+                    else { farc = farp[(size_t)(j - L) * 64]; sel = FAR_PICK; }
                 } else {
                     double accl = P7;
                     bool found = false;
@@ -365,7 +356,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 1 : 
                         if (target < r3) { sel = target < r0 ? q0 : (target < r1 ? q1 : (target < r2 ? q2 : q3)); found = true; }
                         accl = r3;
                     }
-                    if (!found) sel = off_of(L - 1); // rounding left target >= total: the last real hit
+                    for (uint32_t f = 0; f < Lf && !found; ++f) { // the far list continues the row
+                        const uint32_t c = farp[(size_t)f * 64];
+                        accl += gmu[c];
+                        if (target < accl) { farc = c; sel = FAR_PICK; found = true; }
+                    }
+                    if (!found) { // rounding left target >= total: the last real hit
+                        if (Lf) { farc = farp[(size_t)(Lf - 1) * 64]; sel = FAR_PICK; }
+                        else sel = off_of(L - 1);
+                    }
                 }
             }
             return sel;
@@ -420,15 +419,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 1 : 
 
     auto far_tile = [&](const SellTile &d) {
         if (lane < d.nrows()) {
-            const uint8_t *__restrict__ blk = stream + d.off16 * 16;
-            const uint32_t wbase = d.wbase;
+            const uint8_t *__restrict__ blk = stream + d.off16 * 16, *__restrict__ fb = blk + 64 + (size_t)d.ng() * 256;
+            const uint32_t wbase = d.wbase, Ln = blk[lane];
             auto add = [&](uint32_t col, int32_t x) {
                 const uint32_t dd = col - wbase;
                 if (dd < (uint32_t)WIN) atomicAdd(&s_cnt[dd], x);
                 else global_count_add(gcnt, col, x);
             };
-            RowViewFarTile v{(const uint32_t *)(blk + 64) + lane, (const uint32_t *)(blk + 64 + (size_t)d.ng() * 256) + lane, blk[lane], wbase,
-                             s_mu, gmu};
+            const RowViewFarTile v{(const uint32_t *)(blk + 64) + lane, (const uint32_t *)(fb + 64) + lane, Ln, Ln + fb[lane], wbase, s_mu, gmu};
             allocate_row<HAS_K>(v, add, HAS_K ? kmult[d.r0 + lane] : 1u, a, a.row_id_base + d.r0 + lane);
         }
     };
@@ -442,8 +440,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 1 : 
             cur_base = d.wbase;
             __syncthreads();
         }
-        if (d.flags() & SELL_FAST) walk(d, bf, which);
-        else if (d.flags() & SELL_FAR) far_tile(d);
+        if (d.flags() & (HAS_K ? SELL_FAST : SELL_FAST | SELL_FAR)) walk(d, bf, which);
+        else if (d.flags() & SELL_FAR) far_tile(d); // with multiplicities: the generic row walk over the tile's block
         else slow_tile(d);
         issue(refill, bf); // the registers are free again only now: tile i+2 travels while tile i+1 is walked
     };

@@ -319,12 +319,35 @@ def permute_rows(row_ptr, col_idx, k, perm):
     return new_rp, np.ascontiguousarray(np.asarray(col_idx)[idx]), (None if k is None else np.ascontiguousarray(np.asarray(k)[perm]))
 
 
+SELL_WIN = 255  # transcripts per LDS window (mmg_types.h)
+
+
+def sort_hits(row_ptr, col_idx):
+    """Every row's hits in ascending order (a row is a set; src/mmseq.cpp:871 walks it in ascending order)."""
+    rp = np.asarray(row_ptr).astype(np.int64)
+    col = np.asarray(col_idx, np.uint32)
+    if col.size == 0:
+        return col.copy()
+    rid = np.repeat(np.arange(rp.size - 1, dtype=np.int64), np.diff(rp))
+    return np.ascontiguousarray(col[np.lexsort((col, rid))])
+
+
 def canonical_layout(row_ptr, col_idx, k=None):
-    """Rows in the library's stored order: sorted by (key, hash), ties in the caller's order.  Returns (row_ptr, col_idx, k, perm)
-    with perm[stored row] = caller row."""
-    key, h = row_keys(row_ptr, col_idx, k)
+    """Rows in the library's stored order (spec: mmseq_amd/csrc/mmg_types.h): hits ascending within every row, rows sorted by
+    (key, hash), ties in the caller's order; a far row then keeps the hits inside its home window in front of the others.
+    Returns (row_ptr, col_idx, k, perm) with perm[stored row] = caller row."""
+    col_sorted = sort_hits(row_ptr, col_idx)
+    key, h = row_keys(row_ptr, col_sorted, k)
     perm = np.lexsort((h, key))
-    rp, ci, kk = permute_rows(row_ptr, col_idx, k, perm)
+    rp, ci, kk = permute_rows(row_ptr, col_sorted, k, perm)
+    skey = key[perm]
+    far = (skey >> np.uint64(63)).astype(bool)
+    if far.any() and ci.size:
+        lens = np.diff(rp.astype(np.int64))
+        rid = np.repeat(np.arange(lens.size, dtype=np.int64), lens)
+        wbase = (((skey >> np.uint64(18)) & np.uint64((1 << 45) - 1)) << np.uint64(LAYOUT_BAND_SHIFT)).astype(np.uint32)
+        outside = far[rid] & ((ci - wbase[rid]).astype(np.uint32) >= SELL_WIN)  # u32 wrap-around: hits below the window are outside
+        ci = np.ascontiguousarray(ci[np.lexsort((ci, outside, rid))])
     return rp, ci, kk, perm
 
 

@@ -135,7 +135,7 @@ def test_canonical_layout_properties(orc):
     rng = np.random.default_rng(0)
     k = rng.choice([1, 1, 2, 9], size=p.m).astype(np.uint32)
     rp, ci, kk, perm = orc.canonical_layout(p.row_ptr, p.col_idx, k)
-    key, h = orc.row_keys(rp, ci, kk)
+    key, h = orc.row_keys(rp, orc.sort_hits(rp, ci), kk)   # key and hash are functions of the SET of hits
     assert (key[1:] >= key[:-1]).all()
     same = key[1:] == key[:-1]
     assert (h[1:][same] >= h[:-1][same]).all()
@@ -147,3 +147,16 @@ def test_canonical_layout_properties(orc):
     assert np.array_equal(rp3, rp) and np.array_equal(ci3, ci) and np.array_equal(kk3, kk)
     far = key >> np.uint64(63)
     assert 0 < far.sum() < p.m and (np.diff(far.astype(np.int64)) >= 0).all()
+    # a far row is stored with the hits inside its home window first, both parts ascending; every other row ascending
+    wbase = (((key >> np.uint64(18)) & np.uint64((1 << 45) - 1)) << np.uint64(6)).astype(np.int64)
+    n_far_hits = 0
+    for r in range(p.m):
+        row = ci[int(rp[r]):int(rp[r + 1])].astype(np.int64)
+        if not far[r]:
+            assert (np.diff(row) > 0).all()
+            continue
+        inside = (row >= wbase[r]) & (row < wbase[r] + 255)
+        nin = int(inside.sum())
+        assert inside[:nin].all() and (np.diff(row[:nin]) > 0).all() and (np.diff(row[nin:]) > 0).all()
+        n_far_hits += row.size - nin
+    assert n_far_hits > 0

@@ -1,5 +1,5 @@
-"""A/B timing of K1 between builds of libmmgibbs.so on ONE box (boxes of the pool differ by +-10 %, runs on different boxes cannot
-be compared).  usage: k1_ab.py lib_a.so lib_b.so ... [--rows R --transcripts T --avg A --rounds N]
+"""A/B timing of K1 between builds of libmmgibbs.so on ONE box (same box, same process regime: one HIP runtime per process).
+usage: k1_ab.py lib_a.so lib_b.so ... [--rows R --transcripts T --avg A --far F --rounds N]
 Each library is measured in its own subprocess, round-robin, N rounds; prints the mean K1 launch time per library and round."""
 import argparse, json, os, subprocess, sys
 
@@ -20,8 +20,8 @@ for _name in list(_lib.SYMBOLS):          # older builds export fewer entry poin
     if not hasattr(_probe, _name):
         del _lib.SYMBOLS[_name]
 from mmseq_amd import Problem, Sampler
-R, T, A, C = int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), int(sys.argv[5])
-prob = Problem.synthetic(R, T, A, seed=1234)
+R, T, A, C, F = int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), int(sys.argv[5]), float(sys.argv[6])
+prob = Problem.synthetic(R, T, A, seed=1234, far_fraction=F)
 mu0, _ = prob.start_values()
 s = Sampler(prob, mu0, n_chains=C, gibbs_iter=1024, trace_len=1024, keep_trace=False, timing=1)
 s.run(300); s.sync(); s.reset_timing()
@@ -38,12 +38,13 @@ ap.add_argument("--rows", type=int, default=50_000_000)
 ap.add_argument("--transcripts", type=int, default=200_000)
 ap.add_argument("--avg", type=float, default=20.0)
 ap.add_argument("--chains", type=int, default=1)
+ap.add_argument("--far", type=float, default=0.0, help="fraction of the rows with one hit anywhere in the transcriptome")
 ap.add_argument("--rounds", type=int, default=2)
 a = ap.parse_args()
 res = {l: [] for l in a.libs}
 for r in range(a.rounds):
     for l in a.libs:
-        out = subprocess.run([sys.executable, "-c", CHILD, os.path.abspath(l), str(a.rows), str(a.transcripts), str(a.avg), str(a.chains)],
+        out = subprocess.run([sys.executable, "-c", CHILD, os.path.abspath(l), str(a.rows), str(a.transcripts), str(a.avg), str(a.chains), str(a.far)],
                              capture_output=True, text=True)
         line = [x for x in out.stdout.splitlines() if x.startswith("{")]
         if not line:
