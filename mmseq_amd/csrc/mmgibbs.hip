@@ -102,8 +102,12 @@ void mmg::weighted_chunks(const std::vector<uint64_t> &cum, uint64_t grid, std::
     }
     chunk[grid] = nt;
 }
-constexpr uint64_t SELL_SLOW_TILE_COST = 24; // measured: a CSR-walked tile against a register-path tile
-constexpr uint64_t SELL_FAR_TILE_COST = 1;   // a far tile: a register-path tile plus one per far-list entry
+// tile costs for the ranges of the persistent workgroups, in halves of a register-path tile (measured, tools/k1_ab.py --far)
+constexpr uint64_t SELL_FAST_TILE_COST = 2;
+constexpr uint64_t SELL_FAR_TILE_COST = 2;   // plus SELL_FAR_ENTRY_COST per entry of the far list
+constexpr uint64_t SELL_FAR_ENTRY_COST = 3;
+constexpr uint64_t SELL_SLOW_TILE_COST = 48; // a CSR-walked tile
+// k_sample (CSR tiles) costs 2.8 of these units per 64 hits (7.4 ms for 1.0 G uniform hits): a problem dearer on the stream kernel runs there
 
 // Sliced-ELL stream: tiles of <= 64 rows that never cross a (near, band) boundary of the canonical order, one window per tile.
 static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_starts, const uint64_t *d_key)
@@ -173,11 +177,11 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
     const uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>(nt, (uint64_t)p->cu_count * per_cu));
     p->h_sell_cum.assign(nt + 1, 0);
     for (uint64_t t = 0; t < nt; ++t)
-        p->h_sell_cum[t + 1] = p->h_sell_cum[t] + (td[t].nnz == 0 ? 0 : qualifies(td[t]) ? 1 : is_far(t) ? SELL_FAR_TILE_COST + far_nf[t] : SELL_SLOW_TILE_COST);
+        p->h_sell_cum[t + 1] = p->h_sell_cum[t] + (td[t].nnz == 0 ? 0 : qualifies(td[t]) ? SELL_FAST_TILE_COST : is_far(t) ? SELL_FAR_TILE_COST + SELL_FAR_ENTRY_COST * far_nf[t] : SELL_SLOW_TILE_COST);
     std::vector<uint64_t> chunk;
     weighted_chunks(p->h_sell_cum, grid, chunk);
     std::vector<SellTile> st(nt);
-    uint64_t n_fast = 0, n_far = 0, n_live = 0, pos = 0, slots = 0;
+    uint64_t n_fast = 0, n_far = 0, pos = 0, slots = 0;
     for (uint64_t c = 0; c < grid; ++c) {
         bool have = false;
         uint32_t cur = 0;
@@ -196,7 +200,6 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
                 pos += 4 + 16 * (uint64_t)ng + 4 + 16 * (uint64_t)far_nf[t];
                 slots += 256 * (uint64_t)ng + 64 * (uint64_t)far_nf[t];
                 ++n_far;
-                ++n_live;
                 continue;
             }
             // keep the window in force when the whole tile lies inside it; otherwise slide to the band start of its smallest id
@@ -214,13 +217,11 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
             } else {
                 q.meta = sell_meta(d.nrows, 0, 0);
             }
-            ++n_live;
         }
     }
-    // tiles that do not qualify are walked from the CSR inside the same kernel; half the tiles on the register path already
-    // beats the CSR kernel (far rows are sorted last, so the slow tiles are a contiguous tail)
-    const double fast_fraction = n_live ? (double)n_fast / (double)n_live : 0.0;
-    p->use_sell = fast_fraction >= 0.5 || opt(MMG_OPT_SAMPLE_KERNEL) == 2;
+    // tiles that do not qualify are walked from their far lists or from the CSR inside the same kernel (far rows are sorted last:
+    // a contiguous tail); a problem whose tiles cost more than the CSR kernel's on average -- hits uniform over all transcripts -- runs there
+    p->use_sell = p->h_sell_cum[nt] <= p->nnz * 7 / 160 || opt(MMG_OPT_SAMPLE_KERNEL) == 2;
     if (!p->use_sell) { p->h_sell_cum.clear(); return MMG_OK; }
     p->sell_bytes = pos * 16;
     p->n_sell_tiles = nt;

@@ -17,6 +17,7 @@
 namespace mmg {
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+template <bool B> struct BoolTag { static constexpr bool value = B; };
 
 // A tile's block seen through a raw buffer descriptor of exactly its size (64 length bytes + ng groups of 256 bytes).  The sampler and
 // EM kernels request NGC groups per tile whatever its ng (loads retire in order and are waited for by count, so the number issued
@@ -252,7 +253,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 1 : 
         xrowB = (pb & 1u) ? b1 : b0;
     };
 
-    auto walk = [&](const SellTile &d, const Buf &bf, uint32_t which) {
+    // FAR (a tag type): the walk of a far tile -- the same code plus the far list behind the window part; a separate instantiation, so
+    // the walk of a fast tile carries none of it
+    auto walk = [&](const SellTile &d, const Buf &bf, uint32_t which, auto far_tag) {
+        constexpr bool FAR = decltype(far_tag)::value;
         const uint32_t ng = d.ng();                                    // uniform
         const uint32_t *__restrict__ src = (const uint32_t *)(stream + d.off16 * 16 + 64) + lane; // groups beyond the cached ones
         const uint32_t L = bf.len;
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 1 : 
         // far tile: the lane's hits outside the window follow in its far list (stored order: window hits first, mmg_types.h)
         uint32_t Lf = 0;
         const uint32_t *__restrict__ farp = nullptr;
-        if (!HAS_K && (d.flags() & SELL_FAR)) { // uniform
+        if (FAR) {
             const uint8_t *__restrict__ fb = stream + d.off16 * 16 + 64 + (size_t)ng * 256;
             Lf = fb[lane];
             farp = (const uint32_t *)(fb + 64) + lane;
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 1 : 
         };
         auto off_of = [&](uint32_t j) -> uint32_t { return ((group_of(j >> 2) >> (8u * (j & 3u))) & 0xffu) << 3; };
         auto add = [&](uint32_t off, int32_t x) {
-            if (!HAS_K && off == FAR_PICK) global_count_add(gcnt, farc, x);
+            if (FAR && off == FAR_PICK) global_count_add(gcnt, farc, x);
             else atomicAdd((int32_t *)((char *)s_cnt + rep_off + (off >> 1)), x);
         };
         const uint32_t kk = HAS_K ? bf.kk : 1u;
@@ -343,7 +347,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 1 : 
                     const uint32_t Lt = L + Lf;
                     uint32_t j = (uint32_t)(u * (double)Lt);
                     j = j < Lt ? j : Lt - 1;
-                    if (j < L) sel = off_of(j);
+                    if (!FAR || j < L) sel = off_of(j);
                     else { farc = farp[(size_t)(j - L) * 64]; sel = FAR_PICK; }
                 } else {
                     double accl = P7;
@@ -356,13 +360,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 1 : 
                         if (target < r3) { sel = target < r0 ? q0 : (target < r1 ? q1 : (target < r2 ? q2 : q3)); found = true; }
                         accl = r3;
                     }
-                    for (uint32_t f = 0; f < Lf && !found; ++f) { // the far list continues the row
+                    for (uint32_t f = 0; FAR && f < Lf && !found; ++f) { // the far list continues the row
                         const uint32_t c = farp[(size_t)f * 64];
                         accl += gmu[c];
                         if (target < accl) { farc = c; sel = FAR_PICK; found = true; }
                     }
                     if (!found) { // rounding left target >= total: the last real hit
-                        if (Lf) { farc = farp[(size_t)(Lf - 1) * 64]; sel = FAR_PICK; }
+                        if (FAR && Lf) { farc = farp[(size_t)(Lf - 1) * 64]; sel = FAR_PICK; }
                         else sel = off_of(L - 1);
                     }
                 }
@@ -440,7 +444,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 1 : 
             cur_base = d.wbase;
             __syncthreads();
         }
-        if (d.flags() & (HAS_K ? SELL_FAST : SELL_FAST | SELL_FAR)) walk(d, bf, which);
+        if (d.flags() & SELL_FAST) walk(d, bf, which, BoolTag<false>());
+        else if (!HAS_K && (d.flags() & SELL_FAR)) walk(d, bf, which, BoolTag<true>());
         else if (d.flags() & SELL_FAR) far_tile(d); // with multiplicities: the generic row walk over the tile's block
         else slow_tile(d);
         issue(refill, bf); // the registers are free again only now: tile i+2 travels while tile i+1 is walked

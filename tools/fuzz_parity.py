@@ -11,8 +11,13 @@ def one_case(seed, gpu, orc, verbose=True):
     R = int(rng.integers(200, 60000))
     avg = float(rng.choice([1.5, 3, 8, 20, 45]))
     sort = bool(rng.integers(0, 4) != 0)
+    far = float(rng.choice([0.0, 0.0, 0.03, 0.5]))      # rows with a hit anywhere in the transcriptome: far tiles
     p, _ = orc.synth_problem(R=R, T=T, avg_hits=avg, seed=int(rng.integers(1, 1 << 30)), sort=sort,
-                             uniform=bool(rng.integers(0, 5) == 0))
+                             uniform=bool(rng.integers(0, 5) == 0), far_fraction=far)
+    if rng.integers(0, 4) == 0:                          # hits of a row in arbitrary order: the canonical layout sorts them
+        rp64 = p.row_ptr.astype(np.int64)
+        rid = np.repeat(np.arange(p.m), np.diff(rp64))
+        p.col_idx[:] = p.col_idx[np.lexsort((rng.random(p.col_idx.size), rid))]
     k = None
     if rng.integers(0, 2):
         k = rng.choice([1, 1, 1, 2, 3, 8, 9, 40, 5000], size=p.m).astype(np.uint32)
@@ -65,8 +70,9 @@ def one_case(seed, gpu, orc, verbose=True):
         info = prob.info
         prob.close()
         if verbose:
-            print("seed %d ok: R=%d T=%d avg=%g sort=%s k=%s keep=%s tx=%s kernel=%d opts=%s" % (seed, pk.m, T, avg, sort, k is not None, keep_rows,
-                                                                                             tx_order is not None, info.sample_kernel, opts), flush=True)
+            print("seed %d ok: R=%d T=%d avg=%g far=%g sort=%s k=%s keep=%s tx=%s kernel=%d tiles %d fast %d far %d opts=%s" % (
+                seed, pk.m, T, avg, far, sort, k is not None, keep_rows, tx_order is not None, info.sample_kernel, info.n_tiles, info.fast_tiles,
+                info.far_tiles, opts), flush=True)
 
 
 if __name__ == "__main__":
