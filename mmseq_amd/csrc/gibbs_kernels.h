@@ -237,30 +237,34 @@ __device__ __forceinline__ void allocate_row(const View &v, Add add, uint32_t kk
 // Per-tile descriptor builder: one 64-lane workgroup per tile.
 template <typename IdxT>
 __global__ __launch_bounds__(64) void k_tile_desc(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
+                                                  const uint32_t *__restrict__ kmult /* may be null */,
                                                   const uint64_t *__restrict__ tile_row, uint64_t n_tiles, TileDesc *out)
 {
     const uint64_t tile = blockIdx.x;
     if (tile >= n_tiles) return;
     const uint64_t r0 = tile_row[tile], r1 = tile_row[tile + 1];
     const uint64_t nz0 = row_ptr[r0], nz1 = row_ptr[r1];
-    uint32_t mx = 0, mn = 0xffffffffu, n4 = 0, ml = 0;
+    uint32_t mx = 0, mn = 0xffffffffu, n4 = 0, ml = 0, kmx = 1, kn1 = 0;
     for (uint64_t j = nz0 + threadIdx.x; j < nz1; j += 64) { const uint32_t c = col_idx[j]; mx = max(mx, c); mn = min(mn, c); }
     for (uint64_t r = r0 + threadIdx.x; r < r1; r += 64) {
         const uint32_t L = (uint32_t)min((uint64_t)0xffffffffu, (uint64_t)row_ptr[r + 1] - (uint64_t)row_ptr[r]);
         n4 += (L + 3u) & ~3u;
         ml = max(ml, L);
+        if (kmult) { const uint32_t kk = kmult[r]; kmx = max(kmx, kk); kn1 += kk != 1u; }
     }
     for (int off = 32; off > 0; off >>= 1) {
         mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
         mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
         n4 += (uint32_t)__shfl_xor((int)n4, off);
         ml = max(ml, (uint32_t)__shfl_xor((int)ml, off));
+        kmx = max(kmx, (uint32_t)__shfl_xor((int)kmx, off));
+        kn1 += (uint32_t)__shfl_xor((int)kn1, off);
     }
     if (threadIdx.x == 0) {
         TileDesc d;
         d.nz0 = nz0; d.r0 = r0; d.nrows = (uint32_t)(r1 - r0);
         d.nnz = (uint32_t)min((uint64_t)0xffffffffu, nz1 - nz0);
-        d.cmin = 0; d.clast = 0; d.cmax = mx; d.call = mn; d.nnz4 = n4; d.maxlen = ml;
+        d.cmin = 0; d.clast = 0; d.cmax = mx; d.call = mn; d.nnz4 = n4; d.maxlen = ml; d.kmax = kmx; d.knot1 = kn1;
         if (nz1 > nz0) {
             d.cmin = col_idx[nz0];
             uint64_t rl = r1 - 1;

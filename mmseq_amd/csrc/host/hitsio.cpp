@@ -269,13 +269,19 @@ void HitsfileWriter::writeHeaderSchema1()
 }
 void HitsfileWriter::writeHeader() { if (hitsfileSchema == 0) writeHeaderSchema0(); else writeHeaderSchema1(); }
 
-void HitsfileWriter::addReadMapRecord(std::string readName) { currentReadName = readName; currentReadTranscripts.clear(); }
+void HitsfileWriter::addReadMapRecord(std::string readName) { currentReadName = readName; currentReadTranscripts.clear(); currentReadIndices.clear(); }
 void HitsfileWriter::addTranscriptToReadMapRecord(std::string name) { currentReadTranscripts.push_back(name); }
+void HitsfileWriter::addTranscriptIndexToReadMapRecord(uint32_t index)
+{
+    if (index >= transcriptName.size()) { std::cerr << "Error: transcript index " << index << " not in the header.\n"; std::exit(1); }
+    currentReadIndices.push_back(index);
+}
 
 void HitsfileWriter::writeReadMapRecordSchema0()
 {
     std::string s = ">" + currentReadName + "\n";
     for (auto &t : currentReadTranscripts) { s += t; s += "\n"; }
+    for (uint32_t i : currentReadIndices) { s += transcriptName[i]; s += "\n"; }
     sink->write(s.data(), s.size());
 }
 void HitsfileWriter::writeReadMapRecordSchema1()
@@ -295,8 +301,9 @@ void HitsfileWriter::writeReadMapRecordSchema1()
         sink->writeSmall(nEnd);
     }
     deltaBuffer = cur;
-    sink->writeU32(currentReadTranscripts.size());
+    sink->writeU32(currentReadTranscripts.size() + currentReadIndices.size());
     for (auto &t : currentReadTranscripts) sink->writeU32(transcriptToIndex[t]);
+    for (uint32_t i : currentReadIndices) sink->writeU32(i);
 }
 void HitsfileWriter::writeReadMapRecord() { if (hitsfileSchema == 0) writeReadMapRecordSchema0(); else writeReadMapRecordSchema1(); }
 

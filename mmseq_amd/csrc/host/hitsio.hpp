@@ -37,6 +37,9 @@ public:
     void writeHeader();
     void addReadMapRecord(std::string readName);
     void addTranscriptToReadMapRecord(std::string transcriptName);
+    // Additive fast path (mirror of HitsfileReader::readReadMapRecordTranscriptIndex): the transcript by its index in the order of
+    // the addTranscriptMetaData calls -- what the binary schema stores (src/hitsio.cpp:240).  Not to be mixed with names in one record.
+    void addTranscriptIndexToReadMapRecord(uint32_t transcriptIndex);
     void writeReadMapRecord();
     void close(); // flushes the compressor (the reference relies on destructor order)
 
@@ -56,6 +59,7 @@ private:
     std::vector<std::vector<std::string>> identicalTranscripts;
     std::string currentReadName;
     std::vector<std::string> currentReadTranscripts;
+    std::vector<uint32_t> currentReadIndices;
     std::string deltaBuffer;
 };
 

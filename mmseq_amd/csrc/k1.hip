@@ -27,12 +27,12 @@ const void *k1_csr_kernel(bool idx64, bool has_k)
                  : (const void *)k_sample<uint32_t, false, K1C_ELEMS, K1C_WIN, K1C_UNR, K1C_BS, K1C_ROWS>;
 }
 
-void launch_tile_desc(bool idx64, const void *row_ptr, const uint32_t *col, const uint64_t *tile_row, uint64_t n_tiles,
+void launch_tile_desc(bool idx64, const void *row_ptr, const uint32_t *col, const uint32_t *kmult, const uint64_t *tile_row, uint64_t n_tiles,
                       TileDesc *out, hipStream_t s)
 {
     if (!n_tiles) return;
-    if (idx64) hipLaunchKernelGGL(k_tile_desc<uint64_t>, dim3((unsigned)n_tiles), dim3(64), 0, s, (const uint64_t *)row_ptr, col, tile_row, n_tiles, out);
-    else hipLaunchKernelGGL(k_tile_desc<uint32_t>, dim3((unsigned)n_tiles), dim3(64), 0, s, (const uint32_t *)row_ptr, col, tile_row, n_tiles, out);
+    if (idx64) hipLaunchKernelGGL(k_tile_desc<uint64_t>, dim3((unsigned)n_tiles), dim3(64), 0, s, (const uint64_t *)row_ptr, col, kmult, tile_row, n_tiles, out);
+    else hipLaunchKernelGGL(k_tile_desc<uint32_t>, dim3((unsigned)n_tiles), dim3(64), 0, s, (const uint32_t *)row_ptr, col, kmult, tile_row, n_tiles, out);
 }
 
 void launch_tile_far(bool idx64, const void *row_ptr, const uint32_t *col, const uint64_t *key, const uint64_t *tile_row,

@@ -29,6 +29,12 @@ struct mmg_problem {
     mmg::SellTile *d_sell_tiles = nullptr;
     uint64_t *d_sell_chunk = nullptr;
     int grid_sell = 0;
+    // problems with multiplicities: the SELL_HASK tiles and the others as two descriptor lists with their own ranges (null / 0: no
+    // SELL_HASK tile -- the one launch over d_sell_tiles does everything)
+    mmg::SellTile *d_sell_tiles_1 = nullptr, *d_sell_tiles_k = nullptr;
+    uint64_t *d_sell_chunk_k = nullptr;
+    int grid_sell_k = 0;
+    uint64_t n_hask_tiles = 0;
     uint64_t *d_sell_chunk_m[2] = {nullptr, nullptr}; // tile ranges of the fused-chain kernels (2 and 4 chains: fewer resident waves)
     int grid_sell_m[2] = {0, 0};
     bool use_sell = false;

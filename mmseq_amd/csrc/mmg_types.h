@@ -48,6 +48,8 @@ struct TileDesc {
     uint32_t call;  // smallest transcript id in the tile
     uint32_t nnz4;  // hits when every row is padded to a multiple of 4
     uint32_t maxlen;// longest row of the tile
+    uint32_t kmax;  // largest multiplicity in the tile (1 without a k array)
+    uint32_t knot1; // rows whose multiplicity is not 1
 };
 
 // tile flags of the sliced-ELL sample and EM kernels
@@ -55,7 +57,10 @@ struct TileDesc {
 // then 64 far-count bytes and nf groups of 64 lanes x u32 transcript ids (the lane's hits outside the window, in stored order); the
 // sample kernel walks the window part on the register path and adds the far list behind it.  Neither: the rows are walked from the
 // CSR (rows of more than 255 hits, rows kept in an order that is not "window hits first").
-enum : uint32_t { SELL_FAST = 1, SELL_FAR = 2, SELL_EMPTY = 4 };
+// HASK: some row of the tile has a multiplicity other than 1.  A problem with multiplicities is sampled by TWO launches, each over its own
+// list of tile descriptors: k_sample_sell<.., false> walks the tiles without the flag exactly as it walks a problem without a k array
+// (identical reads are a minority, and the canonical order groups them: key field kclass), k_sample_sell<.., true> the flagged ones.
+enum : uint32_t { SELL_FAST = 1, SELL_FAR = 2, SELL_EMPTY = 4, SELL_HASK = 8 };
 
 struct SellTile {
     uint64_t off16;   // 16-byte-unit offset of the tile's block in the stream

@@ -80,7 +80,7 @@ static void problem_free(mmg_problem *p)
     if (!p) return;
     (void)hipSetDevice(p->device);
     for (void *x : {(void *)p->d_row_ptr, (void *)p->d_col, (void *)p->d_k, (void *)p->d_l, (void *)p->d_int_of_ext, (void *)p->d_ext_of_int,
-                    (void *)p->d_sell, (void *)p->d_sell_tiles, (void *)p->d_sell_chunk, (void *)p->d_sell_chunk_m[0], (void *)p->d_sell_chunk_m[1],
+                    (void *)p->d_sell, (void *)p->d_sell_tiles, (void *)p->d_sell_chunk, (void *)p->d_sell_chunk_k, (void *)p->d_sell_tiles_1, (void *)p->d_sell_tiles_k, (void *)p->d_sell_chunk_m[0], (void *)p->d_sell_chunk_m[1],
                     (void *)p->d_tiles, (void *)p->d_chunk_tile,
                     (void *)p->d_colcnt})
         if (x) (void)hipFree(x);
@@ -133,7 +133,7 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
     SELL_TRY(hipMalloc((void **)&d_tile_row, tile_row.size() * sizeof(uint64_t)));
     SELL_TRY(hipMemcpy(d_tile_row, tile_row.data(), tile_row.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
     SELL_TRY(hipMalloc((void **)&d_td, nt * sizeof(TileDesc)));
-    launch_tile_desc(p->idx64, p->d_row_ptr, p->d_col, d_tile_row, nt, d_td, 0);
+    launch_tile_desc(p->idx64, p->d_row_ptr, p->d_col, p->d_k, d_tile_row, nt, d_td, 0);
     SELL_TRY(hipGetLastError());
     std::vector<TileDesc> td(nt);
     SELL_TRY(hipMemcpy(td.data(), d_td, nt * sizeof(TileDesc), hipMemcpyDeviceToHost));
@@ -170,16 +170,32 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
     auto is_far = [&](uint64_t t) { return far_nf[t] <= 255u; };
     cleanup();
 #undef SELL_TRY
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k1_sell_kernel(p->idx64, p->d_k != nullptr), 64, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 16; }
-    if (per_cu > 32) per_cu = 32;
-    if (opt(MMG_OPT_SELL_WAVES_PER_CU) >= 1 && opt(MMG_OPT_SELL_WAVES_PER_CU) < per_cu) per_cu = opt(MMG_OPT_SELL_WAVES_PER_CU);
-    const uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>(nt, (uint64_t)p->cu_count * per_cu));
+    auto resident_grid = [&](bool has_k) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k1_sell_kernel(p->idx64, has_k), 64, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 16; }
+        if (per_cu > 32) per_cu = 32;
+        if (opt(MMG_OPT_SELL_WAVES_PER_CU) >= 1 && opt(MMG_OPT_SELL_WAVES_PER_CU) < per_cu) per_cu = opt(MMG_OPT_SELL_WAVES_PER_CU);
+        return std::max<uint64_t>(1, std::min<uint64_t>(nt, (uint64_t)p->cu_count * per_cu));
+    };
+    const uint64_t grid = resident_grid(false);
+    // h_sell_cum: what a tile costs whatever its multiplicities (the EM kernel's ranges, the choice of the kernel); cum1 / cumk: the
+    // ranges of the two sample launches of a problem with multiplicities -- tiles whose rows all have k = 1, and the others, where a
+    // row draws k times (k <= K_SMALL) or runs a binomial per hit.  Identical reads pile up on few hit sets of few abundant
+    // transcripts: without their cost in the ranges one workgroup ends up with most of them (20 x the kernel time at config 3).
+    auto has_k_rows = [&](uint64_t t) { return p->d_k != nullptr && td[t].knot1 > 0; };
     p->h_sell_cum.assign(nt + 1, 0);
-    for (uint64_t t = 0; t < nt; ++t)
-        p->h_sell_cum[t + 1] = p->h_sell_cum[t] + (td[t].nnz == 0 ? 0 : qualifies(td[t]) ? SELL_FAST_TILE_COST : is_far(t) ? SELL_FAR_TILE_COST + SELL_FAR_ENTRY_COST * far_nf[t] : SELL_SLOW_TILE_COST);
+    std::vector<uint64_t> cum1(nt + 1, 0), cumk(nt + 1, 0);
+    uint64_t n_hask = 0;
+    for (uint64_t t = 0; t < nt; ++t) {
+        const uint64_t c = td[t].nnz == 0 ? 0 : qualifies(td[t]) ? SELL_FAST_TILE_COST : is_far(t) ? SELL_FAR_TILE_COST + SELL_FAR_ENTRY_COST * far_nf[t] : SELL_SLOW_TILE_COST;
+        p->h_sell_cum[t + 1] = p->h_sell_cum[t] + c;
+        const bool hk = has_k_rows(t);
+        n_hask += hk;
+        cum1[t + 1] = cum1[t] + (hk ? 0 : c);
+        cumk[t + 1] = cumk[t] + (!hk ? 0 : 2 * c + (td[t].kmax <= K_SMALL ? (uint64_t)td[t].kmax : 3 * (uint64_t)td[t].maxlen));
+    }
     std::vector<uint64_t> chunk;
-    weighted_chunks(p->h_sell_cum, grid, chunk);
+    weighted_chunks(n_hask ? p->h_sell_cum : cum1, grid, chunk); // (with SELL_HASK tiles: only the windows below follow these ranges)
     std::vector<SellTile> st(nt);
     uint64_t n_fast = 0, n_far = 0, pos = 0, slots = 0;
     for (uint64_t c = 0; c < grid; ++c) {
@@ -191,11 +207,12 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
             SellTile &q = st[t];
             q.off16 = 0; q.r0 = d.r0;
             if (d.nnz == 0) { q.meta = sell_meta(d.nrows, 0, SELL_EMPTY); q.wbase = cur; continue; }
+            const uint32_t hask = has_k_rows(t) ? SELL_HASK : 0u;
             if (is_far(t)) { // its own window: the one its bytes are relative to
                 cur = far_wbase[t]; have = true;
                 q.wbase = cur;
                 const uint32_t ng = (far_nn[t] + 3) / 4;
-                q.meta = sell_meta(d.nrows, ng, SELL_FAR, far_nf[t]);
+                q.meta = sell_meta(d.nrows, ng, SELL_FAR | hask, far_nf[t]);
                 q.off16 = pos;
                 pos += 4 + 16 * (uint64_t)ng + 4 + 16 * (uint64_t)far_nf[t];
                 slots += 256 * (uint64_t)ng + 64 * (uint64_t)far_nf[t];
@@ -209,13 +226,13 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
             const bool fast = d.maxlen <= 255 && d.nrows <= 64 && (uint64_t)d.cmax < (uint64_t)cur + WIN;
             if (fast) {
                 const uint32_t ng = (d.maxlen + 3) / 4;
-                q.meta = sell_meta(d.nrows, ng, SELL_FAST);
+                q.meta = sell_meta(d.nrows, ng, SELL_FAST | hask);
                 q.off16 = pos;
                 pos += 4 + 16 * (uint64_t)ng;
                 slots += 256 * (uint64_t)ng;
                 ++n_fast;
             } else {
-                q.meta = sell_meta(d.nrows, 0, 0);
+                q.meta = sell_meta(d.nrows, 0, hask);
             }
         }
     }
@@ -233,6 +250,32 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
     HIP_TRY(hipMemset(p->d_sell, 0, alloc));
     HIP_TRY(hipMalloc((void **)&p->d_sell_tiles, nt * sizeof(SellTile)));
     HIP_TRY(hipMemcpy(p->d_sell_tiles, st.data(), nt * sizeof(SellTile), hipMemcpyHostToDevice));
+    p->grid_sell = (int)grid;
+    p->n_hask_tiles = n_hask;
+    if (n_hask) { // two launches, each over its own descriptor list and ranges
+        std::vector<SellTile> s1, sk;
+        std::vector<uint64_t> c1(1, 0), ck(1, 0);
+        s1.reserve(nt - n_hask); sk.reserve(n_hask);
+        for (uint64_t t = 0; t < nt; ++t) {
+            if (st[t].flags() & SELL_HASK) { sk.push_back(st[t]); ck.push_back(ck.back() + (cumk[t + 1] - cumk[t])); }
+            else { s1.push_back(st[t]); c1.push_back(c1.back() + (cum1[t + 1] - cum1[t])); }
+        }
+        const uint64_t g1 = std::max<uint64_t>(1, std::min<uint64_t>(s1.size(), grid)), gk = std::max<uint64_t>(1, std::min<uint64_t>(sk.size(), resident_grid(true)));
+        if (s1.empty()) { SellTile e; e.off16 = 0; e.r0 = 0; e.wbase = 0; e.meta = sell_meta(0, 0, SELL_EMPTY); s1.push_back(e); c1.push_back(0); }
+        std::vector<uint64_t> r1, rk;
+        weighted_chunks(c1, g1, r1);
+        weighted_chunks(ck, gk, rk);
+        chunk = r1;
+        HIP_TRY(hipMalloc((void **)&p->d_sell_tiles_1, s1.size() * sizeof(SellTile)));
+        HIP_TRY(hipMemcpy(p->d_sell_tiles_1, s1.data(), s1.size() * sizeof(SellTile), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void **)&p->d_sell_tiles_k, sk.size() * sizeof(SellTile)));
+        HIP_TRY(hipMemcpy(p->d_sell_tiles_k, sk.data(), sk.size() * sizeof(SellTile), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void **)&p->d_sell_chunk_k, rk.size() * sizeof(uint64_t)));
+        HIP_TRY(hipMemcpy(p->d_sell_chunk_k, rk.data(), rk.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        p->grid_sell_k = (int)gk;
+        p->grid_sell = (int)g1;
+        p->device_bytes += (s1.size() + sk.size()) * sizeof(SellTile);
+    }
     HIP_TRY(hipMalloc((void **)&p->d_sell_chunk, chunk.size() * sizeof(uint64_t)));
     HIP_TRY(hipMemcpy(p->d_sell_chunk, chunk.data(), chunk.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
     if (!p->d_k) { // fused-chain kernels: their own (fewer, longer) tile ranges over the same tiles
@@ -252,7 +295,6 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
     launch_encode_sell(p->idx64, p->d_row_ptr, p->d_col, p->d_sell_tiles, nt, p->d_sell, 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
-    p->grid_sell = (int)grid;
     p->device_bytes += p->sell_bytes + nt * sizeof(SellTile);
     return MMG_OK;
 }
@@ -286,7 +328,7 @@ static int problem_build_csr_tiles(mmg_problem *p, const uint64_t *d_rp64)
     hipError_t e = hipMemcpy(d_tile_row, tile_row.data(), tile_row.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_tiles, p->n_tiles * sizeof(TileDesc));
     if (e == hipSuccess) {
-        launch_tile_desc(p->idx64, p->d_row_ptr, p->d_col, d_tile_row, p->n_tiles, p->d_tiles, 0);
+        launch_tile_desc(p->idx64, p->d_row_ptr, p->d_col, p->d_k, d_tile_row, p->n_tiles, p->d_tiles, 0);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipDeviceSynchronize();
     }

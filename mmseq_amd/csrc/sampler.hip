@@ -121,10 +121,13 @@ extern "C" int mmg_sampler_sample(mmg_sampler *s)
     if (p->m > 0) {
         for (int c = 0; c < s->cfg.n_chains;) {
             // chains are advanced in fused pairs where the fused kernel exists (sliced-ELL stream, no multiplicities).  Measured at
-            // config 3 with 8 chains: 3190 chain-iterations/s one chain per launch, 3640 in pairs (111 VGPRs, 4 waves per SIMD),
-            // 2820 in fours (175 VGPRs, 2 waves per SIMD): fours exist for tests and experiments only (MMG_OPT_FUSE_CHAINS).
+            // config 3 with 8 chains: 3470 chain-iterations/s one chain per launch, 3780 in pairs (111 VGPRs, 4 waves per SIMD),
+            // 2970 in fours (175 VGPRs, 2 waves per SIMD): fours exist for tests and experiments only (MMG_OPT_FUSE_CHAINS).
+            // The fused kernels walk every tile that is not a fast tile from the CSR (24 x a fast tile): left to itself the library
+            // pairs chains only when fewer than 1 in 200 tiles are like that -- k_sample_sell has the far-list path.
             int fuse = 1;
-            if (p->use_sell && !p->d_k && opt(MMG_OPT_FUSE_CHAINS) != 1) {
+            const bool pairs_pay = (p->n_sell_tiles - p->n_fast_tiles) * 200 <= p->n_sell_tiles;
+            if (p->use_sell && !p->d_k && opt(MMG_OPT_FUSE_CHAINS) != 1 && (pairs_pay || opt(MMG_OPT_FUSE_CHAINS) > 1)) {
                 const int cap = opt(MMG_OPT_FUSE_CHAINS) > 0 ? opt(MMG_OPT_FUSE_CHAINS) : 2;
                 if (cap >= 4 && c + 4 <= s->cfg.n_chains && p->grid_sell_m[1] > 0) fuse = 4;
                 else if (cap >= 2 && c + 2 <= s->cfg.n_chains && p->grid_sell_m[0] > 0) fuse = 2;
@@ -144,11 +147,17 @@ extern "C" int mmg_sampler_sample(mmg_sampler *s)
                 void *kargs[] = {(void *)&rp, (void *)&ci, (void *)&ts, (void *)&cs, (void *)&mu, (void *)&ss, (void *)&cnt, (void *)&a};
                 HIP_TRY(hipLaunchKernel(k1_sell_multi_kernel(p->idx64, fuse), dim3(p->grid_sell_m[fuse == 4 ? 1 : 0]), dim3(64), kargs, 0, s->cur));
             } else if (p->use_sell) {
-                const SellTile *ts = p->d_sell_tiles;
+                const SellTile *ts = p->grid_sell_k > 0 ? p->d_sell_tiles_1 : p->d_sell_tiles;
                 const uint64_t *cs = p->d_sell_chunk;
                 const uint8_t *ss = p->d_sell;
                 void *kargs[] = {(void *)&rp, (void *)&ci, (void *)&kk, (void *)&ts, (void *)&cs, (void *)&mu, (void *)&ss, (void *)&cnt, (void *)&a};
-                HIP_TRY(hipLaunchKernel(k1_sell_kernel(p->idx64, p->d_k != nullptr), dim3(p->grid_sell), dim3(64), kargs, 0, s->cur));
+                // every tile whose rows all have k = 1 (all of them without a k array) ...
+                HIP_TRY(hipLaunchKernel(k1_sell_kernel(p->idx64, false), dim3(p->grid_sell), dim3(64), kargs, 0, s->cur));
+                if (p->grid_sell_k > 0) { // ... then the tiles that hold collapsed identical reads, in ranges balanced by their cost
+                    ts = p->d_sell_tiles_k;
+                    cs = p->d_sell_chunk_k;
+                    HIP_TRY(hipLaunchKernel(k1_sell_kernel(p->idx64, true), dim3(p->grid_sell_k), dim3(64), kargs, 0, s->cur));
+                }
             } else {
                 const TileDesc *td = p->d_tiles;
                 const uint64_t *ct = p->d_chunk_tile;

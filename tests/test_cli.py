@@ -334,3 +334,36 @@ def test_chains_flag_pools_moments_and_keeps_chain0_traces(tmp_path, gpu):
     assert n_obs > 20
     r = run(["-gpus", "2", "-chains", "3", str(p), str(tmp_path / "x")])
     assert r.returncode == 1 and b"chains a multiple of gpus" in r.stderr
+
+
+@pytest.mark.gpu
+def test_synth_hits_writes_the_generator_rows_and_the_cli_runs_on_them(tmp_path, gpu, orc):
+    """synth_hits (the benchmark workload as a hits FILE, for end-to-end runs at sizes no alignment here provides): both schemas hold
+    the oracle generator's rows in generator order (the writer's transcript-index fast path), 3 % of them with a far hit, and the CLI's
+    outputs on that file equal the Python pipeline's."""
+    tool = os.path.join(ROOT, "mmseq_amd", "csrc", "synth_hits")
+    R, T = 3000, 500
+    p, aux = orc.synth_problem(R=R, T=T, avg_hits=5, seed=1234, sort=False, far_fraction=0.03)
+    rp = p.row_ptr.astype(np.int64)
+    parsed = []
+    for flag, name in ((["-t"], "t.hits"), ([], "b.hits")):
+        path = str(tmp_path / name)
+        r = subprocess.run([tool] + flag + [str(R), str(T), "5", path, "0.03"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert r.returncode == 0, r.stderr.decode()
+        h = H.read_hits(open(path, "rb").read())
+        assert h.names == ["T%07d" % i for i in range(T)] and len(h.reads) == R
+        assert [rid for rid, _ in h.reads[:3]] == ["r0000000000", "r0000000001", "r0000000002"]
+        for i in (0, 1, 17, R - 1):
+            assert h.reads[i][1] == ["T%07d" % c for c in p.col_idx[rp[i]:rp[i + 1]]]
+        assert sum(len(t) for _, t in h.reads) == p.col_idx.size
+        assert all(abs(h.efflen[n] - float(aux["efflen"][j])) <= 1e-5 * float(aux["efflen"][j]) for j, n in enumerate(h.names))
+        assert sorted(t for ts in h.genes.values() for t in ts) == h.names and max(len(ts) for ts in h.genes.values()) <= 7
+        parsed.append(h)
+    assert parsed[0].reads == parsed[1].reads and parsed[0].genes == parsed[1].genes
+    out = str(tmp_path / "out")
+    r = run(["-gibbs_iter", "1024", str(tmp_path / "b.hits"), out], timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    e = H.expected_run(parsed[1], gibbs_iter=1024)
+    ids, rows = _trace_file(out + ".trace_gibbs.gz")
+    assert ids == e["ingest"]["index_sid"]
+    assert rows == [[H.fmt6(v) for v in e["trace"][:, s]] for s in range(1024)]
