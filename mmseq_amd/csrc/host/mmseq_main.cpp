@@ -11,6 +11,7 @@
 // are written after the loop from the device-resident trace, VLAs are heap vectors (:1308-1348).
 // There is no CPU sampler here: without a HIP device the program stops with an error.
 #include <omp.h>
+#include <atomic>
 #include <thread>
 #include <mutex>
 #include <condition_variable>
@@ -434,11 +435,6 @@ int main(int argc, char **argv)
         // map<vector<int>,int> and regrows M)
         vector<uint32_t> table(1u << 16, 0xffffffffu);
         vector<uint64_t> row_hash;
-        auto hash_of = [](const vector<uint32_t> &c) {
-            uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)c.size();
-            for (uint32_t v : c) { h ^= v; h *= 0xff51afd7ed558ccdull; h ^= h >> 32; }
-            return h;
-        };
         auto grow = [&]() {
             vector<uint32_t> bigger(table.size() * 2, 0xffffffffu);
             const size_t mask = bigger.size() - 1;
@@ -449,19 +445,24 @@ int main(int argc, char **argv)
             }
             table.swap(bigger);
         };
-        // The reader (inflate + record decode, strictly sequential: src/hitsio.hpp:77-79) runs in its own thread and hands
-        // over blocks of decoded reads; this thread collapses them.  Two blocks in flight.
-        struct Block { vector<uint32_t> len, idx; };
-        Block blocks[2];
-        int ready[2] = {0, 0}; // 0: free for the reader, 1: filled, 2: filled and last
+        // Three stages, each its own thread, over a ring of blocks of reads: (1) the reader -- inflate + record decode, strictly
+        // sequential (src/hitsio.hpp:77-79); (2) first-seen transcript numbering (:399-408), the read's hit set sorted and freed of
+        // repeats, its hash; (3) this thread: the hit-set table.  The inflate bounds the pipeline.
+        struct Block { vector<uint32_t> len, idx; vector<uint64_t> hash; bool last = false; };
+        constexpr int NB = 4;
+        Block blocks[NB];
+        int state[NB] = {0, 0, 0, 0}; // 0: free for the reader, 1: decoded, 2: prepared for the table
         mutex mtx;
         condition_variable cv;
+        atomic<uint32_t> n_seen{0}; // transcripts numbered so far (progress line only)
+        auto wait_for = [&](int b, int want) { unique_lock<mutex> lk(mtx); cv.wait(lk, [&] { return state[b] == want; }); };
+        auto set_state = [&](int b, int v) { { lock_guard<mutex> lk(mtx); state[b] = v; } cv.notify_all(); };
         thread producer([&]() {
             string rid;
             uint32_t h = 0;
             bool more = true;
-            for (int b = 0; more; b ^= 1) {
-                { unique_lock<mutex> lk(mtx); cv.wait(lk, [&] { return ready[b] == 0; }); }
+            for (int b = 0; more; b = (b + 1) % NB) {
+                wait_for(b, 0);
                 Block &B = blocks[b];
                 B.len.clear(); B.idx.clear();
                 while (B.len.size() < 65536 && (more = hitsfileReader.readReadMapRecordReadID(rid))) {
@@ -469,57 +470,84 @@ int main(int argc, char **argv)
                     while (hitsfileReader.readReadMapRecordTranscriptIndex(h)) { B.idx.push_back(h); ++c; }
                     B.len.push_back(c);
                 }
-                { lock_guard<mutex> lk(mtx); ready[b] = more ? 1 : 2; }
-                cv.notify_all();
+                B.last = !more;
+                set_state(b, 1);
             }
         });
-        vector<uint32_t> comb;
+        thread preparer([&]() {
+            bool last = false;
+            for (int b = 0; !last; b = (b + 1) % NB) {
+                wait_for(b, 1);
+                Block &B = blocks[b];
+                last = B.last;
+                B.hash.resize(B.len.size());
+                size_t at = 0, out = 0;
+                for (size_t r = 0; r < B.len.size(); ++r) {
+                    uint32_t *c = B.idx.data() + out; // the set is written over the block's own indices (never ahead of the read position)
+                    const uint32_t nin = B.len[r];
+                    for (uint32_t q = 0; q < nin; ++q) {
+                        const uint32_t hidx = B.idx[at++];
+                        if (hidx >= nHeader) {
+                            cerr << "Error: a read maps to a transcript that has no @TranscriptMetaData entry (no length).\n";
+                            exit(1);
+                        }
+                        if (hdr2obs[hidx] < 0) {
+                            hdr2obs[hidx] = (int32_t)obs2hdr.size(); obs2hdr.push_back(hidx); doublehits.push_back(0);
+                            n_seen.store((uint32_t)obs2hdr.size(), memory_order_relaxed);
+                        }
+                        c[q] = (uint32_t)hdr2obs[hidx];
+                    }
+                    sort(c, c + nin);
+                    uint32_t nu = 0;
+                    for (uint32_t q = 0; q < nin; ++q) {
+                        if (nu && c[nu - 1] == c[q]) doublehits[c[q]]++; // a transcript listed twice for one read (:421-424)
+                        else c[nu++] = c[q];
+                    }
+                    uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)nu;
+                    for (uint32_t q = 0; q < nu; ++q) { h ^= c[q]; h *= 0xff51afd7ed558ccdull; h ^= h >> 32; }
+                    B.hash[r] = h;
+                    B.len[r] = nu;
+                    out += nu;
+                }
+                set_state(b, 2);
+            }
+        });
         bool last = false;
-        for (int b = 0; !last; b ^= 1) {
-            { unique_lock<mutex> lk(mtx); cv.wait(lk, [&] { return ready[b] != 0; }); last = ready[b] == 2; }
+        for (int b = 0; !last; b = (b + 1) % NB) {
+            wait_for(b, 2);
             const Block &B = blocks[b];
+            last = B.last;
             size_t at = 0;
             for (size_t r = 0; r < B.len.size(); ++r) {
-            numbermappedreads++;
-            comb.clear();
-            for (uint32_t q = 0; q < B.len[r]; ++q) {
-                const uint32_t hidx = B.idx[at++];
-                if (hidx >= nHeader) {
-                    cerr << "Error: a read maps to a transcript that has no @TranscriptMetaData entry (no length).\n";
-                    exit(1);
+                numbermappedreads++;
+                const uint32_t *comb = B.idx.data() + at;
+                const uint32_t nc = B.len[r];
+                at += nc;
+                const uint64_t h = B.hash[r];
+                const size_t mask = table.size() - 1;
+                size_t s = (size_t)h & mask;
+                uint32_t row = 0xffffffffu;
+                for (;; s = (s + 1) & mask) {
+                    const uint32_t rr = table[s];
+                    if (rr == 0xffffffffu) break;
+                    if (row_hash[rr] == h && row_ptr[rr + 1] - row_ptr[rr] == nc && equal(comb, comb + nc, col_idx.begin() + (ptrdiff_t)row_ptr[rr])) { row = rr; break; }
                 }
-                if (hdr2obs[hidx] < 0) { hdr2obs[hidx] = (int32_t)obs2hdr.size(); obs2hdr.push_back(hidx); doublehits.push_back(0); }
-                const uint32_t o = (uint32_t)hdr2obs[hidx];
-                if (find(comb.begin(), comb.end(), o) == comb.end()) comb.push_back(o);
-                else doublehits[o]++;
+                if (row == 0xffffffffu) {
+                    row = (uint32_t)k.size();
+                    if ((row & 0xffff) == 0)
+                        cout << "Found " << n_seen.load(memory_order_relaxed) << " transcripts in " << row << " transcript combinations.\r" << flush;
+                    table[s] = row;
+                    row_hash.push_back(h);
+                    k.push_back(0);
+                    col_idx.insert(col_idx.end(), comb, comb + nc);
+                    row_ptr.push_back(col_idx.size());
+                    if ((uint64_t)k.size() * 2 > table.size()) grow();
+                }
+                k[row]++;
             }
-            sort(comb.begin(), comb.end());
-            const uint64_t h = hash_of(comb);
-            const size_t mask = table.size() - 1;
-            size_t s = (size_t)h & mask;
-            uint32_t row = 0xffffffffu;
-            for (;; s = (s + 1) & mask) {
-                const uint32_t r = table[s];
-                if (r == 0xffffffffu) break;
-                if (row_hash[r] == h && row_ptr[r + 1] - row_ptr[r] == comb.size() &&
-                    equal(comb.begin(), comb.end(), col_idx.begin() + (ptrdiff_t)row_ptr[r])) { row = r; break; }
-            }
-            if (row == 0xffffffffu) {
-                row = (uint32_t)k.size();
-                if ((row & 0xfff) == 0)
-                    cout << "Found " << obs2hdr.size() << " transcripts in " << row << " transcript combinations.\r" << flush;
-                table[s] = row;
-                row_hash.push_back(h);
-                k.push_back(0);
-                col_idx.insert(col_idx.end(), comb.begin(), comb.end());
-                row_ptr.push_back(col_idx.size());
-                if ((uint64_t)k.size() * 2 > table.size()) grow();
-            }
-            k[row]++;
-            }
-            { lock_guard<mutex> lk(mtx); ready[b] = 0; }
-            cv.notify_all();
+            set_state(b, 0);
         }
+        preparer.join();
         producer.join();
         cout << "Found " << obs2hdr.size() << " transcripts in " << k.size() << " transcript combinations." << endl;
     }
@@ -544,15 +572,27 @@ int main(int argc, char **argv)
     }
 
     // ---- start values and the shared-count histogram (src/mmseq.cpp:610-638); host, deterministic
+    //      Every thread owns a range of transcripts and walks all rows: a transcript's shares are added in row order whatever the
+    //      thread count (the reference's order), and the walk is a stream of the hit list.
     vector<vector<int>> counts_shared(n, vector<int>(100, 0));
     vector<double> mu(n, 0.0);
-    for (uint64_t i = 0; i < m; ++i) {
-        const uint64_t b = row_ptr[i], e = row_ptr[i + 1];
-        const int L = (int)(e - b);
-        for (uint64_t j = b; j < e; ++j) {
-            mu[col_idx[j]] += (double)k[i] / L;
-            counts_shared[col_idx[j]][min(L, 100) - 1] += (int)k[i];
-        }
+#pragma omp parallel num_threads(min(16, omp_get_max_threads())) // every thread reads the whole hit list: more only adds traffic
+    {
+        const uint64_t nth = (uint64_t)omp_get_num_threads(), tid = (uint64_t)omp_get_thread_num();
+        const uint32_t lo = (uint32_t)((uint64_t)n * tid / nth), hi = (uint32_t)((uint64_t)n * (tid + 1) / nth);
+        if (lo < hi)
+            for (uint64_t i = 0; i < m; ++i) {
+                const uint64_t b = row_ptr[i], e = row_ptr[i + 1];
+                const int L = (int)(e - b);
+                const double share = (double)k[i] / L;
+                for (uint64_t j = b; j < e; ++j) {
+                    const uint32_t c = col_idx[j];
+                    if (c - lo < hi - lo) {
+                        mu[c] += share;
+                        counts_shared[c][min(L, 100) - 1] += (int)k[i];
+                    }
+                }
+            }
     }
     for (uint32_t t = 0; t < n; ++t) mu[t] /= l[t];
 
