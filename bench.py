@@ -100,14 +100,30 @@ def cpu_baseline(args, total_reads):
 
 
 def side_measurement(name, rows, transcripts, avg_hits, chains=1, uniform=False, sort=True, far_fraction=0.0, steps=48, warmup=8,
-                     seed=1234, device=0, note=""):
-    """One more workload, same protocol (inputs resident, HIP events on the launch stream), shorter: ms per sweep and which kernel ran."""
+                     seed=1234, device=0, note="", multiplicities=False):
+    """One more workload, same protocol (inputs resident, HIP events on the launch stream), shorter: ms per sweep and which kernel ran.
+    multiplicities: the rows get a k array with the distribution a collapsed 50 M-read file of this generator has (93.6 % k = 1,
+    5.3 % k = 2, ... 0.12 % k in 9..36: tools/collapse_probe.py) -- what every real hits file produces (src/mmseq.cpp:409-418)."""
+    import numpy as np
     import torch
     from mmseq_amd import Problem, Sampler
     from mmseq_amd import dist as mdist
     t0 = time.perf_counter()
     prob = Problem.synthetic(rows, transcripts, avg_hits, seed=seed, uniform=uniform, sort=sort, far_fraction=far_fraction,
                              mapped_reads=rows, device=device)
+    if multiplicities:
+        rp, ci = prob.download()
+        l = prob.l()
+        prob.close()
+        rng = np.random.default_rng(seed)
+        u = rng.random(rows)
+        k = np.ones(rows, np.uint32)
+        for thr, val in ((0.064, 2), (0.011, 3), (0.0035, 4), (0.002, 6)):
+            k[u < thr] = val
+        big = u < 0.0012
+        k[big] = rng.integers(9, 37, size=int(big.sum())).astype(np.uint32)
+        prob = Problem.from_csr(rp, ci, l, k=k, device=device)
+        del rp, ci, k, u
     build_s = time.perf_counter() - t0
     inf = prob.info
     mu0, _ = prob.start_values()
@@ -315,6 +331,8 @@ def main():
             R3, T3, H3 = 50_000_000, 200_000, 20.0
             for kw in (dict(name="config 2: 5M reads x 50k transcripts, avg 8 hits, 1 chain", rows=5_000_000, transcripts=50_000, avg_hits=8.0, steps=256, warmup=64),
                        dict(name="config 3: 50M x 200k, 8 chains in one GPU", rows=R3, transcripts=T3, avg_hits=H3, chains=8, steps=16, warmup=4),
+                       dict(name="50M x 200k with multiplicities (k > 1 on 6.4 % of the rows, up to 36): two launches per sweep", rows=R3, transcripts=T3, avg_hits=H3,
+                            multiplicities=True, steps=32),
                        dict(name="50M x 200k, 2 % of the rows with a hit anywhere in the transcriptome", rows=R3, transcripts=T3, avg_hits=H3, far_fraction=0.02, steps=32),
                        dict(name="50M x 200k, 20 % of the rows with a hit anywhere in the transcriptome", rows=R3, transcripts=T3, avg_hits=H3, far_fraction=0.2, steps=24),
                        dict(name="50M x 200k, hits uniform over all transcripts (SURVEY App. D worst case)", rows=R3, transcripts=T3, avg_hits=H3, uniform=True, steps=8, warmup=2),
