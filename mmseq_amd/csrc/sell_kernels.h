@@ -156,7 +156,7 @@ struct RowViewFarTile {
 };
 
 template <typename IdxT, bool HAS_K, int NGC, int REP = 1>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 1 : 7, HAS_K ? 8 : 7))) void k_sample_sell(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 7, HAS_K ? 5 : 7))) void k_sample_sell(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
                                                     const uint32_t *__restrict__ kmult, const SellTile *__restrict__ tiles, const uint64_t *__restrict__ chunk_tile,
                                                     const double *__restrict__ gmu, const uint8_t *__restrict__ stream, int32_t *gcnt,
                                                     SampleArgs a)
