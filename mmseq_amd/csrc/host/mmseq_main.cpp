@@ -112,11 +112,17 @@ static inline int fmt_g(char *tmp, double v)
 }
 
 // Trace files are megabytes of 6-digit numbers: deflate level 6 (the reference's Boost default) manages 12 MB/s per core on
-// them, level 1 73 MB/s for files 11 % larger.  Level 1 unless MMSEQ_GZIP_LEVEL says otherwise; any gzip reader reads both.
+// them, level 1 73 MB/s for files 11 % larger, Huffman coding alone (such text has next to no repeats for LZ77 to find) 110 MB/s for
+// another 3 %.  Huffman-only unless MMSEQ_GZIP_LEVEL asks for a level (default strategy then); any gzip reader reads all of them.
 static int gzip_level()
 {
     static const int level = [] { const char *e = getenv("MMSEQ_GZIP_LEVEL"); const int v = e ? atoi(e) : 1; return v >= 0 && v <= 9 ? v : 1; }();
     return level;
+}
+static int gzip_strategy()
+{
+    static const int strategy = getenv("MMSEQ_GZIP_LEVEL") ? Z_DEFAULT_STRATEGY : Z_HUFFMAN_ONLY;
+    return strategy;
 }
 
 struct GzText {
@@ -136,7 +142,7 @@ struct GzText {
     {
         z_stream zs;
         memset(&zs, 0, sizeof zs);
-        if (deflateInit2(&zs, gzip_level(), Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
+        if (deflateInit2(&zs, gzip_level(), Z_DEFLATED, -15, 8, gzip_strategy()) != Z_OK) {
             cerr << "Error initialising zlib.\n";
             exit(1);
         }
@@ -151,21 +157,13 @@ struct GzText {
         deflateEnd(&zs);
         return out;
     }
-    // chunks (<= 1 GiB each) are compressed in parallel and appended in order
-    void write_chunks(vector<string> &chunks)
+    // already deflated pieces (deflate_chunk of consecutive text), their crc32s and text sizes, appended in order
+    void append_compressed(const vector<string> &comp, const vector<uLong> &crcs, const vector<size_t> &sizes)
     {
-        flush_pending();
-        vector<string> comp(chunks.size());
-        vector<uLong> crcs(chunks.size());
-#pragma omp parallel for schedule(dynamic, 1)
-        for (int64_t i = 0; i < (int64_t)chunks.size(); ++i) {
-            comp[i] = deflate_chunk(chunks[i], false);
-            crcs[i] = crc32(crc32(0L, Z_NULL, 0), (const Bytef *)chunks[i].data(), (uInt)chunks[i].size());
-        }
-        for (size_t i = 0; i < chunks.size(); ++i) {
+        for (size_t i = 0; i < comp.size(); ++i) {
             fwrite(comp[i].data(), 1, comp[i].size(), f);
-            crc = crc32_combine(crc, crcs[i], (z_off_t)chunks[i].size());
-            total += chunks[i].size();
+            crc = crc32_combine(crc, crcs[i], (z_off_t)sizes[i]);
+            total += sizes[i];
         }
     }
     void flush_pending()
@@ -197,48 +195,66 @@ struct GzText {
     }
 };
 
-// rows of n numbers, each followed by a space, one line per sample (src/mmseq.cpp:912-916).
-// Chunks of whole lines (>= ~256 KiB of text) are formatted AND compressed in parallel.
-static void write_trace_lines(GzText &gz, int n_lines, size_t n_cols, const function<double(int, size_t)> &at,
-                              const function<bool(size_t)> &keep)
-{
-    const int lines_per_chunk = (int)max<size_t>(1, (size_t)262144 / max<size_t>(1, n_cols * 9));
-    const int batch = max(1, omp_get_max_threads() * 2);
-    for (int l0 = 0; l0 < n_lines; l0 += lines_per_chunk * batch) {
-        const int nchunks = min(batch, (n_lines - l0 + lines_per_chunk - 1) / lines_per_chunk);
-        vector<string> chunks(nchunks);
-#pragma omp parallel for schedule(dynamic, 1)
-        for (int c = 0; c < nchunks; ++c) {
-            string &s = chunks[c];
-            char tmp[40];
-            const int lb = l0 + c * lines_per_chunk, le = min(n_lines, lb + lines_per_chunk);
-            for (int i = lb; i < le; ++i) {
-                for (size_t col = 0; col < n_cols; ++col) {
-                    if (!keep(col)) continue;
-                    int len = fmt_g(tmp, at(i, col));
-                    tmp[len++] = ' ';
-                    s.append(tmp, len);
-                }
-                s += "\n";
-            }
-        }
-        gz.write_chunks(chunks);
-    }
-}
-
-// The same lines from rows fetched on demand (the trace lives on the device, sample-major: a line of the file is a row there).
+// Rows of n numbers, each followed by a space, one line per sample (src/mmseq.cpp:912-916), from rows fetched on demand (the trace
+// lives on the device, sample-major: a line of the file is a row there).  Three things overlap: the fetch of the next round of rows
+// (device gather + copy), the formatting and compression of this round -- in parallel over pieces of <= 32 k columns of a line
+// (~ 290 KB of text each, deflated independently and joined with sync flushes) -- and the write of the previous round's bytes.
 static void write_trace_rows(GzText &gz, int n_lines, size_t n_cols, const function<void(int, int, double *)> &fetch,
                              const function<bool(size_t)> &keep)
 {
-    if (n_cols == 0) { write_trace_lines(gz, n_lines, 0, [](int, size_t) { return 0.0; }, keep); return; }
-    const int lines_per_chunk = (int)max<size_t>(1, (size_t)262144 / max<size_t>(1, n_cols * 9));
-    const int per_round = lines_per_chunk * max(1, omp_get_max_threads() * 2) * 4;
-    vector<double> buf((size_t)min(per_round, n_lines) * n_cols);
-    for (int l0 = 0; l0 < n_lines; l0 += per_round) {
-        const int cnt = min(per_round, n_lines - l0);
-        fetch(l0, cnt, buf.data());
-        write_trace_lines(gz, cnt, n_cols, [&](int i, size_t col) { return buf[(size_t)i * n_cols + col]; }, keep);
+    vector<char> mask(n_cols);
+    size_t n_keep = 0;
+    for (size_t c = 0; c < n_cols; ++c) n_keep += (mask[c] = keep(c) ? 1 : 0);
+    if (n_keep == 0) { for (int i = 0; i < n_lines; ++i) gz.str("\n"); return; }
+    const size_t cols_per_piece = 32768, pieces_per_line = (n_cols + cols_per_piece - 1) / cols_per_piece;
+    const size_t want_pieces = (size_t)max(1, omp_get_max_threads()) * 2;
+    size_t lines_per_round = max<size_t>((size_t)(64u << 20) / (n_cols * 8), (want_pieces + pieces_per_line - 1) / pieces_per_line);
+    lines_per_round = max<size_t>(1, min<size_t>({lines_per_round, (size_t)(512u << 20) / (n_cols * 8) + 1, (size_t)n_lines}));
+    vector<double> buf[2];
+    buf[0].resize(lines_per_round * n_cols);
+    buf[1].resize(lines_per_round * n_cols);
+    gz.flush_pending();
+    fetch(0, (int)min<size_t>(lines_per_round, (size_t)n_lines), buf[0].data());
+    thread writer;
+    vector<string> comp_prev; // owned by the writer thread while it runs
+    for (int l0 = 0, r = 0; l0 < n_lines; l0 += (int)lines_per_round, ++r) {
+        const int cnt = (int)min<size_t>(lines_per_round, (size_t)(n_lines - l0));
+        const int next0 = l0 + cnt, next_cnt = (int)min<size_t>(lines_per_round, (size_t)max(0, n_lines - next0));
+        thread fetcher;
+        if (next_cnt > 0) fetcher = thread([&, next0, next_cnt, r]() { fetch(next0, next_cnt, buf[(r + 1) & 1].data()); });
+        const double *rows = buf[r & 1].data();
+        const int64_t n_pieces = (int64_t)cnt * (int64_t)pieces_per_line;
+        vector<string> comp((size_t)n_pieces);
+        vector<uLong> crcs((size_t)n_pieces);
+        vector<size_t> sizes((size_t)n_pieces);
+#pragma omp parallel
+        {
+            string text;
+            char tmp[48];
+#pragma omp for schedule(dynamic, 1)
+            for (int64_t pc = 0; pc < n_pieces; ++pc) {
+                const size_t line = (size_t)pc / pieces_per_line, piece = (size_t)pc % pieces_per_line;
+                const size_t c0 = piece * cols_per_piece, c1 = min(n_cols, c0 + cols_per_piece);
+                const double *row = rows + line * n_cols;
+                text.clear();
+                for (size_t c = c0; c < c1; ++c) {
+                    if (!mask[c]) continue;
+                    int len = fmt_g(tmp, row[c]);
+                    tmp[len++] = ' ';
+                    text.append(tmp, (size_t)len);
+                }
+                if (piece + 1 == pieces_per_line) text += "\n";
+                comp[(size_t)pc] = GzText::deflate_chunk(text, false);
+                crcs[(size_t)pc] = crc32(crc32(0L, Z_NULL, 0), (const Bytef *)text.data(), (uInt)text.size());
+                sizes[(size_t)pc] = text.size();
+            }
+        }
+        if (writer.joinable()) writer.join();
+        comp_prev.swap(comp);
+        writer = thread([&gz, &comp_prev, crcs, sizes]() { gz.append_compressed(comp_prev, crcs, sizes); });
+        if (fetcher.joinable()) fetcher.join();
     }
+    if (writer.joinable()) writer.join();
 }
 
 // Stage timings on stderr when MMSEQ_TIMING is set (not part of the reference's output)
@@ -255,9 +271,31 @@ struct StageTimer {
     void total() { if (on) fprintf(stderr, "[timing] %-28s %8.3f s\n", "total", omp_get_wtime() - t0); }
 };
 
+// CPUs this process may actually use: a container's CFS quota (cgroup v2 cpu.max, v1 cpu.cfs_quota_us) is invisible to OpenMP, which
+// then starts one thread per core of the host -- 256 threads throttled to 16 CPUs' worth of time on the GPU boxes here.
+static int cpu_quota()
+{
+    long long quota = -1, period = 100000;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64];
+        if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+        fclose(f);
+    } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+        fclose(g);
+        if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &period) != 1) period = 100000; fclose(h); }
+    }
+    if (quota <= 0 || period <= 0) return 0;
+    return (int)max<long long>(1, (quota + period - 1) / period);
+}
+
 int main(int argc, char **argv)
 {
     StageTimer stage;
+    if (!getenv("OMP_NUM_THREADS")) { // an explicit thread count is the user's (src/mmseq.cpp:323 prints it); otherwise respect the quota
+        const int q = cpu_quota();
+        if (q > 0 && q < omp_get_max_threads()) omp_set_num_threads(q);
+    }
     const int max_threads = omp_get_max_threads();
 
     // DEFAULT PARAMETER VALUES (src/mmseq.cpp:183-205)
