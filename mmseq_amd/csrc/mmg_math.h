@@ -35,8 +35,16 @@ MMG_HD U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1)
 {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // one v_mad_u64_u32 yields both halves of a product (32-bit multiplies are quarter-rate: the Gamma redraw is mostly these)
+        uint64_t p0, p1;
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p0) : "v"(c.x), "s"(0xD2511F53u) : "vcc");
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p1) : "v"(c.z), "s"(0xCD9E8D57u) : "vcc");
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+#else
         const uint32_t hi0 = mulhi32(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
         const uint32_t hi1 = mulhi32(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+#endif
         U4 n;
         n.x = hi1 ^ c.y ^ k0;
         n.y = lo1;
