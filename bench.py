@@ -68,6 +68,21 @@ def pmc_counters(rows, transcripts, avg_hits, chains, kernel):
     return None
 
 
+def cpu_quota():
+    """CPUs this process may use under a cgroup CFS quota (v2 cpu.max / v1 cpu.cfs_quota_us), or None."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else max(1, -(-int(q) // int(per)))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else max(1, -(-q // per))
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(args, total_reads):
     """Oracle ("port" of src/mmseq.cpp:851-918, reference-structured: per-thread MT19937, count slabs,
     conditional-binomial multinomial) timed on this host's cores on a bounded sample of the same workload."""
@@ -76,9 +91,11 @@ def cpu_baseline(args, total_reads):
     p, _ = B.synth_problem(R=Rs, T=args.transcripts, avg_hits=args.avg_hits, seed=args.seed, mapped_reads=total_reads, sort=False)
     mu0, _ = B.start_values(p)
     ncpu = os.cpu_count() or 1
+    quota = cpu_quota()
     # the reference's per-thread count slabs (src/mmseq.cpp:850-855, :896-899) stop scaling at high thread
-    # counts: probe a few and time the best one, so the baseline is the strongest this host offers
-    cands = sorted({t for t in (ncpu, ncpu // 2, 64, 32, 16, 8, 1) if 1 <= t <= ncpu}, reverse=True)
+    # counts: probe a few and time the best one, so the baseline is the strongest this host offers.  A container's CPU quota
+    # (16 CPUs' worth on the 256-core GPU boxes here) is a candidate of its own: more threads than that are throttled.
+    cands = sorted({t for t in (ncpu, ncpu // 2, 64, 32, 16, 8, 1, quota or 1, 2 * (quota or 1)) if 1 <= t <= ncpu}, reverse=True)
     best_t, best_rate = 1, 0.0
     for t in cands:
         r = B.gibbs_ref(p, mu0, seed=args.seed, n_iter=2, trace_len=2, threads=t, want_trace=False)
@@ -94,8 +111,8 @@ def cpu_baseline(args, total_reads):
     reads_it_s_1 = Rs * max(1, iters // 8) / r1["seconds"]
     return {"value": reads_it_s / args.rows, "unit": "iterations/s", "cores": threads, "kind": "port",
             "sample": "first %d generator rows of the same workload (T=%d, avg %.0f hits), %d iterations on %d host threads "
-                      "(best of %s on this %d-CPU host); reads*iter/s scaled to the %d-read problem"
-                      % (Rs, args.transcripts, args.avg_hits, iters, threads, cands, ncpu, args.rows),
+                      "(best of %s on this %d-CPU host, CPU quota %s); reads*iter/s scaled to the %d-read problem"
+                      % (Rs, args.transcripts, args.avg_hits, iters, threads, cands, ncpu, quota, args.rows),
             "reads_iters_per_sec": reads_it_s, "single_thread_iterations_per_sec": reads_it_s_1 / args.rows}
 
 
