@@ -4,11 +4,15 @@
 
 #include <zlib.h>
 
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include <limits>
+#include <mutex>
 #include <sstream>
+#include <thread>
+#include <vector>
 
 namespace hitsio_detail {
 
@@ -31,6 +35,11 @@ public:
     }
     ~ByteSource()
     {
+        if (worker.joinable()) {
+            { std::lock_guard<std::mutex> lk(mtx); stop = true; }
+            cv.notify_all();
+            worker.join();
+        }
         if (zinit) inflateEnd(&zs);
         if (fp) std::fclose(fp);
     }
@@ -84,38 +93,81 @@ public:
     }
 
 private:
+    // A compressed file is ONE zlib stream (src/hitsio.cpp:127): it inflates in a thread of its own, a ring of slabs ahead of the
+    // record decoding, which was a third of the reader's time at 50 M reads.
+    static constexpr int NSLAB = 4;
+    static constexpr size_t SLAB = 1u << 20;
+    struct Slab { std::vector<char> data; size_t len = 0; int state = 0; }; // 0 free, 1 filled, 2 being read
     bool fill()
     {
         pos = len = 0;
         if (!compressed) {
-            len = std::fread(buf, 1, sizeof buf, fp);
+            len = std::fread(raw, 1, sizeof raw, fp);
+            buf = raw;
             return len > 0;
         }
-        if (zdone) return false;
-        zs.next_out = (Bytef *)buf;
-        zs.avail_out = sizeof buf;
-        while (zs.avail_out == sizeof buf) {
-            if (zs.avail_in == 0) {
-                zs.avail_in = (uInt)std::fread(inbuf, 1, sizeof inbuf, fp);
-                zs.next_in = (Bytef *)inbuf;
-                if (zs.avail_in == 0) { zdone = true; break; } // truncated stream: stop like a short read
-            }
-            int rc = inflate(&zs, Z_NO_FLUSH);
-            if (rc == Z_STREAM_END) { zdone = true; break; }
-            if (rc != Z_OK && rc != Z_BUF_ERROR) {
-                std::cerr << "Error decompressing hits file (zlib error " << rc << ").\n";
-                std::exit(1);
-            }
+        if (!worker.joinable() && !zdone) {
+            for (auto &sl : ring) sl.data.resize(SLAB);
+            worker = std::thread([this] { inflate_ahead(); });
         }
-        len = sizeof buf - zs.avail_out;
+        std::unique_lock<std::mutex> lk(mtx);
+        if (reading >= 0) { ring[reading].state = 0; reading = -1; cv.notify_all(); }
+        cv.wait(lk, [&] { return ring[next_read].state == 1 || zdone; });
+        if (ring[next_read].state != 1) return false;
+        reading = next_read;
+        next_read = (next_read + 1) % NSLAB;
+        ring[reading].state = 2;
+        buf = ring[reading].data.data();
+        len = ring[reading].len;
         return len > 0;
     }
+    void inflate_ahead()
+    {
+        for (int w = 0;; w = (w + 1) % NSLAB) {
+            {
+                std::unique_lock<std::mutex> lk(mtx);
+                cv.wait(lk, [&] { return ring[w].state == 0 || stop; });
+                if (stop) return;
+            }
+            Slab &sl = ring[w];
+            zs.next_out = (Bytef *)sl.data.data();
+            zs.avail_out = (uInt)SLAB;
+            bool end = false;
+            while (zs.avail_out == SLAB) {
+                if (zs.avail_in == 0) {
+                    zs.avail_in = (uInt)std::fread(inbuf, 1, sizeof inbuf, fp);
+                    zs.next_in = (Bytef *)inbuf;
+                    if (zs.avail_in == 0) { end = true; break; } // truncated stream: stop like a short read
+                }
+                int rc = inflate(&zs, Z_NO_FLUSH);
+                if (rc == Z_STREAM_END) { end = true; break; }
+                if (rc != Z_OK && rc != Z_BUF_ERROR) {
+                    std::cerr << "Error decompressing hits file (zlib error " << rc << ").\n";
+                    std::exit(1);
+                }
+            }
+            sl.len = SLAB - zs.avail_out;
+            {
+                std::lock_guard<std::mutex> lk(mtx);
+                if (sl.len) sl.state = 1;
+                if (end) zdone = true;
+            }
+            cv.notify_all();
+            if (end) return;
+        }
+    }
     FILE *fp = nullptr;
-    bool compressed = false, zinit = false, zdone = false;
+    bool compressed = false, zinit = false, zdone = false, stop = false;
     z_stream zs;
-    char buf[1 << 16];
+    char raw[1 << 16];
     char inbuf[1 << 16];
+    const char *buf = raw;
     size_t pos = 0, len = 0;
+    Slab ring[NSLAB];
+    int next_read = 0, reading = -1;
+    std::mutex mtx;
+    std::condition_variable cv;
+    std::thread worker;
 };
 
 // ---------------------------------------------------------------- output (plain or zlib level 1)

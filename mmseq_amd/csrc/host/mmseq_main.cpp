@@ -12,6 +12,7 @@
 // There is no CPU sampler here: without a HIP device the program stops with an error.
 #include <omp.h>
 #include <atomic>
+#include <sys/stat.h>
 #include <thread>
 #include <mutex>
 #include <condition_variable>
@@ -468,18 +469,27 @@ int main(int argc, char **argv)
     vector<uint32_t> col_idx;
     long long numbermappedreads = 0;
     {
-        // hit set -> row: open-addressing table of row ids keyed by a 64-bit hash of the sorted set; a candidate is
-        // confirmed against the stored row itself, so there is no per-set key allocation (src/mmseq.cpp:395-441 keeps a
-        // map<vector<int>,int> and regrows M)
-        vector<uint32_t> table(1u << 16, 0xffffffffu);
+        // hit set -> row: open-addressing table keyed by a 64-bit hash of the sorted set; an entry is (upper hash half, row id), a
+        // candidate whose tag matches is confirmed against the stored row itself, so there is no per-set key allocation
+        // (src/mmseq.cpp:395-441 keeps a map<vector<int>,int> and regrows M).  The stage is bound by cache misses (one table line
+        // per read, the stored row for a repeat): the slot of a read a dozen ahead is prefetched, and the table starts at the size
+        // the file suggests (a record is >= 16 compressed bytes) instead of being rebuilt at every doubling.
+        constexpr uint64_t EMPTY = ~0ull;
+        size_t table_size = 1u << 16;
+        {
+            struct stat st_;
+            const uint64_t fsz = stat(hits_file.c_str(), &st_) == 0 ? (uint64_t)st_.st_size : 0;
+            while (table_size < fsz / 16 && table_size < (1ull << 31)) table_size <<= 1;
+        }
+        vector<uint64_t> table(table_size, EMPTY);
         vector<uint64_t> row_hash;
         auto grow = [&]() {
-            vector<uint32_t> bigger(table.size() * 2, 0xffffffffu);
+            vector<uint64_t> bigger(table.size() * 2, EMPTY);
             const size_t mask = bigger.size() - 1;
             for (uint32_t r = 0; r < (uint32_t)row_hash.size(); ++r) {
                 size_t s = (size_t)row_hash[r] & mask;
-                while (bigger[s] != 0xffffffffu) s = (s + 1) & mask;
-                bigger[s] = r;
+                while (bigger[s] != EMPTY) s = (s + 1) & mask;
+                bigger[s] = (row_hash[r] & 0xffffffff00000000ull) | r;
             }
             table.swap(bigger);
         };
@@ -563,18 +573,21 @@ int main(int argc, char **argv)
                 at += nc;
                 const uint64_t h = B.hash[r];
                 const size_t mask = table.size() - 1;
+                if (r + 12 < B.len.size()) __builtin_prefetch(&table[(size_t)B.hash[r + 12] & mask]);
                 size_t s = (size_t)h & mask;
                 uint32_t row = 0xffffffffu;
                 for (;; s = (s + 1) & mask) {
-                    const uint32_t rr = table[s];
-                    if (rr == 0xffffffffu) break;
+                    const uint64_t e = table[s];
+                    if (e == EMPTY) break;
+                    if ((e ^ h) >> 32) continue; // another set's tag
+                    const uint32_t rr = (uint32_t)e;
                     if (row_hash[rr] == h && row_ptr[rr + 1] - row_ptr[rr] == nc && equal(comb, comb + nc, col_idx.begin() + (ptrdiff_t)row_ptr[rr])) { row = rr; break; }
                 }
                 if (row == 0xffffffffu) {
                     row = (uint32_t)k.size();
                     if ((row & 0xffff) == 0)
                         cout << "Found " << n_seen.load(memory_order_relaxed) << " transcripts in " << row << " transcript combinations.\r" << flush;
-                    table[s] = row;
+                    table[s] = (h & 0xffffffff00000000ull) | row;
                     row_hash.push_back(h);
                     k.push_back(0);
                     col_idx.insert(col_idx.end(), comb, comb + nc);

@@ -1,17 +1,16 @@
 // K1 on a sliced-ELL ("SELL-64") 8-bit stream: the default sampler kernel.
 //
-// k_sample16 stages every tile through LDS: the block is written there (ds_write_b128), the row extents and
-// the offsets are read back (ds_read_b128) before the mu gathers can start, and the two waves of a
-// workgroup meet at two barriers per tile.  LDS time is what bounds that kernel, and about half of it is
-// this staging, not the gathers.  Here a tile is 64 consecutive rows = one wave, stored column-major:
-// group g of the tile is 64 x (4 u8 window indices) = 256 contiguous bytes, lane r owns bytes [4r, 4r+4): one
-// byte per hit (the window holds 255 transcripts, index 255 is its 0.0 slot).  A lane loads its own row's
-// groups straight into registers with perfectly coalesced 4-byte loads; nothing but
-// the mu gathers and the count atomic touches LDS, and a workgroup is a single wave, so there is no barrier
-// on the tile path at all.  Rows are padded to the longest row of their tile (rows are sorted by leading
-// transcript and length, so slices are homogeneous) with the offset of the window's 0.0 slot: every lane
-// walks the same number of groups, a pad adds an exact 0.0 and can never be selected, so the draw equals
-// the oracle's plain sequential walk bit for bit -- same keyed stream, same additions in the same order.
+// The CSR-tile kernel (k_sample, gibbs_kernels.h) stages every tile through LDS: the column ids are written there, the row extents
+// and the offsets are read back before the mu gathers can start, and the waves of a workgroup meet at barriers per tile -- LDS time
+// bounds it, and about half of that is staging, not gathers.  Here a tile is 64 consecutive rows = one wave, stored column-major:
+// group g of the tile is 64 x (4 u8 window indices) = 256 contiguous bytes, lane r owns bytes [4r, 4r+4): one byte per hit (the
+// window holds 255 transcripts, index 255 is its 0.0 slot).  A lane loads its own row's groups straight into registers with
+// perfectly coalesced 4-byte loads; nothing but the mu gathers and the count atomic touches LDS, and a workgroup is a single wave,
+// so there is no barrier on the tile path at all.  Rows are padded to the longest row of their tile (the canonical order makes
+// tiles homogeneous in length) with the offset of the window's 0.0 slot: every lane walks the same number of groups, a pad adds an
+// exact 0.0 and can never be selected, so the draw equals the oracle's plain sequential walk bit for bit -- same keyed stream, same
+// additions in the same order.  Rows with hits outside the window keep those in a far list behind the block (far tiles); problems
+// with multiplicities run the tiles that hold them through the HAS_K instantiation in a second launch (mmg_types.h).
 #pragma once
 
 namespace mmg {
