@@ -29,13 +29,33 @@ __global__ __launch_bounds__(256) void k_row_keys(uint64_t m, const uint64_t *__
     if (SORT_HITS) {
         bool ascending = true;
         for (uint64_t j = b + 1; j < e; ++j) ascending = ascending && col[j - 1] <= col[j];
-        if (!ascending) // rare (hits files list them sorted, src/bam2hits.cpp:271-300): insertion sort by the row's own thread
-            for (uint64_t j = b + 1; j < e; ++j) {
-                const uint32_t c = col[j];
-                uint64_t q = j;
-                while (q > b && col[q - 1] > c) { col[q] = col[q - 1]; --q; }
-                col[q] = c;
+        if (!ascending) { // rare (hits files list them sorted, src/bam2hits.cpp:271-300): sorted by the row's own thread
+            uint32_t *a = col + b;
+            if (L <= 64) { // insertion sort
+                for (uint64_t j = 1; j < L; ++j) {
+                    const uint32_t c = a[j];
+                    uint64_t q = j;
+                    while (q > 0 && a[q - 1] > c) { a[q] = a[q - 1]; --q; }
+                    a[q] = c;
+                }
+            } else { // heap sort: a long unsorted row must not cost L^2
+                auto sift = [&](uint64_t root, uint64_t end) {
+                    for (;;) {
+                        uint64_t child = 2 * root + 1;
+                        if (child >= end) return;
+                        if (child + 1 < end && a[child] < a[child + 1]) ++child;
+                        if (a[root] >= a[child]) return;
+                        const uint32_t t = a[root]; a[root] = a[child]; a[child] = t;
+                        root = child;
+                    }
+                };
+                for (uint64_t i = L / 2; i-- > 0;) sift(i, L);
+                for (uint64_t end = L - 1; end > 0; --end) {
+                    const uint32_t t = a[0]; a[0] = a[end]; a[end] = t;
+                    sift(0, end);
+                }
             }
+        }
     }
     uint64_t h = 0x9E3779B97F4A7C15ull + L + ((uint64_t)kk << 32);
     uint32_t lo = 0xffffffffu, hi = 0;
@@ -52,8 +72,8 @@ __global__ __launch_bounds__(256) void k_row_keys(uint64_t m, const uint64_t *__
         const bool near = L <= 255 && (uint64_t)hi - (band << LAYOUT_BAND_SHIFT) < LAYOUT_NEAR_SPAN;
         if (!near) { // home band: one below the band of the row's (lower) median hit
             uint32_t med = col[b + (L - 1) / 2];
-            if (!SORT_HITS) { // rows kept as given (e.g. a stored far row: window hits first): the median by rank, not by position
-                const uint64_t want = (L - 1) / 2;
+            if (!SORT_HITS && L <= 4096) { // rows kept as given (e.g. a stored far row: window hits first): the median by rank, not by
+                const uint64_t want = (L - 1) / 2; // position (rows longer than a tile can hold never become far tiles: any band does)
                 for (uint64_t i = b; i < e; ++i) {
                     const uint32_t c = col[i];
                     uint64_t less = 0, equal = 0;

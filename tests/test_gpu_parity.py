@@ -324,6 +324,35 @@ def test_far_tiles_bit_exact(gpu, orc, with_k):
             assert np.array_equal(m2.trace(c), orc.gibbs_keyed(qs, mu0, seed=5, chain=c, n_iter=4, trace_len=4)["trace"])
 
 
+def test_unsorted_and_very_long_rows(gpu, orc):
+    """Hits of a row delivered in arbitrary order (the library sorts them: insertion sort, heap sort above 64 hits), rows far longer
+    than a tile can hold (CSR-walked), kept rows with a long far row (the rank-median's cap): stored order = the oracle's restatement,
+    chain bit-exact."""
+    rng = np.random.default_rng(33)
+    T = 30000
+    rows = [rng.choice(np.arange(lead, lead + 100), size=int(rng.integers(1, 30)), replace=False).tolist() for lead in rng.integers(0, T - 200, size=4000)]
+    rows.append(rng.permutation(T)[:6000].tolist())                        # 6000 hits all over the range, shuffled
+    rows.append(rng.permutation(np.arange(500, 800)).tolist())            # 300 hits in a window and a half, shuffled
+    rows.append([17])
+    rp = np.cumsum([0] + [len(r) for r in rows]).astype(np.uint64)
+    ci = np.concatenate([np.asarray(r, np.uint32) for r in rows])
+    l = np.linspace(0.3, 3.0, T)
+    p = orc.Problem(rp, ci, l)
+    mu0 = rng.gamma(0.5, 1.0, size=T)
+    for keep in (False, True):
+        prob, ps = _dev(gpu, orc, p, keep_rows=keep)
+        if not keep:
+            c_rp, c_ci, _, _ = orc.canonical_layout(rp, ci)
+            assert np.array_equal(ps.row_ptr, c_rp) and np.array_equal(ps.col_idx, c_ci)
+        else:
+            assert np.array_equal(ps.row_ptr, rp) and np.array_equal(ps.col_idx, ci)
+        s = gpu.Sampler(prob, mu0, seed=3, gibbs_iter=6, trace_len=6)
+        s.run(6)
+        ref = orc.gibbs_keyed(ps, mu0, seed=3, n_iter=6, trace_len=6)
+        assert np.array_equal(s.counts(0), ref["cnt"]) and np.array_equal(s.trace(0), ref["trace"])
+        s.close(); prob.close()
+
+
 def test_chains_and_shards_reproduce_single_chain(gpu, orc):
     """(a) chain c of a multi-chain sampler == a single-chain sampler with chain_base=c;
     (b) read-sharding: two shards' counts summed (the all-reduce) == the unsharded chain."""
