@@ -105,7 +105,7 @@ void mmg::weighted_chunks(const std::vector<uint64_t> &cum, uint64_t grid, std::
 // tile costs for the ranges of the persistent workgroups, in halves of a register-path tile (measured, tools/k1_ab.py --far)
 constexpr uint64_t SELL_FAST_TILE_COST = 2;
 constexpr uint64_t SELL_FAR_TILE_COST = 2;   // plus SELL_FAR_ENTRY_COST per entry of the far list
-constexpr uint64_t SELL_FAR_ENTRY_COST = 3;
+constexpr uint64_t SELL_FAR_ENTRY_COST = 4;
 constexpr uint64_t SELL_SLOW_TILE_COST = 48; // a CSR-walked tile
 // k_sample (CSR tiles) costs 2.8 of these units per 64 hits (7.4 ms for 1.0 G uniform hits): a problem dearer on the stream kernel runs there
 
