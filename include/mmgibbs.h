@@ -42,8 +42,9 @@ enum {
     MMG_ERR_IO = 5
 };
 
-/* rows with k <= MMG_K_SMALL draw k categoricals; above, a conditional-binomial chain */
-#define MMG_K_SMALL 8u
+/* rows with k <= MMG_K_SMALL draw k categoricals (a draw costs a fraction of a microsecond once the row's prefix sums are
+ * there); above, a conditional-binomial chain over the row's hits (one binomial per hit, whatever k) */
+#define MMG_K_SMALL 64u
 
 typedef struct mmg_problem mmg_problem; /* device-resident CSR hit-set matrix M + k + l */
 typedef struct mmg_sampler mmg_sampler; /* chains' state: mu, counts, trace, moments     */

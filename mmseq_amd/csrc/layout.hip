@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void k_row_keys(uint64_t m, const uint64_t *__
             band = (mid > 1 ? mid : 1) - 1;
         }
         const uint64_t kclass = kk <= 1 ? 0 : (kk <= K_SMALL ? 1 : 2);
-        kv = ((uint64_t)(near ? 0 : 1) << 63) | (band << 18) | (kclass << 16) | (L < 0xffff ? L : 0xffff);
+        const uint64_t ksmall = kclass == 1 ? kk : 0; // rows that draw k times sort by k first: a tile draws max k times per lane
+        kv = ((uint64_t)(near ? 0 : 1) << 63) | (band << 18) | (kclass << 16) | (ksmall << 9) | (L < 0x1ff ? L : 0x1ff);
     }
     key[r] = kv;
     if (hash) hash[r] = h;

@@ -24,7 +24,7 @@ constexpr uint32_t K_SMALL = MMG_K_SMALL;   // rows with k <= K_SMALL draw k cat
 //   band    = lead for a near row; for a far row its HOME band: max(median hit >> LAYOUT_BAND_SHIFT, 1) - 1 (lower median,
 //             hit[(len - 1) / 2] of the ascending row): the window starting one band below the row's middle holds its bulk
 //   kclass  = 0 (k <= 1), 1 (k <= K_SMALL), 2 (conditional-binomial chain)
-//   key     = !near << 63 | band << 18 | kclass << 16 | min(len, 0xffff)          (an empty row: key 0)
+//   key     = !near << 63 | band << 18 | kclass << 16 | (kclass == 1 ? k : 0) << 9 | min(len, 0x1ff)      (an empty row: key 0)
 //   hash    = fold of (len, k, the ascending hits)
 // A FAR row is stored with the hits inside its home window [band * 64, band * 64 + SELL_WIN) first and the others behind them, each part
 // ascending: the stored order of a row's hits is the order every kernel and the oracle add its weights in.

@@ -272,11 +272,11 @@ def sokal_ref(x):
 # Restates mmseq_amd/csrc/mmg_types.h + layout.hip:k_row_keys: the order in which libmmgibbs stores the rows of a problem.
 LAYOUT_BAND_SHIFT = 6
 LAYOUT_NEAR_SPAN = 240
-K_SMALL = 8
+K_SMALL = 64
 
 
 def row_keys(row_ptr, col_idx, k=None):
-    """(key, hash) per row: key = !near << 63 | band << 18 | kclass << 16 | min(len, 0xffff) (0 for an empty row), band = the band
+    """(key, hash) per row: key = !near << 63 | band << 18 | kclass << 16 | (kclass == 1 ? k : 0) << 9 | min(len, 0x1ff) (0 for an empty row), band = the band
     of the smallest hit for a near row, the home band (one below the band of hit[(len - 1) // 2]) for a far row;
     hash = fold of (len, k, hits in stored order).  Spec: mmseq_amd/csrc/mmg_types.h."""
     rp = np.asarray(row_ptr).astype(np.int64)
@@ -297,8 +297,9 @@ def row_keys(row_ptr, col_idx, k=None):
         band = np.where(near, band, np.maximum(mid, np.uint64(1)) - np.uint64(1))
         kn = kk[ne]
         kclass = np.where(kn <= 1, 0, np.where(kn <= K_SMALL, 1, 2)).astype(np.uint64)
+        ksmall = np.where(kclass == 1, kn, 0).astype(np.uint64)
         key[ne] = ((~near).astype(np.uint64) << np.uint64(63)) | (band << np.uint64(18)) | (kclass << np.uint64(16)) | \
-            np.minimum(Ln, 0xffff)
+            (ksmall << np.uint64(9)) | np.minimum(Ln, 0x1ff)
     with np.errstate(over="ignore"):
         h = np.uint64(0x9E3779B97F4A7C15) + L.astype(np.uint64) + (kk << np.uint64(32))
         M = np.uint64(0xFF51AFD7ED558CCD)

@@ -47,7 +47,7 @@
 #include <omp.h>
 #endif
 
-#define ORC_K_SMALL 8u /* rows with k <= this: k categorical draws; above: binomial chain */
+#define ORC_K_SMALL 64u /* rows with k <= this: k categorical draws; above: binomial chain */
 
 /* ------------------------------------------------------------------------- */
 /* Philox4x32-10 (Salmon et al., SC'11; Random123 reference constants)        */
