@@ -541,6 +541,46 @@ bool HitsfileReader::readReadMapRecordTranscriptIndex(uint32_t &index)
     return true;
 }
 
+bool HitsfileReader::skipReadMapRecordReadID()
+{
+    if (hitsfileSchema == 0) { std::string unused; return readReadMapRecordReadID(unused); }
+    std::string &s = deltaBuffer; // scratch only: the names are not reconstructed
+    if (!src->getline(s)) return false;
+    if (s.empty()) {
+        auto small = [&]() {
+            int b = src->get();
+            if (b < 0) return false;
+            uint32_t v;
+            return b != 255 || src->readU32(v);
+        };
+        if (!small() || !src->getline(s) || !small()) return false;
+    }
+    uint32_t cnt = 0;
+    if (!src->readU32(cnt)) return false;
+    countReadMapRecord = cnt;
+    return true;
+}
+
+bool HitsfileReader::readReadMapRecordTranscriptIndices(std::vector<uint32_t> &out)
+{
+    if (hitsfileSchema == 0) {
+        uint32_t v = 0;
+        while (readReadMapRecordTranscriptIndex(v)) out.push_back(v);
+        return true;
+    }
+    const size_t n = countReadMapRecord, at = out.size();
+    if (n == 0) return true;
+    out.resize(at + n);
+    unsigned char *raw = (unsigned char *)(out.data() + at); // decoded in place: 4 little-endian bytes per index
+    if (!src->read(raw, n * 4)) { out.resize(at); countReadMapRecord = 0; return false; }
+    for (size_t i = 0; i < n; ++i) {
+        const unsigned char *b = raw + 4 * i;
+        out[at + i] = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
+    }
+    countReadMapRecord = 0;
+    return true;
+}
+
 bool HitsfileReader::readReadMapRecordTranscriptID(std::string &transcriptID)
 {
     if (hitsfileSchema == 0) {

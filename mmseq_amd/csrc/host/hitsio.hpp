@@ -76,6 +76,12 @@ public:
     // Additive fast path: the transcript's index in header order instead of its name
     // (the binary schema stores exactly this, src/hitsio.cpp:435-436).  -1 when the record is done.
     bool readReadMapRecordTranscriptIndex(uint32_t &index);
+    // Additive bulk forms for consumers that need neither read names nor one call per hit (a 50 M-read file has 10^9 of those):
+    // the next record's header without materialising its name -- not to be mixed with readReadMapRecordReadID on one reader,
+    // the delta coding of the names (src/hitsio.cpp:102-115) is not tracked -- and all remaining transcript indices of the record,
+    // appended to `out`.
+    bool skipReadMapRecordReadID();
+    bool readReadMapRecordTranscriptIndices(std::vector<uint32_t> &out);
     int schema() const { return hitsfileSchema; }
 
 private:

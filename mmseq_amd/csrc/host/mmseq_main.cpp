@@ -503,20 +503,23 @@ int main(int argc, char **argv)
         mutex mtx;
         condition_variable cv;
         atomic<uint32_t> n_seen{0}; // transcripts numbered so far (progress line only)
-        auto wait_for = [&](int b, int want) { unique_lock<mutex> lk(mtx); cv.wait(lk, [&] { return state[b] == want; }); };
+        double waited[3] = {0.0, 0.0, 0.0}; // seconds each stage spent waiting for a block (MMSEQ_TIMING: which stage bounds the pipeline)
+        auto wait_for = [&](int b, int want, int stage_id) {
+            const double t0 = omp_get_wtime();
+            { unique_lock<mutex> lk(mtx); cv.wait(lk, [&] { return state[b] == want; }); }
+            waited[stage_id] += omp_get_wtime() - t0;
+        };
         auto set_state = [&](int b, int v) { { lock_guard<mutex> lk(mtx); state[b] = v; } cv.notify_all(); };
         thread producer([&]() {
-            string rid;
-            uint32_t h = 0;
             bool more = true;
             for (int b = 0; more; b = (b + 1) % NB) {
-                wait_for(b, 0);
+                wait_for(b, 0, 0);
                 Block &B = blocks[b];
                 B.len.clear(); B.idx.clear();
-                while (B.len.size() < 65536 && (more = hitsfileReader.readReadMapRecordReadID(rid))) {
-                    uint32_t c = 0;
-                    while (hitsfileReader.readReadMapRecordTranscriptIndex(h)) { B.idx.push_back(h); ++c; }
-                    B.len.push_back(c);
+                while (B.len.size() < 65536 && (more = hitsfileReader.skipReadMapRecordReadID())) { // the read names are not used (:395-441)
+                    const size_t before = B.idx.size();
+                    hitsfileReader.readReadMapRecordTranscriptIndices(B.idx);
+                    B.len.push_back((uint32_t)(B.idx.size() - before));
                 }
                 B.last = !more;
                 set_state(b, 1);
@@ -525,7 +528,7 @@ int main(int argc, char **argv)
         thread preparer([&]() {
             bool last = false;
             for (int b = 0; !last; b = (b + 1) % NB) {
-                wait_for(b, 1);
+                wait_for(b, 1, 1);
                 Block &B = blocks[b];
                 last = B.last;
                 B.hash.resize(B.len.size());
@@ -562,7 +565,7 @@ int main(int argc, char **argv)
         });
         bool last = false;
         for (int b = 0; !last; b = (b + 1) % NB) {
-            wait_for(b, 2);
+            wait_for(b, 2, 2);
             const Block &B = blocks[b];
             last = B.last;
             size_t at = 0;
@@ -599,6 +602,7 @@ int main(int argc, char **argv)
             set_state(b, 0);
         }
         preparer.join();
+        if (stage.on) fprintf(stderr, "[timing] ingest stages waited: decode %.1f s, numbering+sort+hash %.1f s, table %.1f s\n", waited[0], waited[1], waited[2]);
         producer.join();
         cout << "Found " << obs2hdr.size() << " transcripts in " << k.size() << " transcript combinations." << endl;
     }
