@@ -493,21 +493,22 @@ int main(int argc, char **argv)
             }
             table.swap(bigger);
         };
-        // Three stages, each its own thread, over a ring of blocks of reads: (1) the reader -- inflate + record decode, strictly
-        // sequential (src/hitsio.hpp:77-79); (2) first-seen transcript numbering (:399-408), the read's hit set sorted and freed of
-        // repeats, its hash; (3) this thread: the hit-set table.  The inflate bounds the pipeline.
-        struct Block { vector<uint32_t> len, idx; vector<uint64_t> hash; bool last = false; };
-        constexpr int NB = 4;
+        // Four stages over a ring of blocks of reads, each stage its own thread(s): (1) the reader -- inflate (a thread of its own inside
+        // hitsio) + record decode, strictly sequential (src/hitsio.hpp:77-79); (2) first-seen transcript numbering (:399-408),
+        // sequential as well; (3) two threads, alternate blocks: every read's hit set sorted and freed of repeats, its hash -- the
+        // longest stage at 50 M reads; (4) this thread: the hit-set table.
+        struct Block { vector<uint32_t> len, idx, dups; vector<uint64_t> hash; bool last = false; };
+        constexpr int NB = 8, NSORT = 2;
         Block blocks[NB];
-        int state[NB] = {0, 0, 0, 0}; // 0: free for the reader, 1: decoded, 2: prepared for the table
+        int state[NB] = {0, 0, 0, 0, 0, 0, 0, 0}; // 0: free for the reader, 1: decoded, 2: numbered, 3: prepared for the table
         mutex mtx;
         condition_variable cv;
         atomic<uint32_t> n_seen{0}; // transcripts numbered so far (progress line only)
-        double waited[3] = {0.0, 0.0, 0.0}; // seconds each stage spent waiting for a block (MMSEQ_TIMING: which stage bounds the pipeline)
+        double waited[4] = {0.0, 0.0, 0.0, 0.0}; // seconds a stage spent waiting for a block (MMSEQ_TIMING: which stage bounds the pipeline)
         auto wait_for = [&](int b, int want, int stage_id) {
             const double t0 = omp_get_wtime();
             { unique_lock<mutex> lk(mtx); cv.wait(lk, [&] { return state[b] == want; }); }
-            waited[stage_id] += omp_get_wtime() - t0;
+            if (stage_id >= 0) waited[stage_id] += omp_get_wtime() - t0;
         };
         auto set_state = [&](int b, int v) { { lock_guard<mutex> lk(mtx); state[b] = v; } cv.notify_all(); };
         thread producer([&]() {
@@ -525,49 +526,70 @@ int main(int argc, char **argv)
                 set_state(b, 1);
             }
         });
-        thread preparer([&]() {
+        thread numberer([&]() {
             bool last = false;
             for (int b = 0; !last; b = (b + 1) % NB) {
                 wait_for(b, 1, 1);
                 Block &B = blocks[b];
                 last = B.last;
-                B.hash.resize(B.len.size());
-                size_t at = 0, out = 0;
-                for (size_t r = 0; r < B.len.size(); ++r) {
-                    uint32_t *c = B.idx.data() + out; // the set is written over the block's own indices (never ahead of the read position)
-                    const uint32_t nin = B.len[r];
-                    for (uint32_t q = 0; q < nin; ++q) {
-                        const uint32_t hidx = B.idx[at++];
-                        if (hidx >= nHeader) {
-                            cerr << "Error: a read maps to a transcript that has no @TranscriptMetaData entry (no length).\n";
-                            exit(1);
-                        }
-                        if (hdr2obs[hidx] < 0) {
-                            hdr2obs[hidx] = (int32_t)obs2hdr.size(); obs2hdr.push_back(hidx); doublehits.push_back(0);
-                            n_seen.store((uint32_t)obs2hdr.size(), memory_order_relaxed);
-                        }
-                        c[q] = (uint32_t)hdr2obs[hidx];
+                for (uint32_t &x : B.idx) {
+                    const uint32_t hidx = x;
+                    if (hidx >= nHeader) {
+                        cerr << "Error: a read maps to a transcript that has no @TranscriptMetaData entry (no length).\n";
+                        exit(1);
                     }
-                    sort(c, c + nin);
-                    uint32_t nu = 0;
-                    for (uint32_t q = 0; q < nin; ++q) {
-                        if (nu && c[nu - 1] == c[q]) doublehits[c[q]]++; // a transcript listed twice for one read (:421-424)
-                        else c[nu++] = c[q];
+                    if (hdr2obs[hidx] < 0) {
+                        hdr2obs[hidx] = (int32_t)obs2hdr.size(); obs2hdr.push_back(hidx);
+                        n_seen.store((uint32_t)obs2hdr.size(), memory_order_relaxed);
                     }
-                    uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)nu;
-                    for (uint32_t q = 0; q < nu; ++q) { h ^= c[q]; h *= 0xff51afd7ed558ccdull; h ^= h >> 32; }
-                    B.hash[r] = h;
-                    B.len[r] = nu;
-                    out += nu;
+                    x = (uint32_t)hdr2obs[hidx];
                 }
                 set_state(b, 2);
             }
         });
+        atomic<int> last_block{-1}; // index of the block that ends the file, once known
+        vector<thread> sorters;
+        for (int w = 0; w < NSORT; ++w)
+            sorters.emplace_back([&, w]() {
+                for (int b = w;; b = (b + NSORT) % NB) {
+                    { // this sorter's next block, or the end of the file in the other sorter's hands
+                        unique_lock<mutex> lk(mtx);
+                        cv.wait(lk, [&] { return state[b] == 2 || last_block.load() >= 0; });
+                        if (state[b] != 2) return;
+                    }
+                    Block &B = blocks[b];
+                    B.hash.resize(B.len.size());
+                    B.dups.clear();
+                    size_t at = 0, out = 0;
+                    for (size_t r = 0; r < B.len.size(); ++r) {
+                        uint32_t *c = B.idx.data() + out; // the set is written over the block's own indices (never ahead of the read position)
+                        const uint32_t nin = B.len[r];
+                        for (uint32_t q = 0; q < nin; ++q) c[q] = B.idx[at++];
+                        sort(c, c + nin);
+                        uint32_t nu = 0;
+                        for (uint32_t q = 0; q < nin; ++q) {
+                            if (nu && c[nu - 1] == c[q]) B.dups.push_back(c[q]); // a transcript listed twice for one read (:421-424)
+                            else c[nu++] = c[q];
+                        }
+                        uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)nu;
+                        for (uint32_t q = 0; q < nu; ++q) { h ^= c[q]; h *= 0xff51afd7ed558ccdull; h ^= h >> 32; }
+                        B.hash[r] = h;
+                        B.len[r] = nu;
+                        out += nu;
+                    }
+                    const bool was_last = B.last;
+                    if (was_last) last_block.store(b);
+                    set_state(b, 3);
+                    if (was_last) return;
+                }
+            });
+        vector<uint32_t> all_dups;
         bool last = false;
         for (int b = 0; !last; b = (b + 1) % NB) {
-            wait_for(b, 2, 2);
+            wait_for(b, 3, 3);
             const Block &B = blocks[b];
             last = B.last;
+            all_dups.insert(all_dups.end(), B.dups.begin(), B.dups.end());
             size_t at = 0;
             for (size_t r = 0; r < B.len.size(); ++r) {
                 numbermappedreads++;
@@ -601,8 +623,12 @@ int main(int argc, char **argv)
             }
             set_state(b, 0);
         }
-        preparer.join();
-        if (stage.on) fprintf(stderr, "[timing] ingest stages waited: decode %.1f s, numbering+sort+hash %.1f s, table %.1f s\n", waited[0], waited[1], waited[2]);
+        numberer.join();
+        cv.notify_all();
+        for (auto &t : sorters) t.join();
+        doublehits.assign(obs2hdr.size(), 0);
+        for (uint32_t o : all_dups) doublehits[o]++;
+        if (stage.on) fprintf(stderr, "[timing] ingest stages waited: decode %.1f s, numbering %.1f s, table %.1f s (the sort + hash stage is the rest)\n", waited[0], waited[1], waited[3]);
         producer.join();
         cout << "Found " << obs2hdr.size() << " transcripts in " << k.size() << " transcript combinations." << endl;
     }
