@@ -159,7 +159,21 @@ __global__ __launch_bounds__(256) void k_max_len(uint64_t m, const uint64_t *__r
     if ((threadIdx.x & 63) == 0 && L) atomicMax(out, L);
 }
 
+// caller transcript ids -> device ids, in place
+__global__ __launch_bounds__(256) void k_map_cols(uint64_t nnz, uint32_t *__restrict__ col, const uint32_t *__restrict__ int_of_ext)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nnz; j += stride) col[j] = int_of_ext[col[j]];
+}
+
 static inline unsigned blocks_of(uint64_t n) { return (unsigned)((n + 255) / 256); }
+
+hipError_t layout_map_cols(uint64_t nnz, uint32_t *d_col, const uint32_t *d_int_of_ext, hipStream_t s)
+{
+    if (nnz) hipLaunchKernelGGL(k_map_cols, dim3((unsigned)std::min<uint64_t>((nnz + 255) / 256, 65536)), dim3(256), 0, s, nnz, d_col, d_int_of_ext);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? hipStreamSynchronize(s) : e;
+}
 
 hipError_t layout_row_keys(uint64_t m, const uint64_t *d_rp, const uint32_t *d_col, const uint32_t *d_k, uint64_t *d_key, hipStream_t s)
 {

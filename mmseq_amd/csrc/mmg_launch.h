@@ -60,6 +60,7 @@ double host_start_value(uint64_t a0, uint64_t a1, uint64_t a2, double l);
 
 // ---- layout.hip: the canonical row order (mmg_types.h) on the device
 // Row keys of the CSR in its current order.  d_key: m u64 (caller frees).
+hipError_t layout_map_cols(uint64_t nnz, uint32_t *d_col, const uint32_t *d_int_of_ext, hipStream_t s);
 hipError_t layout_row_keys(uint64_t m, const uint64_t *d_rp, const uint32_t *d_col, const uint32_t *d_k, uint64_t *d_key, hipStream_t s);
 // Sorts the CSR canonically: on return *d_rp / *d_col / *d_k (k may be nullptr) are NEW device buffers in canonical order (the
 // old ones are freed), d_key holds the sorted keys.  col_pad: extra u32 slots allocated (zeroed) behind col.  m < 2^32.

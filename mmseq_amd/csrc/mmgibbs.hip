@@ -418,8 +418,8 @@ extern "C" int mmg_problem_create(const mmg_problem_desc *d, int device, mmg_pro
     uint64_t *d_rp64 = nullptr;
     auto bail = [&](int code) { if (d_rp64) (void)hipFree(d_rp64); problem_free(p); return code; };
 #define C_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return bail(fail(MMG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); } while (0)
-    // transcript renumbering: device id = rank of (tx_order[t], t); rows are re-sorted ascending in device ids
-    std::vector<uint32_t> col_int;
+    // transcript renumbering: device id = rank of (tx_order[t], t).  The hits are renumbered on the device; the canonical layout then
+    // sorts every row's hits (layout.hip), kept rows keep the order they came in (a stored far row: window hits first).
     const uint32_t *col_src = d->col_idx;
     std::vector<double> l_int;
     const double *l_src = d->l;
@@ -430,16 +430,6 @@ extern "C" int mmg_problem_create(const mmg_problem_desc *d, int device, mmg_pro
         p->h_ext_of_int = order;
         p->h_int_of_ext.resize(d->n);
         for (uint32_t i = 0; i < d->n; ++i) p->h_int_of_ext[order[i]] = i;
-        col_int.resize(nnz);
-        const std::vector<uint32_t> &map = p->h_int_of_ext;
-        parallel_slices(d->m, [&](uint64_t a, uint64_t b) {
-            for (uint64_t r = a; r < b; ++r) {
-                const uint64_t s = d->row_ptr[r], e = d->row_ptr[r + 1];
-                for (uint64_t j = s; j < e; ++j) col_int[j] = map[d->col_idx[j]];
-                std::sort(col_int.begin() + (ptrdiff_t)s, col_int.begin() + (ptrdiff_t)e);
-            }
-        });
-        col_src = col_int.data();
         l_int.resize(d->n);
         for (uint32_t i = 0; i < d->n; ++i) l_int[i] = d->l[order[i]];
         l_src = l_int.data();
@@ -453,7 +443,7 @@ extern "C" int mmg_problem_create(const mmg_problem_desc *d, int device, mmg_pro
     C_TRY(hipMalloc((void **)&p->d_col, col_bytes));
     C_TRY(hipMemset(p->d_col, 0, col_bytes));
     if (nnz) C_TRY(hipMemcpy(p->d_col, col_src, nnz * sizeof(uint32_t), hipMemcpyHostToDevice));
-    std::vector<uint32_t>().swap(col_int);
+    if (nnz && p->d_int_of_ext) C_TRY(layout_map_cols(nnz, p->d_col, p->d_int_of_ext, 0));
     p->device_bytes += col_bytes;
     if (d->k && d->m) {
         C_TRY(hipMalloc((void **)&p->d_k, d->m * sizeof(uint32_t)));
