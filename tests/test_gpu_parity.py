@@ -353,6 +353,39 @@ def test_unsorted_and_very_long_rows(gpu, orc):
         s.close(); prob.close()
 
 
+def test_shards_of_a_stored_problem_with_far_rows_and_tx_order(gpu, orc):
+    """What `mmseq -gpus N` does: the stored rows of device 0's problem (download), cut at even boundaries, uploaded as kept rows with
+    the same transcript numbering -- the shards' counts add up to the unsharded chain's, far rows (stored window-hits-first, NOT
+    ascending) and multiplicities included."""
+    rng = np.random.default_rng(8)
+    p, _ = orc.synth_problem(R=50000, T=12000, avg_hits=7, seed=31, sort=False, far_fraction=0.25)
+    scat = rng.permutation(p.n).astype(np.uint32)
+    ci_ext = scat[p.col_idx]
+    l_ext = np.empty(p.n); l_ext[scat] = p.l
+    tx_order = np.empty(p.n, np.uint64); tx_order[scat] = np.arange(p.n, dtype=np.uint64)
+    k = rng.choice([1, 1, 1, 2, 5, 70], size=p.m).astype(np.uint32)
+    prob = gpu.Problem.from_csr(p.row_ptr, ci_ext, l_ext, k=k, tx_order=tx_order)
+    assert prob.info.far_tiles > 0
+    rp, ci, kk = prob.download(with_k=True)
+    mu0 = rng.gamma(0.7, 1.0, size=p.n)
+    s = gpu.Sampler(prob, mu0, seed=19, gibbs_iter=1, trace_len=1)
+    s.sample()
+    whole = s.counts(0)
+    assert np.array_equal(whole, orc.sample_counts(orc.Problem(rp, ci, l_ext, k=kk), mu0, seed=19, chain=0, it=0))
+    cut = (p.m // 2) & ~1
+    nz = int(rp[cut])
+    parts = []
+    for lo, hi in ((0, cut), (cut, p.m)):
+        a, b = int(rp[lo]), int(rp[hi])
+        sh = gpu.Problem.from_csr(rp[lo:hi + 1] - rp[lo], ci[a:b], l_ext, k=kk[lo:hi], row_id_base=lo, keep_rows=True, tx_order=tx_order)
+        d_rp, d_ci = sh.download()
+        assert np.array_equal(d_ci, ci[a:b])                       # hit order kept as stored
+        ss = gpu.Sampler(sh, mu0, seed=19, gibbs_iter=1, trace_len=1)
+        ss.sample()
+        parts.append(ss.counts(0))
+    assert np.array_equal(parts[0] + parts[1], whole) and nz > 0
+
+
 def test_chains_and_shards_reproduce_single_chain(gpu, orc):
     """(a) chain c of a multi-chain sampler == a single-chain sampler with chain_base=c;
     (b) read-sharding: two shards' counts summed (the all-reduce) == the unsharded chain."""
