@@ -177,7 +177,11 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
         if (opt(MMG_OPT_SELL_WAVES_PER_CU) >= 1 && opt(MMG_OPT_SELL_WAVES_PER_CU) < per_cu) per_cu = opt(MMG_OPT_SELL_WAVES_PER_CU);
         return std::max<uint64_t>(1, std::min<uint64_t>(nt, (uint64_t)p->cu_count * per_cu));
     };
-    const uint64_t grid = resident_grid(false);
+    // The k = 1 launch: as many workgroups as fit at once while a range is short (every workgroup pays for a window load and the
+    // fill of its prefetch pipeline: at config 2 a range is 10 tiles), up to four generations of them once ranges are long -- the
+    // later generations start as the first ones finish and even out the tail (config 3: 109 tiles per range at one generation, -2 to -4 %).
+    uint64_t grid = resident_grid(false);
+    if (opt(MMG_OPT_SELL_WAVES_PER_CU) < 1) grid = std::min<uint64_t>(nt, grid * std::min<uint64_t>(4, std::max<uint64_t>(1, nt / (grid * 12))));
     // h_sell_cum: what a tile costs whatever its multiplicities (the EM kernel's ranges, the choice of the kernel); cum1 / cumk: the
     // ranges of the two sample launches of a problem with multiplicities -- tiles whose rows all have k = 1, and the others, where a
     // row draws k times (k <= K_SMALL) or runs a binomial per hit.  Identical reads pile up on few hit sets of few abundant

@@ -31,6 +31,14 @@ def lib():
     path = os.path.join(_HERE, "liboracle.so")
     if not os.path.exists(path):
         build()
+    if "OMP_NUM_THREADS" not in os.environ:
+        # a container's CPU quota is invisible to OpenMP: one thread per host core, throttled to the quota's worth of time
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if q != "max":
+                os.environ["OMP_NUM_THREADS"] = str(max(1, -(-int(q) // int(per))))
+        except (OSError, ValueError):
+            pass
     L = C.CDLL(path)
     L.orc_philox.argtypes = [u32p, u32p, u32p]
     L.orc_philox2x32.argtypes = [u32p, C.c_uint32, u32p]
