@@ -177,11 +177,16 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
         if (opt(MMG_OPT_SELL_WAVES_PER_CU) >= 1 && opt(MMG_OPT_SELL_WAVES_PER_CU) < per_cu) per_cu = opt(MMG_OPT_SELL_WAVES_PER_CU);
         return std::max<uint64_t>(1, std::min<uint64_t>(nt, (uint64_t)p->cu_count * per_cu));
     };
-    // The k = 1 launch: as many workgroups as fit at once while a range is short (every workgroup pays for a window load and the
-    // fill of its prefetch pipeline: at config 2 a range is 10 tiles), up to four generations of them once ranges are long -- the
-    // later generations start as the first ones finish and even out the tail (config 3: 109 tiles per range at one generation, -2 to -4 %).
-    uint64_t grid = resident_grid(false);
-    if (opt(MMG_OPT_SELL_WAVES_PER_CU) < 1) grid = std::min<uint64_t>(nt, grid * std::min<uint64_t>(4, std::max<uint64_t>(1, nt / (grid * 12))));
+    // As many workgroups as fit at once while a range is short (every workgroup pays for a window load and the fill of its prefetch
+    // pipeline: at config 2 a range is 10 tiles); once ranges are long, several generations of them with ranges of about 24 tiles --
+    // the later generations start as the first ones finish and even out the tail.  Measured at config 3: k_sample_sell 109 tiles per
+    // range in one generation -> 27 in four, -2 to -4 %; the pair kernel 190 -> 24 in eight, -8 %; shorter ranges lose again.
+    auto generations = [&](uint64_t resident) {
+        if (opt(MMG_OPT_SELL_WAVES_PER_CU) >= 1) return resident;
+        const uint64_t g = (nt + resident * 12) / (resident * 24); // nearest
+        return std::min<uint64_t>(nt, resident * std::min<uint64_t>(16, std::max<uint64_t>(1, g)));
+    };
+    const uint64_t grid = generations(resident_grid(false));
     // h_sell_cum: what a tile costs whatever its multiplicities (the EM kernel's ranges, the choice of the kernel); cum1 / cumk: the
     // ranges of the two sample launches of a problem with multiplicities -- tiles whose rows all have k = 1, and the others, where a
     // row draws k times (k <= K_SMALL) or runs a binomial per hit.  Identical reads pile up on few hit sets of few abundant
@@ -288,7 +293,7 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, k1_sell_multi_kernel(p->idx64, 2 << q), 64, 0) != hipSuccess || pc < 1) { (void)hipGetLastError(); pc = 8; }
             if (pc > 32) pc = 32;
             if (opt(MMG_OPT_SELL_WAVES_PER_CU) >= 1 && opt(MMG_OPT_SELL_WAVES_PER_CU) < pc) pc = opt(MMG_OPT_SELL_WAVES_PER_CU);
-            const uint64_t gq = std::max<uint64_t>(1, std::min<uint64_t>(nt, (uint64_t)p->cu_count * pc));
+            const uint64_t gq = generations(std::max<uint64_t>(1, std::min<uint64_t>(nt, (uint64_t)p->cu_count * pc)));
             std::vector<uint64_t> cq;
             weighted_chunks(p->h_sell_cum, gq, cq);
             HIP_TRY(hipMalloc((void **)&p->d_sell_chunk_m[q], cq.size() * sizeof(uint64_t)));
