@@ -89,6 +89,10 @@ def test_header_consistency_errors(tmp_path):
     p.write_bytes(b"@TranscriptMetaData\tA\t0\t280\n@GeneIsoforms\tG1\tA\n>r\nA\n")
     r = run([str(p), str(tmp_path / "o")])
     assert r.returncode == 1 and b"Error: transcript 'A' has a length of zero." in r.stderr
+    # a read that maps to a transcript without a header entry: reported from inside the ingest pipeline's threads, exit code 1
+    p.write_bytes(b"@TranscriptMetaData\tA\t100\t280\n@GeneIsoforms\tG1\tA\n>r1\nA\n>r2\nA\nZ\n")
+    r = run([str(p), str(tmp_path / "o")], timeout=60)
+    assert r.returncode == 1 and b"has no @TranscriptMetaData entry" in r.stderr
 
 
 def test_without_device_fails_loudly_after_writing_k_and_M(tmp_path):
