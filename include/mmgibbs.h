@@ -102,7 +102,8 @@ typedef struct mmg_problem_info {
     uint64_t padded_slots; /* hit slots of the sliced-ELL stream incl. padding (>= nnz of the fast tiles) */
     int32_t layout;        /* MMG_LAYOUT_* in force                                       */
     int32_t tx_renumbered; /* 1: tx_order was given                                       */
-    int32_t sample_grid;   /* workgroups of the (persistent) sample kernel: resident waves the runtime reports x CUs */
+    int32_t sample_grid;   /* workgroups of the sample kernel: the resident count (waves the runtime reports x CUs) times the
+                              number of generations (1..16: tile ranges of about 24 tiles once the problem is large) */
     int32_t cu_count;
 } mmg_problem_info;
 
