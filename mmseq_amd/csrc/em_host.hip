@@ -128,16 +128,18 @@ extern "C" int mmg_em_create(const mmg_problem *cp, const double *mu0, mmg_em **
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, EM_SELL_BS, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 4; }
             if (per_cu > 32) per_cu = 32;
             uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, (uint64_t)p->cu_count * per_cu));
+            uint64_t resident = 0; // > 0: the last generation's ranges are halved (weighted_chunks_tapered)
             if (opt(MMG_OPT_EM_GRID) >= 1) {
                 if ((uint64_t)opt(MMG_OPT_EM_GRID) < grid) grid = (uint64_t)opt(MMG_OPT_EM_GRID); // tests: long tile ranges on small problems
             } else {
                 // several generations of workgroups once ranges are long (about 24 tiles per wave: mmgibbs.hip, problem_build_sell):
                 // config 3 has 381 tiles per range in one generation, 48 in eight: 1.81 -> 1.52 ms per sweep
                 const uint64_t g = (n_tiles + grid * 24) / (grid * 48);
+                resident = grid;
                 grid = std::min<uint64_t>(n_tiles, grid * std::min<uint64_t>(16, std::max<uint64_t>(1, g)));
             }
             std::vector<uint64_t> chunk(grid + 1);
-            if (p->h_sell_cum.size() == n_tiles + 1) weighted_chunks(p->h_sell_cum, grid, chunk);
+            if (p->h_sell_cum.size() == n_tiles + 1) { weighted_chunks_tapered(p->h_sell_cum, grid, resident, chunk); grid = chunk.size() - 1; }
             else for (uint64_t c = 0; c <= grid; ++c) chunk[c] = (uint64_t)(((unsigned __int128)n_tiles * c) / grid);
             EM_TRY(hipMalloc((void **)&e->d_chunk[w], chunk.size() * sizeof(uint64_t)));
             EM_TRY(hipMemcpy(e->d_chunk[w], chunk.data(), chunk.size() * sizeof(uint64_t), hipMemcpyHostToDevice));

@@ -66,6 +66,7 @@ int fail(int code, const std::string &msg);   // records the thread-local messag
 int opt(int option);                          // mmg_selftest_option value, -1 = default
 int require_device(int device);
 void weighted_chunks(const std::vector<uint64_t> &cum, uint64_t grid, std::vector<uint64_t> &chunk);
+void weighted_chunks_tapered(const std::vector<uint64_t> &cum, uint64_t grid, uint64_t resident, std::vector<uint64_t> &chunk);
 
 #define HIP_TRY(expr)                                                                                         \
     do {                                                                                                      \

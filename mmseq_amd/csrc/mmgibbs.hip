@@ -109,6 +109,23 @@ constexpr uint64_t SELL_FAR_ENTRY_COST = 4;
 constexpr uint64_t SELL_SLOW_TILE_COST = 48; // a CSR-walked tile
 // k_sample (CSR tiles) costs 2.8 of these units per 64 hits (7.4 ms for 1.0 G uniform hits): a problem dearer on the stream kernel runs there
 
+// The same with a tapered end: the last `resident` ranges' worth of cost is cut into twice as many ranges of half the cost (the
+// workgroups that start last finish closer together).  grid -> grid + resident ranges; needs grid >= 2 * resident.
+void mmg::weighted_chunks_tapered(const std::vector<uint64_t> &cum, uint64_t grid, uint64_t resident, std::vector<uint64_t> &chunk)
+{
+    if (resident == 0 || grid < 2 * resident) { mmg::weighted_chunks(cum, grid, chunk); return; }
+    const uint64_t nt = cum.size() - 1, total = cum[nt], full = grid - resident, n = full + 2 * resident;
+    chunk.assign(n + 1, 0);
+    uint64_t t = 0;
+    for (uint64_t c = 1; c < n; ++c) {
+        const uint64_t halves = c <= full ? 2 * c : 2 * full + (c - full); // cost of ranges [0, c) in half-range units
+        const uint64_t target = (uint64_t)(((unsigned __int128)total * halves) / (2 * grid));
+        while (t < nt && cum[t] < target) ++t;
+        chunk[c] = t;
+    }
+    chunk[n] = nt;
+}
+
 // Sliced-ELL stream: tiles of <= 64 rows that never cross a (near, band) boundary of the canonical order, one window per tile.
 static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_starts, const uint64_t *d_key)
 {
@@ -204,10 +221,12 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
         cumk[t + 1] = cumk[t] + (!hk ? 0 : 2 * c + (td[t].kmax <= K_SMALL ? (uint64_t)td[t].kmax : 3 * (uint64_t)td[t].maxlen));
     }
     std::vector<uint64_t> chunk;
-    weighted_chunks(n_hask ? p->h_sell_cum : cum1, grid, chunk); // (with SELL_HASK tiles: only the windows below follow these ranges)
+    if (n_hask) weighted_chunks(p->h_sell_cum, grid, chunk); // (with SELL_HASK tiles: only the windows below follow these ranges)
+    else weighted_chunks_tapered(cum1, grid, opt(MMG_OPT_SELL_WAVES_PER_CU) >= 1 ? 0 : resident_grid(false), chunk);
+    const uint64_t n_ranges = chunk.size() - 1;
     std::vector<SellTile> st(nt);
     uint64_t n_fast = 0, n_far = 0, pos = 0, slots = 0;
-    for (uint64_t c = 0; c < grid; ++c) {
+    for (uint64_t c = 0; c < n_ranges; ++c) {
         bool have = false;
         uint32_t cur = 0;
         for (uint64_t t = chunk[c]; t < chunk[c + 1]; ++t) if (td[t].nnz) { cur = is_far(t) ? far_wbase[t] : td[t].call & BAND_MASK; break; }
@@ -259,7 +278,7 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
     HIP_TRY(hipMemset(p->d_sell, 0, alloc));
     HIP_TRY(hipMalloc((void **)&p->d_sell_tiles, nt * sizeof(SellTile)));
     HIP_TRY(hipMemcpy(p->d_sell_tiles, st.data(), nt * sizeof(SellTile), hipMemcpyHostToDevice));
-    p->grid_sell = (int)grid;
+    p->grid_sell = (int)n_ranges;
     p->n_hask_tiles = n_hask;
     if (n_hask) { // two launches, each over its own descriptor list and ranges
         std::vector<SellTile> s1, sk;
@@ -293,9 +312,10 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, k1_sell_multi_kernel(p->idx64, 2 << q), 64, 0) != hipSuccess || pc < 1) { (void)hipGetLastError(); pc = 8; }
             if (pc > 32) pc = 32;
             if (opt(MMG_OPT_SELL_WAVES_PER_CU) >= 1 && opt(MMG_OPT_SELL_WAVES_PER_CU) < pc) pc = opt(MMG_OPT_SELL_WAVES_PER_CU);
-            const uint64_t gq = generations(std::max<uint64_t>(1, std::min<uint64_t>(nt, (uint64_t)p->cu_count * pc)));
+            const uint64_t rq = std::max<uint64_t>(1, std::min<uint64_t>(nt, (uint64_t)p->cu_count * pc));
             std::vector<uint64_t> cq;
-            weighted_chunks(p->h_sell_cum, gq, cq);
+            weighted_chunks_tapered(p->h_sell_cum, generations(rq), opt(MMG_OPT_SELL_WAVES_PER_CU) >= 1 ? 0 : rq, cq);
+            const uint64_t gq = cq.size() - 1;
             HIP_TRY(hipMalloc((void **)&p->d_sell_chunk_m[q], cq.size() * sizeof(uint64_t)));
             HIP_TRY(hipMemcpy(p->d_sell_chunk_m[q], cq.data(), cq.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
             p->grid_sell_m[q] = (int)gq;
