@@ -224,8 +224,12 @@ def main():
         t = torch.from_numpy(mu0 * prob.l()).cuda()       # shares k/|row| summed over ranks, then / l
         dist.all_reduce(t)
         mu0 = t.cpu().numpy() / prob.l()
-    trace_len = 1024
-    gibbs_iter = 1024                                      # every iteration is a kept sample (BASELINE.md B formula)
+    # every iteration is a kept sample (BASELINE.md B formula): the reference's 1024-iteration, 1024-sample run; a longer timed region
+    # (--warmup + --steps > 1024) keeps every iteration as well, in a longer resident trace
+    need = args.warmup + args.steps
+    trace_len = gibbs_iter = 1024 if need <= 1024 else -(-need // 64) * 64
+    if gibbs_iter * args.transcripts * args.chains * 8 > 200e9:
+        raise SystemExit("warmup + steps = %d: the resident trace would exceed 200 GB" % need)
     chain_base = 0 if args.mode == "shard" else rank * args.chains
     smp = Sampler(prob, mu0, seed=args.seed, n_chains=args.chains, chain_base=chain_base, gibbs_iter=gibbs_iter,
                   trace_len=trace_len, keep_trace=True,
@@ -240,8 +244,6 @@ def main():
         else:
             smp.run(1)
 
-    if args.warmup + args.steps > gibbs_iter:
-        raise SystemExit("warmup + steps must be <= %d" % gibbs_iter)
     cold_ms = None
     if args.settle_iters > 0:
         # The GPU raises its clocks over the first ~100 ms of load: steps right after start-up are ~10 % slower than steps 200+.
