@@ -22,11 +22,21 @@
 extern "C" {
 #endif
 
-#define MMG_ABI_VERSION 3
+#define MMG_ABI_VERSION 4
+/* Version history of the SPEC behind the entry points: under one version a chain is a pure function of (problem, tx_order, seed,
+ * chain, iteration); a bump means the same inputs may yield different bits (golden fixtures and the oracle move with it).
+ *   3  (round 2) rows with 2 <= k <= 64 draw k categoricals (before: k <= 8), sorted by k inside their class.  The constant moved
+ *      without a bump at the time; recorded here.
+ *   4  (round 3) canonical row order: ties inside a key are broken by the CENTRE of the row -- the sum of its hits' offsets in the
+ *      window its key names -- before the content hash, so that the 64 rows of a tile gather neighbouring window slots (LDS bank
+ *      conflicts of the sample and EM kernels: -50 %).  The per-row random stream follows the stored position, so chains of
+ *      problems stored in the canonical layout differ from version 3; MMG_LAYOUT_KEEP_ROWS problems (and the committed golden
+ *      chain, which keeps its rows) do not.  The draw target is now specified as fma(x, t 2^-32, t 2^-33) (mmg_math.h:
+ *      draw_target): the same real number rounded once, bit-identical to version 3 unless t 2^-33 underflows. */
 /* Layout.  The model does not care about the order of rows or the numbering of transcripts (src/mmseq.cpp:399-418 uses
  * first-seen order for both); the kernels do: they keep a window of consecutive transcripts in LDS and want the 64 rows of a
  * wave to have equal lengths.  mmg_problem_create therefore stores the rows in a CANONICAL order of its own (sorted on the
- * device by leading-transcript band, multiplicity class, length and a content hash -- a pure function of the set of rows, so
+ * device by leading-transcript band, multiplicity class, length, row centre and a content hash -- a pure function of the set of rows, so
  * the chain does not depend on the order the caller happened to read them in) and, given tx_order, renumbers the transcripts
  * internally.  Every per-transcript array crossing this ABI stays in the CALLER's numbering; rows never cross it. */
 #define MMG_LAYOUT_CANONICAL 0u /* default: rows re-ordered by the library                                      */

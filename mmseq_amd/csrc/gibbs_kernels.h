@@ -205,14 +205,15 @@ __device__ __forceinline__ void allocate_row(const View &v, Add add, uint32_t kk
     const bool degenerate = !(total > 0.0) || !(total < __builtin_huge_val());
     if (!HAS_K || kk <= K_SMALL) {
         Stream2 s(a.seed, a.chain, TAG_ROW, row_id, a.iter);
+        const double ts = total * 0x1p-32, hs = ts * 0.5; // draw_target (mmg_math.h)
         for (uint32_t d = 0; d < kk; ++d) {
-            const double u = s.next();
+            const uint32_t x = s.next_word();
             uint32_t sel;
             if (degenerate) {
-                sel = (uint32_t)(u * (double)L);
+                sel = (uint32_t)(u32_unit(x) * (double)L);
                 if (sel >= L) sel = L - 1;
             } else {
-                sel = v.pick(u * total);
+                sel = v.pick(draw_target(x, ts, hs));
             }
             add(v.col(sel), 1);
         }

@@ -4,7 +4,8 @@
 // rows as exchangeable.  The library sorts them by (near/far, leading-transcript band, multiplicity class, length, content hash),
 // stably, with rocPRIM radix sorts on the device, so that (a) a 64-row tile of the sliced-ELL stream touches one LDS window and
 // holds rows of equal length, and (b) the stored order -- and with it the per-row random streams -- is a function of the SET of
-// rows, not of the order the caller read them in.
+// rows, not of the order the caller read them in.  Ties inside a key: the centre of the row (sum of its window offsets) before the
+// content hash -- the lanes of a tile then gather neighbouring LDS slots (mmg_types.h).
 #include <cstring>
 #include <algorithm>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -89,6 +90,15 @@ __global__ __launch_bounds__(256) void k_row_keys(uint64_t m, const uint64_t *__
         kv = ((uint64_t)(near ? 0 : 1) << 63) | (band << 18) | (kclass << 16) | (ksmall << 9) | (L < 0x1ff ? L : 0x1ff);
     }
     key[r] = kv;
+    if (hash) {
+        // tie order inside a key: the centre of the row's window hits first (LAYOUT_CSUM, mmg_types.h), then the content hash
+        uint64_t cs = 0;
+        if (L) {
+            const uint32_t wbase = (uint32_t)(((kv >> 18) & LAYOUT_KEY_BAND_MASK) << LAYOUT_BAND_SHIFT);
+            for (uint64_t j = b; j < e; ++j) { const uint32_t d = col[j] - wbase; cs += d < SELL_WIN ? d : 0u; }
+        }
+        h = (cs << 48) | (h >> 16);
+    }
     if (hash) hash[r] = h;
     if (len) len[r] = (uint32_t)(L < 0xffffffffull ? L : 0xffffffffull);
 }

@@ -68,10 +68,11 @@ MMG_HD void philox2x32_10(uint32_t &c0, uint32_t &c1, uint32_t k)
         uint64_t pr;
         asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(pr) : "v"(c0), "s"(0xD256D193u) : "vcc");
         const uint32_t hi = (uint32_t)(pr >> 32), lo = (uint32_t)pr;
+        c0 = __builtin_amdgcn_bitop3_b32(hi, c1, k, 0x96); // hi ^ c1 ^ k as ONE instruction (gfx950): a VALU slot per round less
 #else
         const uint32_t hi = mulhi32(0xD256D193u, c0), lo = 0xD256D193u * c0;
-#endif
         c0 = hi ^ k ^ c1;
+#endif
         c1 = lo;
         k += 0x9E3779B9u;
     }
@@ -121,6 +122,19 @@ MMG_HD double u32_unit(uint32_t x)
 #endif
 }
 
+// The target of a categorical draw over weights of total t from a 32-bit random word x: (x + 1/2) 2^-32 * t, as ONE fused
+// multiply-add of the exact product terms ts = t 2^-32 and hs = t 2^-33 (both exact unless they underflow): fma(x, ts, hs) rounds
+// the real number (x + 1/2) 2^-32 t once, like u32_unit(x) * t does -- in two instructions (conversion, fma) instead of five.
+// Host (libm fma), gfx950 (v_fma_f64) and the oracle agree bit for bit.
+MMG_HD double draw_target(uint32_t x, double ts, double hs)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __fma_rn((double)x, ts, hs);
+#else
+    return __builtin_fma((double)x, ts, hs);
+#endif
+}
+
 // Row stream.  One Philox2x32-10 block serves the TWO rows 2q and 2q+1: key from (seed, chain, tag, q >> 32), counter
 // (q & 0xffffffff, iteration); row id r = 2q + h takes output word h; the b-th uniform of a row uses key + b * 0xBB67AE85.
 // The per-row allocation draw is the bulk of a sweep's integer work (10 quarter-rate multiplies per block): a wave of
@@ -133,13 +147,14 @@ struct Stream2 {
     uint32_t key, c0, c1, blk, half;
     MMG_HD Stream2(uint64_t seed, uint32_t chain, uint32_t tag, uint64_t id, uint32_t iter)
         : key(stream2_key(seed, chain, tag, (uint32_t)(id >> 33))), c0((uint32_t)(id >> 1)), c1(iter), blk(0), half((uint32_t)id & 1u) {}
-    MMG_HD double next()
+    MMG_HD uint32_t next_word()
     {
         uint32_t a = c0, b = c1;
         philox2x32_10(a, b, key + blk * 0xBB67AE85u);
         ++blk;
-        return u32_unit(half ? b : a);
+        return half ? b : a;
     }
+    MMG_HD double next() { return u32_unit(next_word()); }
 };
 
 // one-uniform-at-a-time view of a stream (first of each pair, then second)

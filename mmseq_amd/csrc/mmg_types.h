@@ -18,7 +18,7 @@ constexpr uint32_t K_SMALL = MMG_K_SMALL;   // rows with k <= K_SMALL draw k cat
 // ---- canonical layout (restated in oracle/binding.py:canonical_layout) -----------------------------
 // Rows are exchangeable in the model (src/mmseq.cpp:857-891 visits them in file order only because that is how they were
 // read), and a row is a SET of transcripts (the reference walks it in ascending order, :871).  The library puts every row's hits in
-// ascending order and stores the rows sorted by row_key, ties by row_hash, then by the caller's position.
+// ascending order and stores the rows sorted by row_key, ties by the tie word below, then by the caller's position.
 //   lead    = smallest transcript of the row >> LAYOUT_BAND_SHIFT       (bands of 64 consecutive transcripts)
 //   near    = every hit of the row lies in [lead * 64, lead * 64 + LAYOUT_NEAR_SPAN) and the row has <= 255 hits
 //   band    = lead for a near row; for a far row its HOME band: max(median hit >> LAYOUT_BAND_SHIFT, 1) - 1 (lower median,
@@ -26,6 +26,11 @@ constexpr uint32_t K_SMALL = MMG_K_SMALL;   // rows with k <= K_SMALL draw k cat
 //   kclass  = 0 (k <= 1), 1 (k <= K_SMALL), 2 (conditional-binomial chain)
 //   key     = !near << 63 | band << 18 | kclass << 16 | (kclass == 1 ? k : 0) << 9 | min(len, 0x1ff)      (an empty row: key 0)
 //   hash    = fold of (len, k, the ascending hits)
+//   csum    = sum of (hit - band * 64) over the hits inside the window [band * 64, band * 64 + SELL_WIN)  (<= 255 * 254 < 2^16)
+//   tie     = csum << 48 | hash >> 16: rows of equal key are ordered by their CENTRE first, then by content.  At every step of
+//             its walk a tile's 64 lanes then gather neighbouring window slots -- neighbouring slots sit in different LDS banks,
+//             equal slots broadcast -- instead of 64 random ones: measured LDS bank-conflict cycles of K1 50.1 M -> 24.9 M per
+//             launch at config 3 (profiles/r03_*), a model of the bank rule predicts 4.1 -> 2.5 cycles per gather.
 // A FAR row is stored with the hits inside its home window [band * 64, band * 64 + SELL_WIN) first and the others behind them, each part
 // ascending: the stored order of a row's hits is the order every kernel and the oracle add its weights in.
 // A tile of the sliced-ELL stream never crosses a (near, band) boundary.  Near tiles: all hits fall into ONE 255-wide LDS window

@@ -17,6 +17,7 @@ namespace mmg {
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 template <bool B> struct BoolTag { static constexpr bool value = B; };
+template <int K> struct IntTag { static constexpr int value = K; };
 
 // A tile's block seen through a raw buffer descriptor of exactly its size (64 length bytes + ng groups of 256 bytes).  The sampler and
 // EM kernels request NGC groups per tile whatever its ng (loads retire in order and are waited for by count, so the number issued
@@ -164,7 +165,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
     __shared__ __attribute__((aligned(16))) double s_mu[WIN + 1]; // [WIN] stays 0.0: what pad slots read
     // REP replicas of the counts (lane l adds to replica l % REP) were tried against same-address serialisation of the LDS
     // atomics: with one atomic per ROW they only cost (0.433 ms with 1, 0.445 / 0.455 / 0.473 with 2 / 4 / 8 at cfg 3)
-    __shared__ int32_t s_cnt[REP * (WIN + 1)];
+    // counts at the stride of the weights (slot i at byte 8 i, the upper word unused): the offset that gathered a weight addresses
+    // its count, no shift
+    __shared__ int32_t s_cnt[REP * 2 * (WIN + 1)];
     const uint32_t lane = threadIdx.x;
 
     const uint64_t t_begin = chunk_tile[blockIdx.x], t_end = chunk_tile[blockIdx.x + 1];
@@ -173,15 +176,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
     const uint32_t nt = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(t_end - t_begin));
     const SellTile *__restrict__ T = tiles + t_begin;
 
-    for (int i = lane; i < REP * (WIN + 1); i += 64) s_cnt[i] = 0;
-    const uint32_t rep_off = (lane % REP) * (uint32_t)((WIN + 1) * 4);
+    for (int i = lane; i < REP * 2 * (WIN + 1); i += 64) s_cnt[i] = 0;
+    const uint32_t rep_off = (lane % REP) * (uint32_t)((WIN + 1) * 8);
     if (lane == 0) s_mu[WIN] = 0.0;
 
     auto flush_window = [&](uint32_t base) {
         for (int i = lane; i < WIN; i += 64) {
             int32_t v = 0;
 #pragma unroll
-            for (int r = 0; r < REP; ++r) { v += s_cnt[r * (WIN + 1) + i]; s_cnt[r * (WIN + 1) + i] = 0; }
+            for (int r = 0; r < REP; ++r) { v += s_cnt[2 * (r * (WIN + 1) + i)]; s_cnt[2 * (r * (WIN + 1) + i)] = 0; }
             if (v) global_count_add(gcnt, base + (uint32_t)i, v);
         }
     };
@@ -193,10 +196,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
     };
     auto wo = [&](uint32_t off) { return *(const double *)((const char *)s_mu + off); }; // off = window index * 8
     // byte k of a group word as an LDS byte offset
-#define SELL_OFF0(v) (((v) & 0xffu) << 3)
-#define SELL_OFF1(v) (((v) >> 5) & 0x7f8u)
-#define SELL_OFF2(v) (((v) >> 13) & 0x7f8u)
-#define SELL_OFF3(v) (((v) >> 21) & 0x7f8u)
+    // one instruction per byte (SDWA byte select + shift); written out because the compiler turns the first byte into shift + mask
+    const uint32_t three = 3u;
+    auto sdwa_off = [&](uint32_t v, auto sel_tag) -> uint32_t {
+        constexpr int K = decltype(sel_tag)::value;
+        uint32_t o;
+        if (K == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(o) : "v"(three), "v"(v));
+        else if (K == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(o) : "v"(three), "v"(v));
+        else if (K == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(o) : "v"(three), "v"(v));
+        else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(o) : "v"(three), "v"(v));
+        return o;
+    };
+#define SELL_OFF0(v) sdwa_off(v, IntTag<0>())
+#define SELL_OFF1(v) sdwa_off(v, IntTag<1>())
+#define SELL_OFF2(v) sdwa_off(v, IntTag<2>())
+#define SELL_OFF3(v) sdwa_off(v, IntTag<3>())
 
     // The cached groups and the prefix sums are NAMED registers (macro-expanded), not arrays: a select chain over an
     // array that a loop once indexed is turned back into a dynamic index by the optimiser, and the array lands in scratch.
@@ -300,7 +314,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
             farp = (const uint32_t *)(fb + 64) + lane;
             for (uint32_t f = 0; f < Lf; ++f) t += gmu[farp[(size_t)f * 64]];
         }
-        if (L + Lf == 0) return;
+        if (HAS_K && L + Lf == 0) return; // (without multiplicities an empty row falls out of the draw's rare path: one test less per tile)
         uint32_t farc = 0; // the transcript of a pick from the far list (draw() then returns FAR_PICK)
         constexpr uint32_t FAR_PICK = 0xffffffffu;
         // offsets of group g of this lane's row
@@ -318,7 +332,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
         auto off_of = [&](uint32_t j) -> uint32_t { return ((group_of(j >> 2) >> (8u * (j & 3u))) & 0xffu) << 3; };
         auto add = [&](uint32_t off, int32_t x) {
             if (FAR && off == FAR_PICK) global_count_add(gcnt, farc, x);
-            else atomicAdd((int32_t *)((char *)s_cnt + rep_off + (off >> 1)), x);
+            else atomicAdd((int32_t *)((char *)s_cnt + rep_off + off), x);
         };
         const uint32_t kk = HAS_K ? bf.kk : 1u;
         if (HAS_K && kk == 0) return;
@@ -327,24 +341,66 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
         const bool degenerate = !(t > 0.0) || !(t < __builtin_huge_val());
         const uint64_t row_id = a.row_id_base + d.r0 + lane;
         // one categorical draw: the window byte offset of the selected hit (allocate_row's pick + col)
-        auto draw = [&](double u) -> uint32_t {
-            const double target = u * t;
-            // first cached boundary the target falls below (prefix sums never decrease): one descending sweep of
-            // compares that carries the group's offsets and the prefix before it along
-            const bool hit = target < P7; // the boundaries never decrease: some boundary exceeds the target iff the last one does
-            uint32_t v = 0;
-            double acc = 0.0;
-#define SELL_FIND(i, prev) { const bool c = target < P##i; v = c ? bf.g##i : v; acc = c ? (prev) : acc; asm("" : "+v"(v), "+v"(acc)); }
-            SELL_FIND(7, P6) SELL_FIND(6, P5) SELL_FIND(5, P4) SELL_FIND(4, P3) SELL_FIND(3, P2) SELL_FIND(2, P1) SELL_FIND(1, P0) SELL_FIND(0, 0.0)
-#undef SELL_FIND
-            // resolved inside the group without a branch; lanes without a hit (below) read slot 0 and are overridden
+        const double ts = t * 0x1p-32, hs = ts * 0.5; // draw_target (mmg_math.h): the target of word x is fma(x, ts, hs)
+        // one categorical draw from the random word x: the window byte offset of the selected hit (allocate_row's pick + col)
+        auto draw = [&](uint32_t x) -> uint32_t {
+            const double target = draw_target(x, ts, hs);
+            // First cached boundary above the target.  The boundaries never decrease, so the lanes whose target lies below boundary
+            // i are a subset of those below boundary i + 1: v_cmpx narrows EXEC boundary by boundary, and plain moves under the
+            // narrowed mask leave every lane with the words of the FIRST boundary above its target -- three instructions per
+            // boundary (compare, 32-bit move, 64-bit move), no select (a v_cndmask_b32 that reads VCC costs 23 clocks on gfx950
+            // unless it issues right behind the compare that wrote it: tools/issue_bench.hip).  Boundaries past the tile's last
+            // group repeat the total: the sweep is entered at the last group (ng is uniform, one scalar branch).
+            uint32_t v;
+            double acc;
+            {
+                uint64_t sv, tm;
+#define SELL_STEP(i, prev) "v_cmpx_lt_f64_e64 %[tm], %[t], %[p" #i "]\n\t" "v_mov_b32 %[v], %[g" #i "]\n\t" "v_mov_b64 %[acc], " prev "\n\t"
+                asm volatile("s_mov_b64 %[sv], exec\n\t"
+                             "v_mov_b32 %[v], 0\n\t"
+                             "v_mov_b64 %[acc], 0\n\t"
+                             "s_cmp_ge_u32 %[ng], 8\n\t" "s_cbranch_scc1 .Lsell_b7_%=\n\t"
+                             "s_cmp_eq_u32 %[ng], 7\n\t" "s_cbranch_scc1 .Lsell_b6_%=\n\t"
+                             "s_cmp_eq_u32 %[ng], 6\n\t" "s_cbranch_scc1 .Lsell_b5_%=\n\t"
+                             "s_cmp_eq_u32 %[ng], 5\n\t" "s_cbranch_scc1 .Lsell_b4_%=\n\t"
+                             "s_branch .Lsell_b3_%=\n"
+                             ".Lsell_b7_%=:\n\t" SELL_STEP(7, "%[p6]")
+                             ".Lsell_b6_%=:\n\t" SELL_STEP(6, "%[p5]")
+                             ".Lsell_b5_%=:\n\t" SELL_STEP(5, "%[p4]")
+                             ".Lsell_b4_%=:\n\t" SELL_STEP(4, "%[p3]")
+                             ".Lsell_b3_%=:\n\t" SELL_STEP(3, "%[p2]") SELL_STEP(2, "%[p1]") SELL_STEP(1, "%[p0]") SELL_STEP(0, "0")
+                             "s_mov_b64 exec, %[sv]"
+                             : [v] "=&v"(v), [acc] "=&v"(acc), [sv] "=&s"(sv), [tm] "=&s"(tm)
+                             : [t] "v"(target), [ng] "s"(ng), [p0] "v"(P0), [p1] "v"(P1), [p2] "v"(P2), [p3] "v"(P3), [p4] "v"(P4), [p5] "v"(P5),
+                               [p6] "v"(P6), [p7] "v"(P7), [g0] "v"(bf.g0), [g1] "v"(bf.g1), [g2] "v"(bf.g2), [g3] "v"(bf.g3), [g4] "v"(bf.g4),
+                               [g5] "v"(bf.g5), [g6] "v"(bf.g6), [g7] "v"(bf.g7)
+                             : "scc");
+#undef SELL_STEP
+            }
+            // a stored group word is never 0 (four ascending offsets, pads 255): v == 0 <=> no boundary lies above the target
+            const bool hit = v != 0u;
+            // resolved inside the group without a branch: the three gathers go out together, the same narrowing picks the hit;
+            // lanes without a hit (below) read slot 0 and are overridden
             const uint32_t o0 = SELL_OFF0(v), o1 = SELL_OFF1(v), o2 = SELL_OFF2(v), o3 = SELL_OFF3(v);
-            const double p0 = acc + wo(o0), p1 = p0 + wo(o1), p2 = p1 + wo(o2);
-            uint32_t sel = target < p0 ? o0 : (target < p1 ? o1 : (target < p2 ? o2 : o3));
-            if (!hit) { // rare: a degenerate total (0, inf, NaN never compare below anything), a row of more than 32 hits, rounding
-                if (degenerate) {
+            double w0 = wo(o0), w1 = wo(o1), w2 = wo(o2);
+            asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2)); // all three requested before the first is waited for
+            const double p0 = acc + w0, p1 = p0 + w1, p2 = p1 + w2;
+            uint32_t sel = o3;
+            {
+                uint64_t sv, tm;
+                asm volatile("s_mov_b64 %[sv], exec\n\t"
+                             "v_cmpx_lt_f64_e64 %[tm], %[t], %[p2]\n\t" "v_mov_b32 %[sel], %[o2]\n\t"
+                             "v_cmpx_lt_f64_e64 %[tm], %[t], %[p1]\n\t" "v_mov_b32 %[sel], %[o1]\n\t"
+                             "v_cmpx_lt_f64_e64 %[tm], %[t], %[p0]\n\t" "v_mov_b32 %[sel], %[o0]\n\t"
+                             "s_mov_b64 exec, %[sv]"
+                             : [sel] "+&v"(sel), [sv] "=&s"(sv), [tm] "=&s"(tm)
+                             : [t] "v"(target), [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [o0] "v"(o0), [o1] "v"(o1), [o2] "v"(o2));
+            }
+            if (!hit) { // rare: an empty row, a degenerate total (0, inf, NaN never compare below anything), a row of more than 32 hits, rounding
+                if (L + Lf == 0) sel = (uint32_t)WIN * 8u; // no row in this lane: the count of the pad slot, which is never flushed
+                else if (degenerate) {
                     const uint32_t Lt = L + Lf;
-                    uint32_t j = (uint32_t)(u * (double)Lt);
+                    uint32_t j = (uint32_t)(u32_unit(x) * (double)Lt);
                     j = j < Lt ? j : Lt - 1;
                     if (!FAR || j < L) sel = off_of(j);
                     else { farc = farp[(size_t)(j - L) * 64]; sel = FAR_PICK; }
@@ -372,12 +428,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
             }
             return sel;
         };
-        if (!HAS_K) { add(draw(u32_unit(xrow)), 1); return; }
+        if (!HAS_K) { add(draw(xrow), 1); return; }
         if (kk <= K_SMALL) {
             Stream2 s(a.seed, a.chain, TAG_ROW, row_id, a.iter);
             {
 #pragma unroll 1
-                for (uint32_t dd = 0; dd < kk; ++dd) add(draw(s.next()), 1);
+                for (uint32_t dd = 0; dd < kk; ++dd) add(draw(s.next_word()), 1);
             }
             return;
         }
@@ -412,7 +468,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
             const uint32_t L = (uint32_t)((uint64_t)row_ptr[d.r0 + lane + 1] - st);
             auto add = [&](uint32_t col, int32_t x) {
                 const uint32_t dd = col - wbase;
-                if (dd < (uint32_t)WIN) atomicAdd(&s_cnt[dd], x);
+                if (dd < (uint32_t)WIN) atomicAdd(&s_cnt[2 * dd], x);
                 else global_count_add(gcnt, col, x);
             };
             RowViewGlobalWin<WIN> v{col_idx + st, L, wbase, s_mu, gmu};
@@ -426,7 +482,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
             const uint32_t wbase = d.wbase, Ln = blk[lane];
             auto add = [&](uint32_t col, int32_t x) {
                 const uint32_t dd = col - wbase;
-                if (dd < (uint32_t)WIN) atomicAdd(&s_cnt[dd], x);
+                if (dd < (uint32_t)WIN) atomicAdd(&s_cnt[2 * dd], x);
                 else global_count_add(gcnt, col, x);
             };
             const RowViewFarTile v{(const uint32_t *)(blk + 64) + lane, (const uint32_t *)(fb + 64) + lane, Ln, Ln + fb[lane], wbase, s_mu, gmu};
@@ -452,27 +508,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
 
     SellTile none;
     none.off16 = 0; none.r0 = 0; none.wbase = 0; none.meta = sell_meta(0, 0, SELL_EMPTY);
-    // past the end of the range: the last descriptor re-read (one unconditional scalar load per tile) and marked empty
     auto tile_at = [&](uint32_t i) {
         SellTile d = T[min(i, nt - 1u)];
         d.meta = i < nt ? d.meta : none.meta;
         return d;
     };
-
     SellTile dA = tile_at(0), dB = tile_at(1);
-    Buf bufA, bufB; // A: even tiles of the range, B: odd tiles
-    // the window first: its loads are waited for to the last one, which must not include the two blocks requested below
-    // (the loop is entered with A's and B's loads in flight, A's older -- exactly the state its back edge arrives in)
+    Buf bufA, bufB;
     load_window(dA.wbase);
     uint32_t cur_base = dA.wbase;
     __syncthreads();
     issue(dA, bufA);
     issue(dB, bufB);
     for (uint32_t i = 0; i < nt; i += 2) {
-        const SellTile nA = tile_at(i + 2), nB = tile_at(i + 3); // scalar loads: in flight while A and B are walked
+        const SellTile nA = tile_at(i + 2), nB = tile_at(i + 3);
         if (!HAS_K) pair_rng(dA, dB);
         process(dA, cur_base, nA, bufA, 0);
-        process(dB, cur_base, nB, bufB, 1); // past the end of the range dB is the empty tile: same loads, no walk
+        process(dB, cur_base, nB, bufB, 1);
         dA = nA;
         dB = nB;
     }

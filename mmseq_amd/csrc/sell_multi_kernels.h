@@ -21,7 +21,9 @@ __global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict
     constexpr int WIN = (int)SELL_WIN;
     constexpr int SH = NCH == 2 ? 4 : 5;                       // log2 of the bytes per window entry
     __shared__ __attribute__((aligned(16))) double s_mu[(WIN + 1) * NCH]; // entry [WIN] stays 0.0 for every chain: what pad slots read
-    __shared__ int32_t s_cnt[NCH * (WIN + 1)];                 // [chain][index]
+    // counts laid out like the weights, [index][chain] at 8 bytes per chain (upper word unused): the offset that gathered a hit's
+    // weights, plus 8 c, addresses chain c's count of it -- no address arithmetic per pick
+    __shared__ int32_t s_cnt[2 * NCH * (WIN + 1)];
     const uint32_t lane = threadIdx.x;
 
     const uint64_t t_begin = chunk_tile[blockIdx.x], t_end = chunk_tile[blockIdx.x + 1];
@@ -29,15 +31,15 @@ __global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict
     const uint32_t nt = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(t_end - t_begin));
     const SellTile *__restrict__ T = tiles + t_begin;
 
-    for (int i = lane; i < NCH * (WIN + 1); i += 64) s_cnt[i] = 0;
+    for (int i = lane; i < 2 * NCH * (WIN + 1); i += 64) s_cnt[i] = 0;
     if (lane < NCH) s_mu[WIN * NCH + lane] = 0.0;
 
     auto flush_window = [&](uint32_t base) {
         for (int i = lane; i < WIN; i += 64) {
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                const int32_t v = s_cnt[c * (WIN + 1) + i];
-                s_cnt[c * (WIN + 1) + i] = 0;
+                const int32_t v = s_cnt[2 * (i * NCH + c)];
+                s_cnt[2 * (i * NCH + c)] = 0;
                 if (v) global_count_add(gcnt + (size_t)c * a.n, base + (uint32_t)i, v);
             }
         }
@@ -50,10 +52,20 @@ __global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict
         }
     };
     // byte k of a group word as the LDS byte offset of the window entry (all chains)
-#define SM_OFF0(v) (((v) & 0xffu) << SH)
-#define SM_OFF1(v) ((((v) >> 8) & 0xffu) << SH)
-#define SM_OFF2(v) ((((v) >> 16) & 0xffu) << SH)
-#define SM_OFF3(v) (((v) >> 24) << SH)
+    const uint32_t shv = (uint32_t)SH;
+    auto sdwa_off = [&](uint32_t v, auto sel_tag) -> uint32_t { // one instruction per byte, as in k_sample_sell
+        constexpr int K = decltype(sel_tag)::value;
+        uint32_t o;
+        if (K == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(o) : "v"(shv), "v"(v));
+        else if (K == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(o) : "v"(shv), "v"(v));
+        else if (K == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(o) : "v"(shv), "v"(v));
+        else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(o) : "v"(shv), "v"(v));
+        return o;
+    };
+#define SM_OFF0(v) sdwa_off(v, IntTag<0>())
+#define SM_OFF1(v) sdwa_off(v, IntTag<1>())
+#define SM_OFF2(v) sdwa_off(v, IntTag<2>())
+#define SM_OFF3(v) sdwa_off(v, IntTag<3>())
     struct W { double c[NCH]; };
     auto wo = [&](uint32_t off) {
         W r;
@@ -137,7 +149,6 @@ __global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict
 #pragma unroll
             for (int c = 0; c < NCH; ++c) { t[c] += w0.c[c]; t[c] += w1.c[c]; t[c] += w2.c[c]; t[c] += w3.c[c]; }
         }
-        if (L == 0) return;
         auto group_of = [&](uint32_t g) -> uint32_t {
             uint32_t r = bf.g0;
             asm("" : "+v"(r));
@@ -152,25 +163,58 @@ __global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict
         for (int c = 0; c < NCH; ++c) {
             const double tc = t[c];
             const bool degenerate = !(tc > 0.0) || !(tc < __builtin_huge_val());
-            const double u = u32_unit(which ? xrowB[c] : xrowA[c]);
-            const double target = u * tc;
-            const bool hit = target < P7[c]; // the boundaries never decrease
-            uint32_t v = 0;
-            double acc = 0.0;
-#define SM_FIND(i, prev) { const bool cc = target < P##i[c]; v = cc ? bf.g##i : v; acc = cc ? (prev) : acc; asm("" : "+v"(v), "+v"(acc)); }
-            SM_FIND(7, P6[c]) SM_FIND(6, P5[c]) SM_FIND(5, P4[c]) SM_FIND(4, P3[c]) SM_FIND(3, P2[c]) SM_FIND(2, P1[c]) SM_FIND(1, P0[c]) SM_FIND(0, 0.0)
-#undef SM_FIND
+            const uint32_t x = which ? xrowB[c] : xrowA[c];
+            const double ts = tc * 0x1p-32, hs = ts * 0.5;
+            const double target = draw_target(x, ts, hs); // mmg_math.h
+            // v_cmpx narrowing, entered at the tile's last group, as in k_sample_sell (sell_kernels.h: draw)
+            uint32_t v;
+            double acc;
+            {
+                uint64_t sv, tm;
+#define SM_STEP(i, prev) "v_cmpx_lt_f64_e64 %[tm], %[t], %[p" #i "]\n\t" "v_mov_b32 %[v], %[g" #i "]\n\t" "v_mov_b64 %[acc], " prev "\n\t"
+                asm volatile("s_mov_b64 %[sv], exec\n\t"
+                             "v_mov_b32 %[v], 0\n\t"
+                             "v_mov_b64 %[acc], 0\n\t"
+                             "s_cmp_ge_u32 %[ng], 8\n\t" "s_cbranch_scc1 .Lsm_b7_%=\n\t"
+                             "s_cmp_eq_u32 %[ng], 7\n\t" "s_cbranch_scc1 .Lsm_b6_%=\n\t"
+                             "s_cmp_eq_u32 %[ng], 6\n\t" "s_cbranch_scc1 .Lsm_b5_%=\n\t"
+                             "s_cmp_eq_u32 %[ng], 5\n\t" "s_cbranch_scc1 .Lsm_b4_%=\n\t"
+                             "s_branch .Lsm_b3_%=\n"
+                             ".Lsm_b7_%=:\n\t" SM_STEP(7, "%[p6]")
+                             ".Lsm_b6_%=:\n\t" SM_STEP(6, "%[p5]")
+                             ".Lsm_b5_%=:\n\t" SM_STEP(5, "%[p4]")
+                             ".Lsm_b4_%=:\n\t" SM_STEP(4, "%[p3]")
+                             ".Lsm_b3_%=:\n\t" SM_STEP(3, "%[p2]") SM_STEP(2, "%[p1]") SM_STEP(1, "%[p0]") SM_STEP(0, "0")
+                             "s_mov_b64 exec, %[sv]"
+                             : [v] "=&v"(v), [acc] "=&v"(acc), [sv] "=&s"(sv), [tm] "=&s"(tm)
+                             : [t] "v"(target), [ng] "s"(ng), [p0] "v"(P0[c]), [p1] "v"(P1[c]), [p2] "v"(P2[c]), [p3] "v"(P3[c]), [p4] "v"(P4[c]),
+                               [p5] "v"(P5[c]), [p6] "v"(P6[c]), [p7] "v"(P7[c]), [g0] "v"(bf.g0), [g1] "v"(bf.g1), [g2] "v"(bf.g2), [g3] "v"(bf.g3),
+                               [g4] "v"(bf.g4), [g5] "v"(bf.g5), [g6] "v"(bf.g6), [g7] "v"(bf.g7)
+                             : "scc");
+#undef SM_STEP
+            }
+            const bool hit = v != 0u; // a stored group word is never 0
             const double *m = (const double *)((const char *)s_mu + c * 8);
             uint32_t sel; // LDS byte offset of the selected window entry
             {
                 const uint32_t o0 = SM_OFF0(v), o1 = SM_OFF1(v), o2 = SM_OFF2(v), o3 = SM_OFF3(v);
-                const double p0 = acc + *(const double *)((const char *)m + o0), p1 = p0 + *(const double *)((const char *)m + o1),
-                             p2 = p1 + *(const double *)((const char *)m + o2);
-                sel = target < p0 ? o0 : (target < p1 ? o1 : (target < p2 ? o2 : o3));
+                double w0 = *(const double *)((const char *)m + o0), w1 = *(const double *)((const char *)m + o1), w2 = *(const double *)((const char *)m + o2);
+                asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2)); // all three requested before the first is waited for
+                const double p0 = acc + w0, p1 = p0 + w1, p2 = p1 + w2;
+                sel = o3;
+                uint64_t sv, tm;
+                asm volatile("s_mov_b64 %[sv], exec\n\t"
+                             "v_cmpx_lt_f64_e64 %[tm], %[t], %[p2]\n\t" "v_mov_b32 %[sel], %[o2]\n\t"
+                             "v_cmpx_lt_f64_e64 %[tm], %[t], %[p1]\n\t" "v_mov_b32 %[sel], %[o1]\n\t"
+                             "v_cmpx_lt_f64_e64 %[tm], %[t], %[p0]\n\t" "v_mov_b32 %[sel], %[o0]\n\t"
+                             "s_mov_b64 exec, %[sv]"
+                             : [sel] "+&v"(sel), [sv] "=&s"(sv), [tm] "=&s"(tm)
+                             : [t] "v"(target), [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [o0] "v"(o0), [o1] "v"(o1), [o2] "v"(o2));
             }
-            if (!hit) { // rare: degenerate total, a row of more than 32 hits, rounding
-                if (degenerate) {
-                    const uint32_t j = (uint32_t)(u * (double)L);
+            if (!hit) { // rare: an empty row, a degenerate total, a row of more than 32 hits, rounding
+                if (L == 0) sel = (uint32_t)WIN << SH; // no row in this lane: the count of the pad slot, which is never flushed
+                else if (degenerate) {
+                    const uint32_t j = (uint32_t)(u32_unit(x) * (double)L);
                     sel = off_of(j < L ? j : L - 1);
                 } else {
                     double accl = P7[c];
@@ -187,7 +231,7 @@ __global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict
                     if (!found) sel = off_of(L - 1); // rounding left target >= total: the last real hit
                 }
             }
-            atomicAdd((int32_t *)((char *)s_cnt + c * (WIN + 1) * 4 + (sel >> (SH - 2))), 1);
+            atomicAdd((int32_t *)((char *)s_cnt + c * 8 + sel), 1);
         }
     };
 #undef SM_GROUPS
@@ -230,7 +274,7 @@ __global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict
                 int32_t *gc = gcnt + (size_t)c * a.n;
                 auto add = [&](uint32_t col, int32_t x) {
                     const uint32_t dd = col - wbase;
-                    if (dd < (uint32_t)WIN) atomicAdd(&s_cnt[c * (WIN + 1) + dd], x);
+                    if (dd < (uint32_t)WIN) atomicAdd(&s_cnt[2 * (dd * NCH + c)], x);
                     else global_count_add(gc, col, x);
                 };
                 RowViewMulti v{col_idx + st, L, wbase, a.n, s_mu + c, gmu + (size_t)c * a.n};

@@ -283,10 +283,14 @@ LAYOUT_NEAR_SPAN = 240
 K_SMALL = 64
 
 
+SELL_WIN = 255  # transcripts per LDS window (mmg_types.h)
+
+
 def row_keys(row_ptr, col_idx, k=None):
-    """(key, hash) per row: key = !near << 63 | band << 18 | kclass << 16 | (kclass == 1 ? k : 0) << 9 | min(len, 0x1ff) (0 for an empty row), band = the band
+    """(key, tie) per row: key = !near << 63 | band << 18 | kclass << 16 | (kclass == 1 ? k : 0) << 9 | min(len, 0x1ff) (0 for an empty row), band = the band
     of the smallest hit for a near row, the home band (one below the band of hit[(len - 1) // 2]) for a far row;
-    hash = fold of (len, k, hits in stored order).  Spec: mmseq_amd/csrc/mmg_types.h."""
+    tie = csum << 48 | hash >> 16, hash = fold of (len, k, hits in stored order), csum = sum of (hit - 64 * band) over the hits inside
+    [64 * band, 64 * band + SELL_WIN).  Spec: mmseq_amd/csrc/mmg_types.h."""
     rp = np.asarray(row_ptr).astype(np.int64)
     col = np.asarray(col_idx, np.uint32)
     L = np.diff(rp)
@@ -316,7 +320,18 @@ def row_keys(row_ptr, col_idx, k=None):
             c = col[rp[sel] + j].astype(np.uint64)
             hj = (h[sel] ^ c) * M
             h[sel] = hj ^ (hj >> np.uint64(32))
-    return key, h
+    # tie order inside a key (ABI 4): the CENTRE of the row first -- the sum of its hits' offsets in the window its key names
+    # (hits outside that window count 0) -- then the content hash: tie = csum << 48 | hash >> 16.  Rows of one tile then gather
+    # neighbouring window slots at every step of the walk (fewer LDS bank conflicts, mmg_types.h).
+    cs = np.zeros(m, np.uint64)
+    if col.size:
+        wbase = (((key >> np.uint64(18)) & np.uint64((1 << 45) - 1)) << np.uint64(LAYOUT_BAND_SHIFT)).astype(np.uint32)
+        rid = np.repeat(np.arange(m, dtype=np.int64), L)
+        with np.errstate(over="ignore"):
+            d = (col - wbase[rid]).astype(np.uint32)        # u32 wrap-around: hits below the window are outside
+        cs = np.bincount(rid, weights=np.where(d < SELL_WIN, d, 0).astype(np.float64), minlength=m).astype(np.uint64)
+    tie = (cs << np.uint64(48)) | (h >> np.uint64(16))
+    return key, tie
 
 
 def permute_rows(row_ptr, col_idx, k, perm):
@@ -327,8 +342,6 @@ def permute_rows(row_ptr, col_idx, k, perm):
     idx = np.repeat(rp[:-1][perm] - new_rp[:-1].astype(np.int64), lens) + np.arange(int(lens.sum()), dtype=np.int64)
     return new_rp, np.ascontiguousarray(np.asarray(col_idx)[idx]), (None if k is None else np.ascontiguousarray(np.asarray(k)[perm]))
 
-
-SELL_WIN = 255  # transcripts per LDS window (mmg_types.h)
 
 
 def sort_hits(row_ptr, col_idx):

@@ -145,13 +145,15 @@ static inline orc_stream2 stream2_make(uint64_t seed, uint32_t chain, uint32_t t
     return s;
 }
 
-static inline double stream2_next(orc_stream2 *s)
+static inline uint32_t stream2_next_word(orc_stream2 *s)
 {
     uint32_t a = s->c0, b = s->c1;
     philox2x32_10(&a, &b, s->key + s->blk * 0xBB67AE85u);
     s->blk++;
-    return ((double)(s->half ? b : a) + 0.5) * 0x1p-32;
+    return s->half ? b : a;
 }
+static inline double u32_unit(uint32_t x) { return ((double)x + 0.5) * 0x1p-32; }
+static inline double stream2_next(orc_stream2 *s) { return u32_unit(stream2_next_word(s)); }
 
 /* one Philox block = one pair of uniforms */
 static inline void stream_pair(orc_stream *s, double *ua, double *ub)
@@ -397,13 +399,16 @@ uint32_t orc_binomial_keyed(uint64_t seed, uint64_t id, uint32_t n, double p)
 /* ------------------------------------------------------------------------- */
 /* Keyed Gibbs kernels (the spec the HIP kernels implement)                    */
 /* ------------------------------------------------------------------------- */
-static inline uint32_t pick_index(const uint32_t *cols, uint32_t L, const double *mu, double total, double u)
+/* One categorical draw from the 32-bit word x (mmg_math.h: draw_target): the target is (x + 1/2) 2^-32 * total rounded ONCE,
+ * computed as fma(x, total 2^-32, total 2^-33); then the first hit whose running sum (stored order) exceeds it. */
+static inline uint32_t pick_index(const uint32_t *cols, uint32_t L, const double *mu, double total, uint32_t x)
 {
     if (!(total > 0.0) || !(total < INFINITY)) { /* degenerate weights: uniform over the hits */
-        uint32_t j = (uint32_t)(u * (double)L);
+        uint32_t j = (uint32_t)(u32_unit(x) * (double)L);
         return j < L ? j : L - 1;
     }
-    double target = u * total, acc = 0.0;
+    const double ts = total * 0x1p-32, hs = ts * 0.5;
+    double target = fma((double)x, ts, hs), acc = 0.0;
     for (uint32_t j = 0; j < L; ++j) {
         acc += mu[cols[j]];
         if (target < acc) return j;
@@ -422,8 +427,8 @@ static void keyed_row_allocate(const uint32_t *cols, uint32_t L, uint32_t k, con
     if (k <= ORC_K_SMALL) {
         orc_stream2 s = stream2_make(seed, chain, ORC_TAG_ROW, row_id, iter);
         for (uint32_t d = 0; d < k; ++d) {
-            double u = stream2_next(&s);
-            cnt[cols[pick_index(cols, L, mu, total, u)]] += 1;
+            uint32_t x = stream2_next_word(&s);
+            cnt[cols[pick_index(cols, L, mu, total, x)]] += 1;
         }
         return;
     }

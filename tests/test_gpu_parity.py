@@ -198,7 +198,7 @@ def test_full_chain_bit_exact(gpu, orc, R, T, avg, kernel):
 
 
 def test_rows_with_multiplicity_bit_exact(gpu, orc):
-    """k > 1 rows: k <= 8 -> repeated categorical draws; k > 8 -> conditional-binomial chain."""
+    """k > 1 rows: k <= 64 (MMG_K_SMALL) -> repeated categorical draws; above -> conditional-binomial chain."""
     p, mu0, _ = _mk(orc, 5000, 400, 5)
     rng = np.random.default_rng(7)
     k = rng.choice([1, 2, 3, 8, 9, 50, 1000, 20000], size=p.m).astype(np.uint32)

@@ -34,7 +34,7 @@ def counters(pass_name):
 
 
 allc = {}
-for p in ("fetch", "write", "sqa", "sqb", "sqc", "sqd"):
+for p in ("fetch", "write", "sqa", "sqb", "sqc", "sqd", "sqe"):
     for k, v in counters(p).items():
         allc.setdefault(k, {}).update(v)
 k1 = [k for k in allc if sub in k]
