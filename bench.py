@@ -352,6 +352,9 @@ def main():
                        dict(name="config 3: 50M x 200k, 8 chains in one GPU", rows=R3, transcripts=T3, avg_hits=H3, chains=8, steps=16, warmup=4),
                        dict(name="50M x 200k with multiplicities (k > 1 on 6.4 % of the rows, up to 36): two launches per sweep", rows=R3, transcripts=T3, avg_hits=H3,
                             multiplicities=True, steps=32),
+                       dict(name="50M x 200k like a real hits file: multiplicities (k > 1 on 6.4 % of the rows) AND 2 % of the rows with a hit anywhere in the "
+                                 "transcriptome, 8 chains in one GPU (pairs over the k = 1 register-path tiles, one launch each for the far and the multiplicity tiles)",
+                            rows=R3, transcripts=T3, avg_hits=H3, multiplicities=True, far_fraction=0.02, chains=8, steps=16, warmup=4),
                        dict(name="50M x 200k, 2 % of the rows with a hit anywhere in the transcriptome", rows=R3, transcripts=T3, avg_hits=H3, far_fraction=0.02, steps=32),
                        dict(name="50M x 200k, 20 % of the rows with a hit anywhere in the transcriptome", rows=R3, transcripts=T3, avg_hits=H3, far_fraction=0.2, steps=24),
                        dict(name="50M x 200k, hits uniform over all transcripts (SURVEY App. D worst case)", rows=R3, transcripts=T3, avg_hits=H3, uniform=True, steps=8, warmup=2),

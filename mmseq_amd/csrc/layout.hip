@@ -208,6 +208,101 @@ hipError_t layout_scan_lens(uint64_t m, const uint32_t *d_len, uint64_t *d_rp, h
     return e;
 }
 
+// ---- step 0 of the canonical layout: rows with a small multiplicity are stored as that many rows of multiplicity 1
+__global__ __launch_bounds__(256) void k_expand_count(uint64_t m, const uint32_t *__restrict__ k, uint32_t *__restrict__ reps, unsigned long long *stats)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= m) return;
+    const uint32_t kk = k[r];
+    const bool ex = kk >= 2u && kk <= K_SMALL;
+    reps[r] = ex ? kk : 1u;
+    if (ex) atomicAdd(&stats[0], 1ull);                    // rows that expand
+    else if (kk != 1u) atomicAdd(&stats[1], 1ull);         // multiplicities that stay (0, or the conditional-binomial class)
+}
+
+__global__ __launch_bounds__(256) void k_expand_rows(uint64_t m, const uint64_t *__restrict__ rp, const uint32_t *__restrict__ k,
+                                                     const uint64_t *__restrict__ first /* m + 1: first stored copy of row r */,
+                                                     uint32_t *__restrict__ len_new, uint32_t *__restrict__ k_new, uint32_t *__restrict__ src)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= m) return;
+    const uint64_t a = first[r], b = first[r + 1];
+    const uint64_t L = rp[r + 1] - rp[r];
+    const uint32_t kk = k[r];
+    for (uint64_t q = a; q < b; ++q) {
+        len_new[q] = (uint32_t)(L < 0xffffffffull ? L : 0xffffffffull);
+        k_new[q] = b - a > 1 ? 1u : kk;
+        src[q] = (uint32_t)r;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_expand_cols(uint64_t m_new, const uint64_t *__restrict__ rp_old, const uint32_t *__restrict__ col_old,
+                                                     const uint32_t *__restrict__ src, const uint64_t *__restrict__ rp_new, uint32_t *__restrict__ col_new)
+{
+    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= m_new) return;
+    const uint64_t s0 = rp_old[src[q]], d0 = rp_new[q], L = rp_new[q + 1] - d0;
+    for (uint64_t j = 0; j < L; ++j) col_new[d0 + j] = col_old[s0 + j];
+}
+
+hipError_t layout_expand_rows(uint64_t *m_io, uint64_t *nnz_io, uint64_t **d_rp, uint32_t **d_col, uint32_t **d_k, size_t col_pad, hipStream_t s)
+{
+    const uint64_t m = *m_io;
+    if (m == 0 || !d_k || !*d_k) return hipSuccess;
+    if (m >= 0xffffffffull) return hipSuccess;           // (the caller rejects such a problem for the canonical layout anyway)
+    uint32_t *reps = nullptr, *len_new = nullptr, *k_new = nullptr, *src = nullptr, *col_new = nullptr;
+    uint64_t *first = nullptr, *rp_new = nullptr;
+    unsigned long long *d_stats = nullptr, stats[2] = {0, 0};
+    hipError_t e = hipSuccess;
+    auto done = [&](hipError_t rc) {
+        for (void *x : {(void *)reps, (void *)len_new, (void *)k_new, (void *)src, (void *)col_new, (void *)first, (void *)rp_new, (void *)d_stats})
+            if (x) (void)hipFree(x);
+        return rc;
+    };
+#define X_TRY(expr) do { e = (expr); if (e != hipSuccess) return done(e); } while (0)
+    X_TRY(hipMalloc((void **)&reps, m * 4));
+    X_TRY(hipMalloc((void **)&d_stats, 16));
+    X_TRY(hipMemsetAsync(d_stats, 0, 16, s));
+    const unsigned g = blocks_of(m);
+    hipLaunchKernelGGL(k_expand_count, dim3(g), dim3(256), 0, s, m, (const uint32_t *)*d_k, reps, d_stats);
+    X_TRY(hipGetLastError());
+    X_TRY(hipMemcpyAsync(stats, d_stats, 16, hipMemcpyDeviceToHost, s));
+    X_TRY(hipStreamSynchronize(s));
+    if (stats[0] == 0) { // nothing to expand; an array of ones is no array
+        if (stats[1] == 0) { (void)hipFree(*d_k); *d_k = nullptr; }
+        return done(hipSuccess);
+    }
+    X_TRY(hipMalloc((void **)&first, (m + 1) * 8));
+    X_TRY(layout_scan_lens(m, reps, first, s));
+    uint64_t m_new = 0;
+    X_TRY(hipMemcpy(&m_new, first + m, 8, hipMemcpyDeviceToHost));
+    if (m_new >= 0xffffffffull) return done(hipErrorInvalidValue); // reported by the caller: too many stored rows for one device
+    X_TRY(hipMalloc((void **)&len_new, m_new * 4));
+    X_TRY(hipMalloc((void **)&k_new, m_new * 4));
+    X_TRY(hipMalloc((void **)&src, m_new * 4));
+    hipLaunchKernelGGL(k_expand_rows, dim3(g), dim3(256), 0, s, m, (const uint64_t *)*d_rp, (const uint32_t *)*d_k, (const uint64_t *)first, len_new, k_new, src);
+    X_TRY(hipGetLastError());
+    X_TRY(hipMalloc((void **)&rp_new, (m_new + 1) * 8));
+    X_TRY(layout_scan_lens(m_new, len_new, rp_new, s));
+    uint64_t nnz_new = 0;
+    X_TRY(hipMemcpy(&nnz_new, rp_new + m_new, 8, hipMemcpyDeviceToHost));
+    X_TRY(hipMalloc((void **)&col_new, (nnz_new + col_pad) * 4));
+    X_TRY(hipMemsetAsync(col_new + nnz_new, 0, col_pad * 4, s));
+    hipLaunchKernelGGL(k_expand_cols, dim3(blocks_of(m_new)), dim3(256), 0, s, m_new, (const uint64_t *)*d_rp, (const uint32_t *)*d_col, (const uint32_t *)src,
+                       (const uint64_t *)rp_new, col_new);
+    X_TRY(hipGetLastError());
+    X_TRY(hipStreamSynchronize(s));
+    (void)hipFree(*d_rp); *d_rp = rp_new; rp_new = nullptr;
+    (void)hipFree(*d_col); *d_col = col_new; col_new = nullptr;
+    (void)hipFree(*d_k);
+    if (stats[1] == 0) *d_k = nullptr;                     // every multiplicity expanded away
+    else { *d_k = k_new; k_new = nullptr; }
+    *m_io = m_new;
+    *nnz_io = nnz_new;
+#undef X_TRY
+    return done(hipSuccess);
+}
+
 static hipError_t sort_pairs(uint64_t m, uint64_t *k_in, uint64_t *k_out, uint32_t *v_in, uint32_t *v_out, hipStream_t s)
 {
     size_t tmp = 0;

@@ -35,8 +35,15 @@ struct mmg_problem {
     uint64_t *d_sell_chunk_k = nullptr;
     int grid_sell_k = 0;
     uint64_t n_hask_tiles = 0;
-    uint64_t *d_sell_chunk_m[2] = {nullptr, nullptr}; // tile ranges of the fused-chain kernels (2 and 4 chains: fewer resident waves)
-    int grid_sell_m[2] = {0, 0};
+    // chains advanced in pairs: k_sample_sell_multi walks the register-path tiles without multiplicities (d_sell_tiles_f; the whole
+    // list when every tile is like that) in its own ranges (2 and 4 chains: fewer resident waves); the other tiles without
+    // multiplicities -- far tiles, CSR-walked tiles -- are a third list (d_sell_tiles_x) that k_sample_sell walks for all the
+    // chains of the sampler in ONE launch (grid.y = chain), and so are the SELL_HASK tiles
+    mmg::SellTile *d_sell_tiles_f = nullptr, *d_sell_tiles_x = nullptr; // f may alias d_sell_tiles / d_sell_tiles_1 (not owned then)
+    bool owns_tiles_f = false;
+    uint64_t *d_sell_chunk_m[2] = {nullptr, nullptr}, *d_sell_chunk_x = nullptr;
+    int grid_sell_m[2] = {0, 0}, grid_sell_x = 0;
+    uint64_t n_x_tiles = 0;
     bool use_sell = false;
     std::vector<uint64_t> h_sell_cum;           // cumulative tile cost, kept for the EM kernel's own ranges
     // CSR tiles of the fallback kernel k_sample (built only when the sliced-ELL stream is not used)

@@ -80,7 +80,7 @@ static void problem_free(mmg_problem *p)
     if (!p) return;
     (void)hipSetDevice(p->device);
     for (void *x : {(void *)p->d_row_ptr, (void *)p->d_col, (void *)p->d_k, (void *)p->d_l, (void *)p->d_int_of_ext, (void *)p->d_ext_of_int,
-                    (void *)p->d_sell, (void *)p->d_sell_tiles, (void *)p->d_sell_chunk, (void *)p->d_sell_chunk_k, (void *)p->d_sell_tiles_1, (void *)p->d_sell_tiles_k, (void *)p->d_sell_chunk_m[0], (void *)p->d_sell_chunk_m[1],
+                    (void *)p->d_sell, (void *)p->d_sell_tiles, (void *)p->d_sell_chunk, (void *)p->d_sell_chunk_k, (void *)p->d_sell_tiles_1, (void *)p->d_sell_tiles_k, (void *)p->d_sell_chunk_m[0], (void *)p->d_sell_chunk_m[1], (void *)(p->owns_tiles_f ? p->d_sell_tiles_f : nullptr), (void *)p->d_sell_tiles_x, (void *)p->d_sell_chunk_x,
                     (void *)p->d_tiles, (void *)p->d_chunk_tile,
                     (void *)p->d_colcnt})
         if (x) (void)hipFree(x);
@@ -306,19 +306,49 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
     }
     HIP_TRY(hipMalloc((void **)&p->d_sell_chunk, chunk.size() * sizeof(uint64_t)));
     HIP_TRY(hipMemcpy(p->d_sell_chunk, chunk.data(), chunk.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-    if (!p->d_k) { // fused-chain kernels: their own (fewer, longer) tile ranges over the same tiles
-        for (int q = 0; q < 2; ++q) {
-            int pc = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, k1_sell_multi_kernel(p->idx64, 2 << q), 64, 0) != hipSuccess || pc < 1) { (void)hipGetLastError(); pc = 8; }
-            if (pc > 32) pc = 32;
-            if (opt(MMG_OPT_SELL_WAVES_PER_CU) >= 1 && opt(MMG_OPT_SELL_WAVES_PER_CU) < pc) pc = opt(MMG_OPT_SELL_WAVES_PER_CU);
-            const uint64_t rq = std::max<uint64_t>(1, std::min<uint64_t>(nt, (uint64_t)p->cu_count * pc));
-            std::vector<uint64_t> cq;
-            weighted_chunks_tapered(p->h_sell_cum, generations(rq), opt(MMG_OPT_SELL_WAVES_PER_CU) >= 1 ? 0 : rq, cq);
-            const uint64_t gq = cq.size() - 1;
-            HIP_TRY(hipMalloc((void **)&p->d_sell_chunk_m[q], cq.size() * sizeof(uint64_t)));
-            HIP_TRY(hipMemcpy(p->d_sell_chunk_m[q], cq.data(), cq.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-            p->grid_sell_m[q] = (int)gq;
+    { // chains in pairs (k_sample_sell_multi): the register-path tiles without multiplicities in their own ranges, the rest apart
+        std::vector<SellTile> sf, sx;
+        std::vector<uint64_t> cf(1, 0), cx(1, 0);
+        for (uint64_t t = 0; t < nt; ++t) {
+            const uint32_t fl = st[t].flags();
+            if (fl & (SELL_HASK | SELL_EMPTY)) continue;
+            const uint64_t c = p->h_sell_cum[t + 1] - p->h_sell_cum[t];
+            if (fl & SELL_FAST) { sf.push_back(st[t]); cf.push_back(cf.back() + c); }
+            else { sx.push_back(st[t]); cx.push_back(cx.back() + c); }
+        }
+        p->n_x_tiles = sx.size();
+        if (!sf.empty()) {
+            if (sf.size() == nt) p->d_sell_tiles_f = p->d_sell_tiles;           // every tile: the list that exists
+            else {
+                HIP_TRY(hipMalloc((void **)&p->d_sell_tiles_f, sf.size() * sizeof(SellTile)));
+                HIP_TRY(hipMemcpy(p->d_sell_tiles_f, sf.data(), sf.size() * sizeof(SellTile), hipMemcpyHostToDevice));
+                p->owns_tiles_f = true;
+                p->device_bytes += sf.size() * sizeof(SellTile);
+            }
+            const uint64_t nf = sf.size();
+            for (int q = 0; q < 2; ++q) {
+                int pc = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, k1_sell_multi_kernel(p->idx64, 2 << q), 64, 0) != hipSuccess || pc < 1) { (void)hipGetLastError(); pc = 8; }
+                if (pc > 32) pc = 32;
+                if (opt(MMG_OPT_SELL_WAVES_PER_CU) >= 1 && opt(MMG_OPT_SELL_WAVES_PER_CU) < pc) pc = opt(MMG_OPT_SELL_WAVES_PER_CU);
+                const uint64_t rq = std::max<uint64_t>(1, std::min<uint64_t>(nf, (uint64_t)p->cu_count * pc));
+                const uint64_t gen = opt(MMG_OPT_SELL_WAVES_PER_CU) >= 1 ? rq : std::min<uint64_t>(nf, rq * std::min<uint64_t>(16, std::max<uint64_t>(1, (nf + rq * 12) / (rq * 24))));
+                std::vector<uint64_t> cq;
+                weighted_chunks_tapered(cf, gen, opt(MMG_OPT_SELL_WAVES_PER_CU) >= 1 ? 0 : rq, cq);
+                HIP_TRY(hipMalloc((void **)&p->d_sell_chunk_m[q], cq.size() * sizeof(uint64_t)));
+                HIP_TRY(hipMemcpy(p->d_sell_chunk_m[q], cq.data(), cq.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+                p->grid_sell_m[q] = (int)(cq.size() - 1);
+            }
+        }
+        if (!sx.empty()) {
+            HIP_TRY(hipMalloc((void **)&p->d_sell_tiles_x, sx.size() * sizeof(SellTile)));
+            HIP_TRY(hipMemcpy(p->d_sell_tiles_x, sx.data(), sx.size() * sizeof(SellTile), hipMemcpyHostToDevice));
+            std::vector<uint64_t> rx;
+            weighted_chunks(cx, std::max<uint64_t>(1, std::min<uint64_t>(sx.size(), resident_grid(false))), rx);
+            HIP_TRY(hipMalloc((void **)&p->d_sell_chunk_x, rx.size() * sizeof(uint64_t)));
+            HIP_TRY(hipMemcpy(p->d_sell_chunk_x, rx.data(), rx.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+            p->grid_sell_x = (int)(rx.size() - 1);
+            p->device_bytes += sx.size() * sizeof(SellTile);
         }
     }
     launch_encode_sell(p->idx64, p->d_row_ptr, p->d_col, p->d_sell_tiles, nt, p->d_sell, 0);
@@ -388,6 +418,13 @@ static int problem_build(mmg_problem *p, uint64_t *d_rp64)
     auto bail = [&](int code) { if (d_key) (void)hipFree(d_key); if (d_rp64) (void)hipFree(d_rp64); return code; };
 #define B_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return bail(fail(MMG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); } while (0)
     std::vector<uint64_t> seg;
+    if (p->m && p->layout == (int)MMG_LAYOUT_CANONICAL && p->d_k) {
+        // a row with 2 <= k <= K_SMALL is stored as k rows with k = 1: identical reads then run on the register path like any
+        // other read, instead of through the multiplicity kernel (mmg_types.h)
+        hipError_t ex = layout_expand_rows(&p->m, &p->nnz, &d_rp64, &p->d_col, &p->d_k, 16, 0);
+        if (ex == hipErrorInvalidValue) return bail(fail(MMG_ERR_ARG, "the canonical layout stores rows with 2 <= k <= 64 as k rows: more than 2^32 stored rows on one device"));
+        B_TRY(ex);
+    }
     if (p->m) {
         B_TRY(hipMalloc((void **)&d_key, p->m * sizeof(uint64_t)));
         if (p->layout == (int)MMG_LAYOUT_CANONICAL) {

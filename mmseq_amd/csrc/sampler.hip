@@ -119,52 +119,71 @@ extern "C" int mmg_sampler_sample(mmg_sampler *s)
         HIP_TRY(hipEventRecord(s->ev_pool[e0], s->cur));
     }
     if (p->m > 0) {
-        for (int c = 0; c < s->cfg.n_chains;) {
-            // chains are advanced in fused pairs where the fused kernel exists (sliced-ELL stream, no multiplicities).  Measured at
-            // config 3 with 8 chains: 3470 chain-iterations/s one chain per launch, 3780 in pairs (111 VGPRs, 4 waves per SIMD),
-            // 2970 in fours (175 VGPRs, 2 waves per SIMD): fours exist for tests and experiments only (MMG_OPT_FUSE_CHAINS).
-            // The fused kernels walk every tile that is not a fast tile from the CSR (24 x a fast tile): left to itself the library
-            // pairs chains only when fewer than 1 in 200 tiles are like that -- k_sample_sell has the far-list path.
-            int fuse = 1;
-            const bool pairs_pay = (p->n_sell_tiles - p->n_fast_tiles) * 200 <= p->n_sell_tiles;
-            if (p->use_sell && !p->d_k && opt(MMG_OPT_FUSE_CHAINS) != 1 && (pairs_pay || opt(MMG_OPT_FUSE_CHAINS) > 1)) {
-                const int cap = opt(MMG_OPT_FUSE_CHAINS) > 0 ? opt(MMG_OPT_FUSE_CHAINS) : 2;
-                if (cap >= 4 && c + 4 <= s->cfg.n_chains && p->grid_sell_m[1] > 0) fuse = 4;
-                else if (cap >= 2 && c + 2 <= s->cfg.n_chains && p->grid_sell_m[0] > 0) fuse = 2;
-            }
+        const int C = s->cfg.n_chains;
+        auto args_of = [&](int c) {
             SampleArgs a;
             a.seed = s->cfg.seed; a.row_id_base = p->row_id_base; a.n = p->n;
             a.chain = (uint32_t)(s->cfg.chain_base + c);
             a.iter = (uint32_t)s->iter;
-            const void *rp = p->d_row_ptr;
-            const uint32_t *ci = p->d_col, *kk = p->d_k;
-            const double *mu = s->d_mu + (size_t)c * p->n;
-            int32_t *cnt = s->d_cnt + (size_t)c * p->n;
-            if (fuse > 1) {
-                const SellTile *ts = p->d_sell_tiles;
-                const uint64_t *cs = p->d_sell_chunk_m[fuse == 4 ? 1 : 0];
-                const uint8_t *ss = p->d_sell;
+            return a;
+        };
+        const void *rp = p->d_row_ptr;
+        const uint32_t *ci = p->d_col, *kk = p->d_k;
+        const uint8_t *ss = p->d_sell;
+        // k_sample_sell over one tile list for chains [c0, c0 + nc): grid.y = chain
+        auto launch_single = [&](const SellTile *ts, const uint64_t *cs, int grid, bool has_k, int c0, int nc) -> int {
+            SampleArgs a = args_of(c0);
+            const double *mu = s->d_mu + (size_t)c0 * p->n;
+            int32_t *cnt = s->d_cnt + (size_t)c0 * p->n;
+            void *kargs[] = {(void *)&rp, (void *)&ci, (void *)&kk, (void *)&ts, (void *)&cs, (void *)&mu, (void *)&ss, (void *)&cnt, (void *)&a};
+            HIP_TRY(hipLaunchKernel(k1_sell_kernel(p->idx64, has_k), dim3(grid, nc), dim3(64), kargs, 0, s->cur));
+            return MMG_OK;
+        };
+        if (p->use_sell) {
+            // Chains are advanced in fused pairs over the register-path tiles without multiplicities (measured at config 3 with 8
+            // chains: 3470 chain-iterations/s one chain per launch, 3780 in pairs at 4 waves per SIMD, 2970 in fours at 2 waves
+            // per SIMD: fours exist for tests and experiments only, MMG_OPT_FUSE_CHAINS).  The tiles that are neither -- far tiles,
+            // CSR-walked tiles, tiles holding rows with multiplicities: what every real hits file has -- take the single-chain
+            // kernel, one launch per kind for all the paired chains together.
+            const int want = opt(MMG_OPT_FUSE_CHAINS);
+            int fuse = want == 1 ? 1 : (want >= 4 ? 4 : 2);
+            if (fuse == 4 && p->grid_sell_m[1] <= 0) fuse = 2;
+            if (p->grid_sell_m[0] <= 0 || !p->d_sell_tiles_f) fuse = 1;
+            const int n_fused = fuse > 1 ? (C / fuse) * fuse : 0, n_rest = fuse == 4 ? ((C - n_fused) / 2) * 2 : 0;
+            for (int c = 0; c < n_fused + n_rest; ) {
+                const int f = c < n_fused ? fuse : 2;
+                SampleArgs a = args_of(c);
+                const SellTile *ts = p->d_sell_tiles_f;
+                const uint64_t *cs = p->d_sell_chunk_m[f == 4 ? 1 : 0];
+                const double *mu = s->d_mu + (size_t)c * p->n;
+                int32_t *cnt = s->d_cnt + (size_t)c * p->n;
                 void *kargs[] = {(void *)&rp, (void *)&ci, (void *)&ts, (void *)&cs, (void *)&mu, (void *)&ss, (void *)&cnt, (void *)&a};
-                HIP_TRY(hipLaunchKernel(k1_sell_multi_kernel(p->idx64, fuse), dim3(p->grid_sell_m[fuse == 4 ? 1 : 0]), dim3(64), kargs, 0, s->cur));
-            } else if (p->use_sell) {
-                const SellTile *ts = p->grid_sell_k > 0 ? p->d_sell_tiles_1 : p->d_sell_tiles;
-                const uint64_t *cs = p->d_sell_chunk;
-                const uint8_t *ss = p->d_sell;
-                void *kargs[] = {(void *)&rp, (void *)&ci, (void *)&kk, (void *)&ts, (void *)&cs, (void *)&mu, (void *)&ss, (void *)&cnt, (void *)&a};
-                // every tile whose rows all have k = 1 (all of them without a k array) ...
-                HIP_TRY(hipLaunchKernel(k1_sell_kernel(p->idx64, false), dim3(p->grid_sell), dim3(64), kargs, 0, s->cur));
-                if (p->grid_sell_k > 0) { // ... then the tiles that hold collapsed identical reads, in ranges balanced by their cost
-                    ts = p->d_sell_tiles_k;
-                    cs = p->d_sell_chunk_k;
-                    HIP_TRY(hipLaunchKernel(k1_sell_kernel(p->idx64, true), dim3(p->grid_sell_k), dim3(64), kargs, 0, s->cur));
-                }
-            } else {
+                HIP_TRY(hipLaunchKernel(k1_sell_multi_kernel(p->idx64, f), dim3(p->grid_sell_m[f == 4 ? 1 : 0]), dim3(64), kargs, 0, s->cur));
+                c += f;
+            }
+            const int n_paired = n_fused + n_rest;
+            if (n_paired > 0 && p->grid_sell_x > 0) { // their far / CSR-walked tiles
+                int rc = launch_single(p->d_sell_tiles_x, p->d_sell_chunk_x, p->grid_sell_x, false, 0, n_paired);
+                if (rc) return rc;
+            }
+            if (n_paired < C) { // chains without a partner: every tile without multiplicities in one launch
+                int rc = launch_single(p->grid_sell_k > 0 ? p->d_sell_tiles_1 : p->d_sell_tiles, p->d_sell_chunk, p->grid_sell, false, n_paired, C - n_paired);
+                if (rc) return rc;
+            }
+            if (p->grid_sell_k > 0) { // the tiles that hold collapsed identical reads, in ranges balanced by their cost, for every chain
+                int rc = launch_single(p->d_sell_tiles_k, p->d_sell_chunk_k, p->grid_sell_k, true, 0, C);
+                if (rc) return rc;
+            }
+        } else {
+            for (int c = 0; c < C; ++c) {
+                SampleArgs a = args_of(c);
                 const TileDesc *td = p->d_tiles;
                 const uint64_t *ct = p->d_chunk_tile;
+                const double *mu = s->d_mu + (size_t)c * p->n;
+                int32_t *cnt = s->d_cnt + (size_t)c * p->n;
                 void *kargs[] = {(void *)&rp, (void *)&ci, (void *)&kk, (void *)&td, (void *)&ct, (void *)&mu, (void *)&cnt, (void *)&a};
                 HIP_TRY(hipLaunchKernel(k1_csr_kernel(p->idx64, p->d_k != nullptr), dim3(p->grid_sample), dim3(K1C_BS), kargs, 0, s->cur));
             }
-            c += fuse;
         }
     }
     if (timed) {

@@ -158,8 +158,8 @@ struct RowViewFarTile {
 template <typename IdxT, bool HAS_K, int NGC, int REP = 1>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 7, HAS_K ? 5 : 7))) void k_sample_sell(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
                                                     const uint32_t *__restrict__ kmult, const SellTile *__restrict__ tiles, const uint64_t *__restrict__ chunk_tile,
-                                                    const double *__restrict__ gmu, const uint8_t *__restrict__ stream, int32_t *gcnt,
-                                                    SampleArgs a)
+                                                    const double *__restrict__ gmu /* [grid.y][n] */, const uint8_t *__restrict__ stream,
+                                                    int32_t *gcnt /* [grid.y][n] */, SampleArgs a)
 {
     constexpr int WIN = (int)SELL_WIN;
     __shared__ __attribute__((aligned(16))) double s_mu[WIN + 1]; // [WIN] stays 0.0: what pad slots read
@@ -169,6 +169,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
     // its count, no shift
     __shared__ int32_t s_cnt[REP * 2 * (WIN + 1)];
     const uint32_t lane = threadIdx.x;
+    // grid.y = chain: the tile lists that only some rows are on (multiplicities, far rows) are walked for every chain of a sampler
+    // in one launch -- their launches are bound by a few long rows, eight of them side by side fill the GPU eight times better
+    gmu += (size_t)blockIdx.y * a.n;
+    gcnt += (size_t)blockIdx.y * a.n;
+    a.chain += blockIdx.y;
 
     const uint64_t t_begin = chunk_tile[blockIdx.x], t_end = chunk_tile[blockIdx.x + 1];
     if (t_begin >= t_end) return;

@@ -357,12 +357,25 @@ def sort_hits(row_ptr, col_idx):
 def canonical_layout(row_ptr, col_idx, k=None):
     """Rows in the library's stored order (spec: mmseq_amd/csrc/mmg_types.h): hits ascending within every row, rows sorted by
     (key, hash), ties in the caller's order; a far row then keeps the hits inside its home window in front of the others.
+    A caller row with 2 <= k <= K_SMALL is stored as k rows with k = 1 (k comes back as None when no other multiplicity is left).
     Returns (row_ptr, col_idx, k, perm) with perm[stored row] = caller row."""
     col_sorted = sort_hits(row_ptr, col_idx)
+    src = None
+    if k is not None:
+        # step 0 (ABI 4): a row with 2 <= k <= K_SMALL is stored as k rows with k = 1; an array of ones is no array
+        kk0 = np.asarray(k).astype(np.int64)
+        reps = np.where((kk0 >= 2) & (kk0 <= K_SMALL), kk0, 1)
+        if (reps > 1).any():
+            src = np.repeat(np.arange(kk0.size, dtype=np.int64), reps)
+            row_ptr, col_sorted, k = permute_rows(row_ptr, col_sorted, np.where(reps > 1, 1, kk0).astype(np.uint32), src)
+        if (np.asarray(k) == 1).all():
+            k = None
     key, h = row_keys(row_ptr, col_sorted, k)
     perm = np.lexsort((h, key))
     rp, ci, kk = permute_rows(row_ptr, col_sorted, k, perm)
     skey = key[perm]
+    if src is not None:
+        perm = src[perm]
     far = (skey >> np.uint64(63)).astype(bool)
     if far.any() and ci.size:
         lens = np.diff(rp.astype(np.int64))

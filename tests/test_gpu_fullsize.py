@@ -56,6 +56,34 @@ def test_first_sweeps_bit_exact_against_oracle_at_full_size(full, gpu, orc):
         assert np.array_equal(mu_g, mu_o) and ll_g == ll_o
 
 
+def test_chain_pair_kernel_bit_exact_at_full_size(full, gpu, orc):
+    """BASELINE configs[2]: chains advanced in fused pairs (k_sample_sell_multi) at the full launch geometry -- eight generations of
+    ranges at config 3 -- against the oracle, chain by chain, for the first two sweeps; then eight chains in one sampler (four
+    pair launches per sweep): every chain assigns every read exactly once, and chain c equals the pair run's chain c."""
+    name, prob, mu0, uh = full
+    rp, ci = prob.download()
+    p = orc.Problem(rp, ci, prob.l())
+    iters = 2
+    s = gpu.Sampler(prob, mu0, seed=4321, n_chains=2, gibbs_iter=iters, trace_len=iters)
+    s.run(iters)
+    pair = []
+    for c in range(2):
+        ref = orc.gibbs_keyed(p, mu0, seed=4321, chain=c, n_iter=iters, trace_len=iters)
+        assert np.array_equal(s.counts(c), ref["cnt"]), "chain %d counts" % c
+        assert np.array_equal(s.trace(c), ref["trace"]), "chain %d trace" % c
+        pair.append(_digest(s.trace(c), s.counts(c)))
+    s.close()
+    s = gpu.Sampler(prob, mu0, seed=4321, n_chains=8, gibbs_iter=iters, trace_len=iters)
+    for _ in range(iters):
+        s.sample()
+        for c in range(8):
+            assert int(s.counts(c).astype(np.int64).sum()) == prob.info.total_k
+        s.update()
+    assert [_digest(s.trace(c), s.counts(c)) for c in range(2)] == pair
+    assert len({_digest(s.trace(c)) for c in range(8)}) == 8           # eight different chains
+    s.close()
+
+
 def test_conservation_and_kernel_independence_at_full_size(full, gpu):
     name, prob, mu0, uh = full
     R, T, avg = CONFIGS[name]

@@ -372,10 +372,12 @@ def test_shards_of_a_stored_problem_with_far_rows_and_tx_order(gpu, orc):
     s.sample()
     whole = s.counts(0)
     assert np.array_equal(whole, orc.sample_counts(orc.Problem(rp, ci, l_ext, k=kk), mu0, seed=19, chain=0, it=0))
-    cut = (p.m // 2) & ~1
+    m_st = rp.size - 1                                         # stored rows: a caller row with 2 <= k <= 64 is k of them
+    assert m_st > p.m and set(np.unique(kk)) == {1, 70}
+    cut = (m_st // 2) & ~1
     nz = int(rp[cut])
     parts = []
-    for lo, hi in ((0, cut), (cut, p.m)):
+    for lo, hi in ((0, cut), (cut, m_st)):
         a, b = int(rp[lo]), int(rp[hi])
         sh = gpu.Problem.from_csr(rp[lo:hi + 1] - rp[lo], ci[a:b], l_ext, k=kk[lo:hi], row_id_base=lo, keep_rows=True, tx_order=tx_order)
         d_rp, d_ci = sh.download()
@@ -486,7 +488,7 @@ def test_em_stepper_paths_match_oracle(gpu, orc, sort, em_kernel, grid):
     # without dead transcripts and the empty row (the reference's arithmetic turns those into NaN), the same device
     # path follows the reference's own summation order to rounding
     mu1, _ = orc.start_values(pk)
-    keep = np.ones(pk.m, bool)
+    keep = np.ones(k.size, bool)
     keep[999] = False
     p2 = orc.Problem(p.row_ptr, p.col_idx, pk.l, k=k[keep])
     prob2 = gpu.Problem.from_csr(p2.row_ptr, p2.col_idx, p2.l, k=p2.k)
@@ -559,7 +561,8 @@ def test_golden_em_on_device(gpu):
     e = json.load(open(os.path.join(gd, "em_fixed_tiny.json")))
     fh = lambda xs: np.array([float.fromhex(x) for x in xs])
     prob = gpu.Problem.from_csr(np.asarray(g["row_ptr"], np.uint64), np.asarray(g["col_idx"], np.uint32), fh(g["l"]),
-                                k=np.asarray(g["k"], np.uint32))                 # EM sums are exact: any row order gives these bits
+                                k=np.asarray(g["k"], np.uint32), keep_rows=True)  # (the canonical layout stores a row with 2 <= k <= 64 as k
+                                                                                 # rows: k terms 1/d instead of one term k/d, other low bits)
     for r in e["runs"]:
         em = prob.em_stepper(fh(r["mu_start"]))
         for _ in range(r["sweeps"]):

@@ -133,24 +133,32 @@ def test_canonical_layout_properties(orc):
     import numpy as np
     p, _ = orc.synth_problem(R=8000, T=900, avg_hits=6, seed=3, sort=False, far_fraction=0.05)
     rng = np.random.default_rng(0)
-    k = rng.choice([1, 1, 2, 9], size=p.m).astype(np.uint32)
+    k = rng.choice([1, 1, 2, 9, 70], size=p.m).astype(np.uint32)
     rp, ci, kk, perm = orc.canonical_layout(p.row_ptr, p.col_idx, k)
-    key, h = orc.row_keys(rp, orc.sort_hits(rp, ci), kk)   # key and hash are functions of the SET of hits
+    # rows with 2 <= k <= 64 are stored as k rows with k = 1 (ABI 4); the larger multiplicities stay
+    m_st = rp.size - 1
+    assert m_st == int(np.where((k >= 2) & (k <= 64), k, 1).sum()) and set(np.unique(kk)) == {1, 70}
+    assert int(kk.astype(np.int64).sum()) == int(k.astype(np.int64).sum())
+    assert np.array_equal(np.bincount(perm, minlength=p.m), np.where((k >= 2) & (k <= 64), k, 1))   # perm[stored row] = caller row
+    assert np.array_equal(np.diff(rp.astype(np.int64)), np.diff(p.row_ptr.astype(np.int64))[perm])
+    key, h = orc.row_keys(rp, orc.sort_hits(rp, ci), kk)   # key and tie word are functions of the SET of hits
     assert (key[1:] >= key[:-1]).all()
     same = key[1:] == key[:-1]
     assert (h[1:][same] >= h[:-1][same]).all()
     rp2, ci2, kk2, perm2 = orc.canonical_layout(rp, ci, kk)
-    assert np.array_equal(rp2, rp) and np.array_equal(ci2, ci) and np.array_equal(kk2, kk) and np.array_equal(perm2, np.arange(p.m))
+    assert np.array_equal(rp2, rp) and np.array_equal(ci2, ci) and np.array_equal(kk2, kk) and np.array_equal(perm2, np.arange(m_st))
     sh = rng.permutation(p.m)
     rps, cis, ks = orc.permute_rows(p.row_ptr, p.col_idx, k, sh)
     rp3, ci3, kk3, _ = orc.canonical_layout(rps, cis, ks)
     assert np.array_equal(rp3, rp) and np.array_equal(ci3, ci) and np.array_equal(kk3, kk)
+    _, _, k_none, _ = orc.canonical_layout(p.row_ptr, p.col_idx, np.minimum(k, 9).astype(np.uint32))
+    assert k_none is None                                  # every multiplicity expanded: an array of ones is no array
     far = key >> np.uint64(63)
-    assert 0 < far.sum() < p.m and (np.diff(far.astype(np.int64)) >= 0).all()
+    assert 0 < far.sum() < m_st and (np.diff(far.astype(np.int64)) >= 0).all()
     # a far row is stored with the hits inside its home window first, both parts ascending; every other row ascending
     wbase = (((key >> np.uint64(18)) & np.uint64((1 << 45) - 1)) << np.uint64(6)).astype(np.int64)
     n_far_hits = 0
-    for r in range(p.m):
+    for r in range(m_st):
         row = ci[int(rp[r]):int(rp[r + 1])].astype(np.int64)
         if not far[r]:
             assert (np.diff(row) > 0).all()

@@ -35,6 +35,7 @@ def one_case(seed, gpu, orc, verbose=True):
     if rng.integers(0, 3) == 0: opts["sell_waves_per_cu"] = 1
     if rng.integers(0, 3) == 0: opts["em_grid"] = int(rng.integers(1, 9))
     if rng.integers(0, 3) == 0: opts["em_kernel"] = 0
+    if rng.integers(0, 4) == 0: opts["fuse_chains"] = int(rng.choice([1, 4]))
     keep_rows = bool(rng.integers(0, 3) == 0)
     tx_order = None
     if rng.integers(0, 3) == 0:                          # device renumbering: random gene sizes over a random scatter
@@ -51,7 +52,7 @@ def one_case(seed, gpu, orc, verbose=True):
         assert np.array_equal(g_uh, uh), "unique hits"
         assert np.array_equal(g_mu0, orc.start_values_exact(pk)), "start values"
         n_it = int(rng.integers(1, 6))
-        chains = int(rng.choice([1, 1, 3]))
+        chains = int(rng.choice([1, 1, 2, 3, 5]))        # pairs over the fast tiles, grid.y launches over far / multiplicity tiles, an odd chain
         alpha, beta = float(rng.choice([0.1, 1.0])), float(rng.choice([0.1, 2.0]))
         s = gpu.Sampler(prob, mu0, alpha=alpha, beta=beta, seed=seed, n_chains=chains, chain_base=2, gibbs_iter=n_it, trace_len=n_it)
         s.run(n_it)
