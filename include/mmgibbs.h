@@ -264,8 +264,12 @@ void mmg_group_destroy(mmg_group *g);
 int mmg_group_run_sharded(mmg_group *g, mmg_sampler *const *samplers, int n_iter);
 /* Chains mode: every sampler advances its own chains (distinct chain_base) by n_iter iterations; nothing is exchanged. */
 int mmg_group_run_chains(mmg_group *g, mmg_sampler *const *samplers, int n_iter);
-/* ncclAllReduce(fp64, sum) of the posterior moments over the devices (in place: afterwards every sampler's moments hold the
- * sums over devices), then summed over the chains of a device: sum_log[n], sum_log2[n] (caller's numbering) over n_samples
+/* Both run calls drive every device from its own host thread (thread i binds device i and enqueues its kernels and collectives
+ * in order).  Host time the slowest of them spent per iteration in the last run call, in microseconds: what a device waits
+ * for between iterations when its kernels are shorter than that. */
+int mmg_group_enqueue_us(const mmg_group *g, double *us_per_device_iteration);
+/* ncclAllReduce(fp64, sum) of the posterior moments over the devices (into scratch buffers: the samplers keep their own moments,
+ * the call may be repeated), then summed over the chains of a device: sum_log[n], sum_log2[n] (caller's numbering) over n_samples
  * kept samples of all chains. */
 int mmg_group_pool_moments(mmg_group *g, mmg_sampler *const *samplers, double *sum_log, double *sum_log2, int64_t *n_samples);
 /* Host helper: contiguous row ranges of (nearly) equal hit counts for `parts` shards: bounds[i] = first row of part i (even),

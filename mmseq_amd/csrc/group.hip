@@ -18,6 +18,9 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 using namespace mmg;
@@ -57,6 +60,7 @@ Rccl g_rccl;
 struct mmg_group {
     std::vector<int> devices;
     std::vector<ncclComm_t> comms;
+    double last_enqueue_us = 0.0; // host time per device-iteration of the last run_* call (slowest driver thread)
 };
 
 #define NCCL_TRY(expr)                                                                                                   \
@@ -109,20 +113,59 @@ static int check_samplers(const mmg_group *g, mmg_sampler *const *s, std::vector
         if (rc) return rc;
         if (v[i].p->device != g->devices[i]) return fail(MMG_ERR_ARG, "sampler i must live on device i of the group");
         if (v[i].p->n != v[0].p->n || v[i].cfg.n_chains != v[0].cfg.n_chains) return fail(MMG_ERR_ARG, "samplers of a group must agree on transcripts and chains");
+        if (v[i].iter != v[0].iter || v[i].cfg.gibbs_iter != v[0].cfg.gibbs_iter || v[i].cfg.trace_len != v[0].cfg.trace_len)
+            return fail(MMG_ERR_ARG, "samplers of a group must be at the same iteration with the same gibbs_iter and trace_len");
     }
     return MMG_OK;
 }
 
-// in-place sum over the devices of `count` elements at ptrs[i], each on its sampler's stream
-static int all_reduce(const mmg_group *g, const std::vector<SamplerView> &v, void *const *ptrs, size_t count, ncclDataType_t type)
+// One driver thread per device: thread i binds device i once and enqueues that device's kernels and collectives in order.  A
+// single host thread that visits the devices in turn pays a hipSetDevice and three launches per device and iteration -- at
+// config-2 scale (40 us per iteration) eight devices would wait for the host.  RCCL accepts concurrent enqueues on the
+// communicators of one ncclCommInitAll from one thread each, without a group bracket.  f(i) returns an MMG code; the first
+// failure (with its message) is what the caller sees, and the other threads stop at their next iteration.
+template <typename F>
+static int drive_devices(mmg_group *g, size_t G, int n_iter, F body)
+{
+    std::vector<int> rc(G, MMG_OK);
+    std::vector<std::string> msg(G);
+    std::vector<double> us(G, 0.0);
+    std::atomic<bool> stop{false};
+    auto run = [&](size_t i) {
+        if (hipSetDevice(g->devices[i]) != hipSuccess) { rc[i] = MMG_ERR_HIP; msg[i] = "hipSetDevice"; stop = true; return; }
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int it = 0; it < n_iter && !stop.load(std::memory_order_relaxed); ++it) {
+            const int r = body(i);
+            if (r != MMG_OK) { rc[i] = r; msg[i] = mmg_last_error(); stop = true; return; }
+        }
+        us[i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    };
+    if (G == 1) run(0);
+    else {
+        std::vector<std::thread> th;
+        for (size_t i = 1; i < G; ++i) th.emplace_back(run, i);
+        run(0);
+        for (auto &t : th) t.join();
+    }
+    for (size_t i = 0; i < G; ++i) if (rc[i] != MMG_OK) return fail(rc[i], msg[i]);
+    g->last_enqueue_us = n_iter > 0 ? *std::max_element(us.begin(), us.end()) / n_iter : 0.0;
+    return MMG_OK;
+}
+
+// sum over the devices of `count` elements: send[i] -> recv[i] (may be the same buffer), each on its sampler's stream; one thread
+// enqueues for every device, hence the group bracket -- which is closed on the error path as well
+static int all_reduce(const mmg_group *g, const std::vector<SamplerView> &v, void *const *send, void *const *recv, size_t count, ncclDataType_t type)
 {
     NCCL_TRY(g_rccl.GroupStart());
-    for (size_t i = 0; i < v.size(); ++i) {
-        HIP_TRY(hipSetDevice(g->devices[i]));
-        NCCL_TRY(g_rccl.AllReduce(ptrs[i], ptrs[i], count, type, ncclSum, g->comms[i], v[i].stream));
+    int rc = MMG_OK;
+    for (size_t i = 0; i < v.size() && rc == MMG_OK; ++i) {
+        if (hipSetDevice(g->devices[i]) != hipSuccess) { rc = fail(MMG_ERR_HIP, "hipSetDevice"); break; }
+        const ncclResult_t r = g_rccl.AllReduce(send[i], recv[i], count, type, ncclSum, g->comms[i], v[i].stream);
+        if (r != ncclSuccess) rc = fail(MMG_ERR_HIP, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
     }
-    NCCL_TRY(g_rccl.GroupEnd());
-    return MMG_OK;
+    const ncclResult_t e = g_rccl.GroupEnd();
+    if (rc == MMG_OK && e != ncclSuccess) rc = fail(MMG_ERR_HIP, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(e));
+    return rc;
 }
 
 extern "C" int mmg_group_run_sharded(mmg_group *g, mmg_sampler *const *samplers, int n_iter)
@@ -138,12 +181,15 @@ extern "C" int mmg_group_run_sharded(mmg_group *g, mmg_sampler *const *samplers,
     std::vector<void *> cnt(G);
     uint64_t count = 0;
     for (size_t i = 0; i < G; ++i) if ((rc = mmg_sampler_counts_devptr(samplers[i], &cnt[i], &count)) != MMG_OK) return rc;
-    for (int it = 0; it < n_iter; ++it) {
-        for (size_t i = 0; i < G; ++i) if ((rc = mmg_sampler_sample(samplers[i])) != MMG_OK) return rc;      // src/mmseq.cpp:857-891 on the device's rows
-        if (G > 1 && (rc = all_reduce(g, v, cnt.data(), (size_t)count, ncclInt32)) != MMG_OK) return rc;      // :896-899 across devices
-        for (size_t i = 0; i < G; ++i) if ((rc = mmg_sampler_update(samplers[i])) != MMG_OK) return rc;      // :905-917, identical everywhere
-    }
-    return MMG_OK;
+    return drive_devices(g, G, n_iter, [&](size_t i) -> int {
+        int r = mmg_sampler_sample(samplers[i]);                                                          // src/mmseq.cpp:857-891 on the device's rows
+        if (r != MMG_OK) return r;
+        if (G > 1) {                                                                                      // :896-899 across devices
+            const ncclResult_t e = g_rccl.AllReduce(cnt[i], cnt[i], (size_t)count, ncclInt32, ncclSum, g->comms[i], v[i].stream);
+            if (e != ncclSuccess) return fail(MMG_ERR_HIP, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(e));
+        }
+        return mmg_sampler_update(samplers[i]);                                                           // :905-917, identical everywhere
+    });
 }
 
 extern "C" int mmg_group_run_chains(mmg_group *g, mmg_sampler *const *samplers, int n_iter)
@@ -152,9 +198,13 @@ extern "C" int mmg_group_run_chains(mmg_group *g, mmg_sampler *const *samplers, 
     int rc = check_samplers(g, samplers, v);
     if (rc) return rc;
     if (n_iter < 0) return fail(MMG_ERR_ARG, "bad argument");
-    // interleaved so that every device has work queued from the first iteration on
-    for (int it = 0; it < n_iter; ++it)
-        for (size_t i = 0; i < v.size(); ++i) if ((rc = mmg_sampler_run(samplers[i], 1)) != MMG_OK) return rc;
+    return drive_devices(g, v.size(), n_iter, [&](size_t i) -> int { return mmg_sampler_run(samplers[i], 1); });
+}
+
+extern "C" int mmg_group_enqueue_us(const mmg_group *g, double *us_per_device_iteration)
+{
+    if (!g || !us_per_device_iteration) return fail(MMG_ERR_ARG, "NULL argument");
+    *us_per_device_iteration = g->last_enqueue_us;
     return MMG_OK;
 }
 
@@ -164,23 +214,47 @@ extern "C" int mmg_group_pool_moments(mmg_group *g, mmg_sampler *const *samplers
     int rc = check_samplers(g, samplers, v);
     if (rc) return rc;
     const size_t G = v.size();
-    std::vector<void *> mom(G);
+    for (size_t i = 1; i < G; ++i)
+        if (v[i].n_kept != v[0].n_kept) return fail(MMG_ERR_ARG, "samplers of a group must have kept the same number of samples");
+    std::vector<void *> mom(G), red(G, nullptr);
     uint64_t count = 0;
     for (size_t i = 0; i < G; ++i) if ((rc = mmg_sampler_moments_devptr(samplers[i], &mom[i], &count)) != MMG_OK) return rc;
-    if (G > 1 && (rc = all_reduce(g, v, mom.data(), (size_t)count, ncclDouble)) != MMG_OK) return rc;
-    // every device now holds the sums over devices; chains of a device are added up on the host
+    // reduced into scratch buffers: the samplers keep their own moments, so pooling twice -- or pooling, running on and pooling
+    // again -- counts nothing twice
+    auto release = [&]() { for (size_t i = 0; i < G; ++i) if (red[i]) { (void)hipSetDevice(g->devices[i]); (void)hipFree(red[i]); } };
     const uint32_t n = v[0].p->n;
     const int C = v[0].cfg.n_chains;
-    std::vector<double> a(n), b(n);
-    int64_t ns = 0, total = 0;
-    if (sum_log) std::fill(sum_log, sum_log + n, 0.0);
-    if (sum_log2) std::fill(sum_log2, sum_log2 + n, 0.0);
-    for (int c = 0; c < C; ++c) {
-        if ((rc = mmg_sampler_get_moments(samplers[0], c, a.data(), b.data(), &ns)) != MMG_OK) return rc;
-        for (uint32_t t = 0; t < n; ++t) { if (sum_log) sum_log[t] += a[t]; if (sum_log2) sum_log2[t] += b[t]; }
-        total += ns * (int64_t)G;
+    std::vector<double> pooled((size_t)count);
+    if (G > 1) {
+        for (size_t i = 0; i < G; ++i) {
+            if (hipSetDevice(g->devices[i]) != hipSuccess || hipMalloc(&red[i], (size_t)count * sizeof(double)) != hipSuccess) { release(); return fail(MMG_ERR_HIP, "hipMalloc (pooled moments)"); }
+        }
+        if ((rc = all_reduce(g, v, mom.data(), red.data(), (size_t)count, ncclDouble)) != MMG_OK) { release(); return rc; }
+        hipError_t e = hipSetDevice(g->devices[0]);
+        if (e == hipSuccess) e = hipStreamSynchronize(v[0].stream);
+        if (e == hipSuccess) e = hipMemcpy(pooled.data(), red[0], (size_t)count * sizeof(double), hipMemcpyDeviceToHost);
+        for (size_t i = 1; i < G && e == hipSuccess; ++i) { e = hipSetDevice(g->devices[i]); if (e == hipSuccess) e = hipStreamSynchronize(v[i].stream); }
+        release();
+        if (e != hipSuccess) return fail(MMG_ERR_HIP, std::string("pooled moments: ") + hipGetErrorString(e));
+    } else {
+        hipError_t e = hipSetDevice(g->devices[0]);
+        if (e == hipSuccess) e = hipStreamSynchronize(v[0].stream);
+        if (e == hipSuccess) e = hipMemcpy(pooled.data(), mom[0], (size_t)count * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return fail(MMG_ERR_HIP, std::string("pooled moments: ") + hipGetErrorString(e));
     }
-    if (n_samples) *n_samples = total;
+    // pooled: [2][C][n] in device numbering, summed over devices; the chains of a device are added up here, in the caller's numbering
+    std::vector<double> a(n), tmp(n);
+    for (int w = 0; w < 2; ++w) {
+        double *out = w == 0 ? sum_log : sum_log2;
+        if (!out) continue;
+        std::fill(a.begin(), a.end(), 0.0);
+        for (int c = 0; c < C; ++c) {
+            const double *src = pooled.data() + ((size_t)w * C + (size_t)c) * n;
+            for (uint32_t t = 0; t < n; ++t) a[t] += src[t];
+        }
+        to_ext(v[0].p, a, out);
+    }
+    if (n_samples) *n_samples = v[0].n_kept * (int64_t)C * (int64_t)G;
     return MMG_OK;
 }
 

@@ -66,6 +66,7 @@ struct SamplerView {
     const double *d_trace;   // [C][trace_len][n] sample-major, device numbering; nullptr without keep_trace
     hipStream_t stream;
     int iter;
+    int64_t n_kept;          // samples kept so far
 };
 int sampler_view(mmg_sampler *s, SamplerView *v);
 

@@ -40,7 +40,7 @@ static void sampler_free(mmg_sampler *s)
 int mmg::sampler_view(mmg_sampler *s, SamplerView *v)
 {
     if (!s || !v) return fail(MMG_ERR_ARG, "NULL argument");
-    v->p = s->p; v->cfg = s->cfg; v->d_trace = s->d_trace; v->stream = s->cur; v->iter = s->iter;
+    v->p = s->p; v->cfg = s->cfg; v->d_trace = s->d_trace; v->stream = s->cur; v->iter = s->iter; v->n_kept = s->n_kept;
     return MMG_OK;
 }
 
