@@ -149,6 +149,12 @@ int mmg_problem_info_get(const mmg_problem *p, mmg_problem_info *info);
  * k m u32; any may be NULL): what a checker needs to replay the chain row by row -- stored row i walks its hits in the
  * returned order and draws from random stream row_id_base + i. */
 int mmg_problem_download(const mmg_problem *p, uint64_t *row_ptr, uint32_t *col_idx, uint32_t *k);
+/* Rows [lo, hi) of a stored problem as a problem of its own on `device`: a read shard (its rows draw from the random streams
+ * row_id_base + lo + i, like the rows of the parent) or, with lo = 0 and hi = m, a replica for chains mode.  Cut on the parent's
+ * device and copied device to device (peer copy); rows, hit order and transcript numbering stay as stored. */
+int mmg_problem_shard(const mmg_problem *full, uint64_t lo, uint64_t hi, int device, mmg_problem **out);
+/* mmg_shard_bounds (below) on the stored rows of p: bounds[0..parts]. */
+int mmg_problem_shard_bounds(const mmg_problem *p, int parts, uint64_t *bounds);
 int mmg_problem_get_l(const mmg_problem *p, double *l);
 /* Start values and the unique-hit column, src/mmseq.cpp:617-638: mu0[t] = sum_{i: t in row i}
  * k_i/|row i| / l[t]; unique_hits[t] = sum of k_i over rows {t} (bit-exact integer). Either
@@ -272,6 +278,12 @@ int mmg_group_enqueue_us(const mmg_group *g, double *us_per_device_iteration);
  * the call may be repeated), then summed over the chains of a device: sum_log[n], sum_log2[n] (caller's numbering) over n_samples
  * kept samples of all chains. */
 int mmg_group_pool_moments(mmg_group *g, mmg_sampler *const *samplers, double *sum_log, double *sum_log2, int64_t *n_samples);
+/* EM (src/mmseq.cpp:741-811) over read shards: shards[i] on device i holds a contiguous range of the stored rows.  Every phase of a
+ * sweep runs on every device, then xe (max), the exact fixed-point accumulators with the log-likelihood limbs (uint64 sums) and,
+ * once, the hits per transcript are all-reduced: integer sums, so every device holds the bits the unsharded EM produces, takes the
+ * same repeat decisions and applies the same update.  ems[0..G) are returned; step and read ems[0] with mmg_em_step /
+ * mmg_em_get_mu, destroy every member with mmg_em_destroy. */
+int mmg_group_em_create(mmg_group *g, const mmg_problem *const *shards, const double *mu0, mmg_em **ems, double *loglik0);
 /* Host helper: contiguous row ranges of (nearly) equal hit counts for `parts` shards: bounds[i] = first row of part i (even),
  * bounds[parts] = m. */
 int mmg_shard_bounds(const uint64_t *row_ptr, uint64_t m, int parts, uint64_t *bounds);
@@ -297,6 +309,11 @@ enum {
     MMG_OPT_COUNT_ = 6
 };
 int mmg_selftest_option(int option, int value);
+/* The sharded EM of mmg_group_em_create with every shard on ONE device and the exchange done by plain kernels: `sweeps` sweeps from
+ * mu0, mu (caller's numbering), the log-likelihood and the number of repeated passes -- the same bits as mmg_problem_em on the
+ * unsharded problem. */
+int mmg_selftest_em_shards(const mmg_problem *const *shards, int n_shards, const double *mu0, int sweeps, double *mu, double *loglik,
+                           int *repeated_passes);
 /* What the HIP runtime reports about the k == NULL sliced-ELL sample kernel on `device`: registers, LDS and scratch bytes per
  * thread, and resident 64-thread workgroups per CU (hipOccupancyMaxActiveBlocksPerMultiprocessor). */
 int mmg_selftest_kernel_info(int device, int *vgprs, int *lds_bytes, int *scratch_bytes, int *resident_per_cu);

@@ -111,6 +111,10 @@ SYMBOLS = {
     "mmg_group_run_sharded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "mmg_group_run_chains": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "mmg_group_enqueue_us": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "mmg_problem_shard": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_void_p)]),
+    "mmg_problem_shard_bounds": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "mmg_group_em_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
+    "mmg_selftest_em_shards": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "mmg_group_pool_moments": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
     "mmg_shard_bounds": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]),
     "mmg_host_gamma_trace": (C.c_int, [C.c_uint64, C.c_uint64, C.c_double, C.c_double, C.c_int, C.c_void_p]),

@@ -35,6 +35,15 @@ void launch_em_colcount(const uint32_t *col, uint64_t nnz, uint64_t *cnt, unsign
 {
     if (nnz) hipLaunchKernelGGL(k_em_colcount, dim3(grid), dim3(256), 0, s, col, nnz, cnt);
 }
+// dst[i] op= src[i] (same device): the exchange of the EM self test that runs read shards side by side on ONE device
+__global__ void k_combine_u64(uint64_t *dst, const uint64_t *src, size_t n) { const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) dst[i] += src[i]; }
+__global__ void k_combine_max_i32(int32_t *dst, const int32_t *src, size_t n) { const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) dst[i] = max(dst[i], src[i]); }
+void launch_combine(void *dst, const void *src, size_t n, bool max_i32, hipStream_t s)
+{
+    if (!n) return;
+    if (max_i32) hipLaunchKernelGGL(k_combine_max_i32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (int32_t *)dst, (const int32_t *)src, n);
+    else hipLaunchKernelGGL(k_combine_u64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (uint64_t *)dst, (const uint64_t *)src, n);
+}
 void launch_fill_i32(int32_t *p, uint32_t n, int32_t v, hipStream_t s)
 {
     hipLaunchKernelGGL(k_fill_i32, dim3((n + 255) / 256), dim3(256), 0, s, p, n, v);

@@ -258,6 +258,39 @@ extern "C" int mmg_group_pool_moments(mmg_group *g, mmg_sampler *const *samplers
     return MMG_OK;
 }
 
+// ---- EM over read shards: one member per device, xe / accumulators / column counts exchanged with RCCL between the phases
+namespace {
+struct EmGroupCtx { mmg_group *g; };
+std::function<int(int)> make_rccl_reduce(const std::vector<mmg_em *> &es, void *ctx)
+{
+    mmg_group *g = ((EmGroupCtx *)ctx)->g;
+    return [es, g](int what) -> int {
+        NCCL_TRY(g_rccl.GroupStart());
+        int rc = MMG_OK;
+        for (size_t i = 0; i < es.size() && rc == MMG_OK; ++i) {
+            void *p = nullptr;
+            size_t cnt = 0;
+            em_exchange_buffers(es[i], what, &p, &cnt);
+            if (hipSetDevice(g->devices[i]) != hipSuccess) { rc = fail(MMG_ERR_HIP, "hipSetDevice"); break; }
+            const ncclResult_t r = g_rccl.AllReduce(p, p, cnt, what == 0 ? ncclInt32 : ncclUint64, what == 0 ? ncclMax : ncclSum, g->comms[i], (hipStream_t)0);
+            if (r != ncclSuccess) rc = fail(MMG_ERR_HIP, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
+        }
+        const ncclResult_t e = g_rccl.GroupEnd();
+        if (rc == MMG_OK && e != ncclSuccess) rc = fail(MMG_ERR_HIP, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(e));
+        return rc;
+    };
+}
+} // namespace
+
+extern "C" int mmg_group_em_create(mmg_group *g, const mmg_problem *const *shards, const double *mu0, mmg_em **ems, double *loglik0)
+{
+    if (!g || !shards || !mu0 || !ems) return fail(MMG_ERR_ARG, "NULL argument");
+    for (size_t i = 0; i < g->devices.size(); ++i)
+        if (!shards[i] || shards[i]->device != g->devices[i]) return fail(MMG_ERR_ARG, "shard i must live on device i of the group");
+    EmGroupCtx ctx{g};
+    return em_create_sharded(shards, (int)g->devices.size(), mu0, make_rccl_reduce, &ctx, ems, loglik0);
+}
+
 // Contiguous row ranges of (nearly) equal hit counts: bounds[i] = first row of part i, bounds[parts] = m.  Boundaries are even
 // row indices (a Philox block serves the rows 2q and 2q+1: shards that start on even rows keep every block on one device).
 extern "C" int mmg_shard_bounds(const uint64_t *row_ptr, uint64_t m, int parts, uint64_t *bounds)

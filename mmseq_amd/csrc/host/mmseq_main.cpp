@@ -821,13 +821,38 @@ int main(int argc, char **argv)
     }
 
     stage.mark("device problem build");
-    // ---- EM on the device (src/mmseq.cpp:741-811): mu stays there; this loop owns the stopping rule and the output
+    // ---- several devices: the stored problem (canonical order, device numbering) is cut into contiguous read shards, one per device
+    //      (one chain: EM and Gibbs both run sharded), or replicated (chains >= devices).  Cut on device 0 and copied device to
+    //      device (mmg_problem_shard): nothing comes back to the host.
+    vector<mmg_problem *> dprob;   // problems created here (besides prob)
+    vector<mmg_problem *> part;    // problem of device i
+    mmg_group *grp = nullptr;
+    const bool shard = gpus > 1 && chains == 1;
+    if (gpus > 1) {
+        vector<int> devs(gpus);
+        for (int i = 0; i < gpus; ++i) devs[i] = device + i;
+        MMG_TRY(mmg_group_create(devs.data(), gpus, &grp));
+        mmg_problem_info inf;
+        MMG_TRY(mmg_problem_info_get(prob, &inf));
+        vector<uint64_t> bounds(gpus + 1, 0);
+        if (shard) MMG_TRY(mmg_problem_shard_bounds(prob, gpus, bounds.data()));
+        part.resize(gpus);
+        for (int i = 0; i < gpus; ++i) {
+            if (!shard && i == 0) { part[0] = prob; continue; }
+            MMG_TRY(mmg_problem_shard(prob, shard ? bounds[i] : 0, shard ? bounds[i + 1] : inf.m, devs[i], &part[i]));
+            dprob.push_back(part[i]);
+        }
+        stage.mark(shard ? "read shards" : "replicas");
+    }
+    // ---- EM on the device(s) (src/mmseq.cpp:741-811): mu stays there; this loop owns the stopping rule and the output
     GzText *gz_em = debug ? new GzText(output_base + ".trace_em.gz") : nullptr;
     if (gz_em) { for (uint32_t t = 0; t < n; t++) { gz_em->str(sid(t)); gz_em->str(" "); } gz_em->str("\n"); }
     {
         double loglik = 0.0;
-        mmg_em *em = nullptr;
-        MMG_TRY(mmg_em_create(prob, mu.data(), &em, &loglik));
+        vector<mmg_em *> ems(shard ? gpus : 1, nullptr);
+        if (shard) MMG_TRY(mmg_group_em_create(grp, part.data(), mu.data(), ems.data(), &loglik)); // exact integer sums: the bits of the unsharded EM
+        else MMG_TRY(mmg_em_create(prob, mu.data(), &ems[0], &loglik));
+        mmg_em *em = ems[0];
         stage.mark("EM set-up + first pass");
         double llr = epsilon + 1;
         int iter = 0;
@@ -848,7 +873,7 @@ int main(int argc, char **argv)
             iter++;
         }
         MMG_TRY(mmg_em_get_mu(em, mu.data()));
-        mmg_em_destroy(em);
+        for (auto e : ems) mmg_em_destroy(e);
         cout << endl;
         cout.unsetf(ios::floatfield);
         cout.precision(6);
@@ -861,54 +886,22 @@ int main(int argc, char **argv)
     //      one device: `chains` chains in one sampler.  several devices, one chain: the stored rows are cut into contiguous shards
     //      (mmg_shard_bounds), one per device, counts all-reduced over RCCL every iteration -- bit-identical to the one-device run.
     //      several devices, chains >= devices: the stored problem is replicated, every device runs chains / gpus chains.
-    vector<mmg_problem *> dprob;   // problems created here (besides prob)
     vector<mmg_sampler *> smps;
-    mmg_group *grp = nullptr;
     {
         mmg_config cfg;
         memset(&cfg, 0, sizeof cfg);
         cfg.alpha = alpha; cfg.beta = beta; cfg.seed = (uint64_t)(int64_t)seed;
         cfg.n_chains = gpus > 1 ? max(1, chains / gpus) : chains; cfg.chain_base = 0; cfg.gibbs_iter = gibbs_iter; cfg.trace_len = trace_length;
         cfg.keep_trace = 1; cfg.timing = 0;
-        const bool shard = gpus > 1 && chains == 1;
         if (gpus == 1) {
             smps.resize(1);
             MMG_TRY(mmg_sampler_create(prob, &cfg, mu_em.data(), &smps[0]));
         } else {
-            vector<int> devs(gpus);
-            for (int i = 0; i < gpus; ++i) devs[i] = device + i;
-            MMG_TRY(mmg_group_create(devs.data(), gpus, &grp));
-            // the rows as the library stores them (its canonical order): shards / replicas keep them as they are
-            mmg_problem_info inf;
-            MMG_TRY(mmg_problem_info_get(prob, &inf));
-            vector<uint64_t> srp(inf.m + 1);
-            vector<uint32_t> sci(inf.nnz), sk(inf.m);
-            MMG_TRY(mmg_problem_download(prob, srp.data(), sci.data(), sk.data()));
-            vector<uint64_t> tx_order(n);
-            {
-                vector<uint32_t> perm(n);
-                MMG_TRY(mmg_problem_tx_perm(prob, perm.data()));
-                for (uint32_t t = 0; t < n; ++t) tx_order[t] = perm[t]; // the same device numbering on every device
-            }
-            vector<uint64_t> bounds(gpus + 1, 0);
-            if (shard) MMG_TRY(mmg_shard_bounds(srp.data(), inf.m, gpus, bounds.data()));
             smps.resize(gpus);
             for (int i = 0; i < gpus; ++i) {
-                const uint64_t lo = shard ? bounds[i] : 0, hi = shard ? bounds[i + 1] : inf.m;
-                mmg_problem *pi = prob;
-                if (shard || i > 0) {
-                    vector<uint64_t> rp(hi - lo + 1);
-                    for (size_t r = 0; r < rp.size(); ++r) rp[r] = srp[lo + r] - srp[lo];
-                    mmg_problem_desc pd;
-                    memset(&pd, 0, sizeof pd);
-                    pd.m = hi - lo; pd.n = n; pd.row_ptr = rp.data(); pd.col_idx = sci.data() + srp[lo]; pd.k = sk.data() + lo; pd.l = l.data();
-                    pd.row_id_base = lo; pd.layout = MMG_LAYOUT_KEEP_ROWS; pd.tx_order = tx_order.data();
-                    MMG_TRY(mmg_problem_create(&pd, devs[i], &pi));
-                    dprob.push_back(pi);
-                }
                 mmg_config ci = cfg;
                 ci.chain_base = shard ? 0 : i * cfg.n_chains;
-                MMG_TRY(mmg_sampler_create(pi, &ci, mu_em.data(), &smps[i]));
+                MMG_TRY(mmg_sampler_create(part[i], &ci, mu_em.data(), &smps[i]));
             }
         }
         const int chunk = max(1, gibbs_iter / 16);

@@ -396,6 +396,20 @@ hipError_t layout_segments(uint64_t m, const uint64_t *d_key, uint64_t max_segme
     return e;
 }
 
+// out[r] = in[lo + r] - in[lo] for r in [0, cnt]: the row offsets of a shard, from 32- or 64-bit offsets of the whole problem
+template <typename IdxT>
+__global__ __launch_bounds__(256) void k_rebase(const IdxT *__restrict__ in, uint64_t lo, uint64_t cnt1, uint64_t *__restrict__ out)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < cnt1) out[r] = (uint64_t)in[lo + r] - (uint64_t)in[lo];
+}
+hipError_t layout_rebase_row_ptr(bool idx64, const void *d_rp, uint64_t lo, uint64_t rows, uint64_t *d_out, hipStream_t s)
+{
+    if (idx64) hipLaunchKernelGGL(k_rebase<uint64_t>, dim3(blocks_of(rows + 1)), dim3(256), 0, s, (const uint64_t *)d_rp, lo, rows + 1, d_out);
+    else hipLaunchKernelGGL(k_rebase<uint32_t>, dim3(blocks_of(rows + 1)), dim3(256), 0, s, (const uint32_t *)d_rp, lo, rows + 1, d_out);
+    return hipGetLastError();
+}
+
 hipError_t layout_narrow_row_ptr(uint64_t m, const uint64_t *d_rp64, uint32_t *d_rp32, hipStream_t s)
 {
     hipLaunchKernelGGL(k_narrow, dim3(blocks_of(m + 1)), dim3(256), 0, s, m + 1, d_rp64, d_rp32);

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 #include "../../include/mmgibbs.h"
@@ -56,6 +57,7 @@ struct mmg_problem {
 };
 
 struct mmg_sampler;
+struct mmg_em;
 
 namespace mmg {
 
@@ -69,6 +71,14 @@ struct SamplerView {
     int64_t n_kept;          // samples kept so far
 };
 int sampler_view(mmg_sampler *s, SamplerView *v);
+
+// read shards of one problem as one EM (em_host.hip): make_reduce(members, ctx) returns the exchange called between the phases with
+// what = 0 (xe: max, int32), 1 (accumulators + log-likelihood limbs: sum, uint64), 2 (column counts: sum, uint64); the buffers of a
+// member come from em_exchange_buffers
+int em_create_sharded(const mmg_problem *const *shards, int n_shards, const double *mu0,
+                      std::function<int(int)> (*make_reduce)(const std::vector<mmg_em *> &, void *), void *ctx, mmg_em **ems, double *loglik0);
+void em_exchange_buffers(mmg_em *e, int what, void **ptr, size_t *count);
+int em_device(const mmg_em *e);
 
 int fail(int code, const std::string &msg);   // records the thread-local message behind mmg_last_error(), returns code
 int opt(int option);                          // mmg_selftest_option value, -1 = default

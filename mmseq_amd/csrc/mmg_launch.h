@@ -26,6 +26,7 @@ void launch_em_rows_global(bool idx64, bool measure, const void *row_ptr, const 
                            EmArgs a, hipStream_t s);
 void launch_em_colcount(const uint32_t *col, uint64_t nnz, uint64_t *cnt, unsigned grid, hipStream_t s);
 void launch_fill_i32(int32_t *p, uint32_t n, int32_t v, hipStream_t s);
+void launch_combine(void *dst, const void *src, size_t n, bool max_i32, hipStream_t s); // dst[i] += src[i] (uint64) or max (int32), one device
 void launch_em_prepare(uint32_t n, const double *mu, const double *l, const uint64_t *colcnt, const int32_t *ref, int measured,
                        uint32_t *word, uint64_t *hi, uint64_t *lo, double *partial, uint64_t *ll, const uint32_t *int_of_ext,
                        hipStream_t s);
@@ -72,6 +73,8 @@ hipError_t layout_expand_rows(uint64_t *m, uint64_t *nnz, uint64_t **d_rp, uint3
 // Start rows of the maximal runs of equal (near, band) in d_key (ascending; first entry 0).  Empty if there are more than
 // max_segments runs (rows in no useful order).
 hipError_t layout_segments(uint64_t m, const uint64_t *d_key, uint64_t max_segments, std::vector<uint64_t> &starts, hipStream_t s);
+// d_out[0..rows] = row offsets of rows [lo, lo + rows) of a stored problem, rebased to 0 (d_out on the SAME device as d_rp)
+hipError_t layout_rebase_row_ptr(bool idx64, const void *d_rp, uint64_t lo, uint64_t rows, uint64_t *d_out, hipStream_t s);
 // narrow u64 row offsets to u32 on the device
 hipError_t layout_narrow_row_ptr(uint64_t m, const uint64_t *d_rp64, uint32_t *d_rp32, hipStream_t s);
 // d_rp[0..m] = running sum of d_len[0..m)

@@ -530,6 +530,101 @@ extern "C" int mmg_problem_create(const mmg_problem_desc *d, int device, mmg_pro
     return MMG_OK;
 }
 
+// Rows [lo, hi) of a stored problem as a problem of its own on `device` -- a read shard (row_id_base = the parent's + lo) or, with
+// lo = 0 and hi = m, a replica -- cut on the parent's device and copied device to device (peer copy over xGMI): the rows, their hit
+// order and the transcript numbering stay as stored, nothing passes through the host.
+extern "C" int mmg_problem_shard(const mmg_problem *full, uint64_t lo, uint64_t hi, int device, mmg_problem **out)
+{
+    if (!full || !out) return fail(MMG_ERR_ARG, "NULL argument");
+    if (lo > hi || hi > full->m) return fail(MMG_ERR_ARG, "row range out of bounds");
+    int rc = require_device(device);
+    if (rc) return rc;
+    mmg_problem *p = new mmg_problem();
+    p->device = device;
+    p->m = hi - lo; p->n = full->n; p->row_id_base = full->row_id_base + lo; p->layout = (int)MMG_LAYOUT_KEEP_ROWS;
+    p->h_l = full->h_l;
+    p->h_int_of_ext = full->h_int_of_ext; p->h_ext_of_int = full->h_ext_of_int;
+    uint64_t *src_rp = nullptr, *d_rp64 = nullptr;
+    auto bail = [&](int code) {
+        if (src_rp) { (void)hipSetDevice(full->device); (void)hipFree(src_rp); }
+        if (d_rp64) { (void)hipSetDevice(device); (void)hipFree(d_rp64); }
+        problem_free(p);
+        return code;
+    };
+#define SH_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return bail(fail(MMG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); } while (0)
+    // the shard's row offsets, rebased on the parent's device
+    SH_TRY(hipSetDevice(full->device));
+    SH_TRY(hipMalloc((void **)&src_rp, (p->m + 1) * sizeof(uint64_t)));
+    SH_TRY(layout_rebase_row_ptr(full->idx64, full->d_row_ptr, lo, p->m, src_rp, 0));
+    uint64_t nz0 = 0, nz1 = 0;
+    if (full->idx64) {
+        SH_TRY(hipMemcpy(&nz0, (const uint64_t *)full->d_row_ptr + lo, 8, hipMemcpyDeviceToHost));
+        SH_TRY(hipMemcpy(&nz1, (const uint64_t *)full->d_row_ptr + hi, 8, hipMemcpyDeviceToHost));
+    } else {
+        uint32_t a = 0, b = 0;
+        SH_TRY(hipMemcpy(&a, (const uint32_t *)full->d_row_ptr + lo, 4, hipMemcpyDeviceToHost));
+        SH_TRY(hipMemcpy(&b, (const uint32_t *)full->d_row_ptr + hi, 4, hipMemcpyDeviceToHost));
+        nz0 = a; nz1 = b;
+    }
+    p->nnz = nz1 - nz0;
+    SH_TRY(hipSetDevice(device));
+    SH_TRY(hipMalloc((void **)&d_rp64, (p->m + 1) * sizeof(uint64_t)));
+    SH_TRY(hipMemcpyPeer(d_rp64, device, src_rp, full->device, (p->m + 1) * sizeof(uint64_t)));
+    const size_t col_bytes = (p->nnz + 16) * sizeof(uint32_t);
+    SH_TRY(hipMalloc((void **)&p->d_col, col_bytes));
+    SH_TRY(hipMemset(p->d_col, 0, col_bytes));
+    if (p->nnz) SH_TRY(hipMemcpyPeer(p->d_col, device, full->d_col + nz0, full->device, p->nnz * sizeof(uint32_t)));
+    p->device_bytes += col_bytes;
+    if (full->d_k && p->m) {
+        SH_TRY(hipMalloc((void **)&p->d_k, p->m * sizeof(uint32_t)));
+        SH_TRY(hipMemcpyPeer(p->d_k, device, full->d_k + lo, full->device, p->m * sizeof(uint32_t)));
+        p->device_bytes += p->m * 4;
+        std::vector<uint32_t> hk(p->m); // total_k of the shard (one pass over its multiplicities)
+        SH_TRY(hipMemcpy(hk.data(), p->d_k, p->m * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (uint32_t v : hk) p->total_k += v;
+    } else p->total_k = p->m;
+    SH_TRY(hipMalloc((void **)&p->d_l, p->n * sizeof(double)));
+    {
+        std::vector<double> l_int;
+        to_int(p, p->h_l.data(), l_int);
+        SH_TRY(hipMemcpy(p->d_l, l_int.data(), p->n * sizeof(double), hipMemcpyHostToDevice));
+    }
+    p->device_bytes += p->n * 8;
+    if (p->renumbered()) {
+        SH_TRY(hipMalloc((void **)&p->d_int_of_ext, p->n * 4));
+        SH_TRY(hipMalloc((void **)&p->d_ext_of_int, p->n * 4));
+        SH_TRY(hipMemcpy(p->d_int_of_ext, p->h_int_of_ext.data(), p->n * 4, hipMemcpyHostToDevice));
+        SH_TRY(hipMemcpy(p->d_ext_of_int, p->h_ext_of_int.data(), p->n * 4, hipMemcpyHostToDevice));
+        p->device_bytes += p->n * 8;
+    }
+    SH_TRY(hipSetDevice(full->device));
+    SH_TRY(hipFree(src_rp));
+    src_rp = nullptr;
+    SH_TRY(hipSetDevice(device));
+#undef SH_TRY
+    uint64_t *rp = d_rp64;
+    d_rp64 = nullptr; // consumed by problem_build
+    rc = problem_build(p, rp);
+    if (rc) return bail(rc);
+    *out = p;
+    return MMG_OK;
+}
+
+// mmg_shard_bounds on the stored rows of a problem (only the row offsets are read back)
+extern "C" int mmg_problem_shard_bounds(const mmg_problem *p, int parts, uint64_t *bounds)
+{
+    if (!p || !bounds || parts < 1) return fail(MMG_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(p->device));
+    std::vector<uint64_t> rp(p->m + 1);
+    if (p->idx64) HIP_TRY(hipMemcpy(rp.data(), p->d_row_ptr, (p->m + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    else {
+        std::vector<uint32_t> rp32(p->m + 1);
+        HIP_TRY(hipMemcpy(rp32.data(), p->d_row_ptr, (p->m + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i <= p->m; ++i) rp[i] = rp32[i];
+    }
+    return mmg_shard_bounds(rp.data(), p->m, parts, bounds);
+}
+
 extern "C" int mmg_problem_create_synthetic(const mmg_synth_desc *d, int device, mmg_problem **out)
 {
     if (!d || !out) return fail(MMG_ERR_ARG, "NULL argument");

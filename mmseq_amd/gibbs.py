@@ -75,6 +75,17 @@ class Problem:
         check(self._lib.mmg_problem_download(self._h, _ptr(rp), _ptr(ci), _ptr(k)))
         return (rp, ci, k) if with_k else (rp, ci)
 
+    def shard(self, lo, hi, device=0):
+        """Rows [lo, hi) of the stored problem as a problem of its own (mmg_problem_shard: cut and copied on the device side)."""
+        h = C.c_void_p()
+        check(self._lib.mmg_problem_shard(self._h, int(lo), int(hi), int(device), C.byref(h)))
+        return Problem(h)
+
+    def shard_bounds(self, parts):
+        b = np.empty(parts + 1, np.uint64)
+        check(self._lib.mmg_problem_shard_bounds(self._h, int(parts), _ptr(b)))
+        return b
+
     def tx_perm(self):
         out = np.empty(self.info.n, np.uint32)
         check(self._lib.mmg_problem_tx_perm(self._h, _ptr(out)))
@@ -377,6 +388,19 @@ class Summary:
             self.close()
         except Exception:
             pass
+
+
+def em_shards_selftest(shards, mu0, sweeps):
+    """mmg_selftest_em_shards: the sharded EM of mmg_group_em_create with all shards on one device (exchange by kernels).
+    Returns (mu, loglik, repeated_passes)."""
+    lib = _lib.load()
+    arr = (C.c_void_p * len(shards))(*[p._h for p in shards])
+    mu0 = np.ascontiguousarray(mu0, np.float64)
+    mu = np.empty_like(mu0)
+    ll = C.c_double(0.0)
+    rep = C.c_int(0)
+    check(lib.mmg_selftest_em_shards(arr, len(shards), _ptr(mu0), int(sweeps), _ptr(mu), C.byref(ll), C.byref(rep)))
+    return mu, ll.value, rep.value
 
 
 # ---- self-test hooks -----------------------------------------------------------------------

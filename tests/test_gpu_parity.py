@@ -388,6 +388,61 @@ def test_shards_of_a_stored_problem_with_far_rows_and_tx_order(gpu, orc):
     assert np.array_equal(parts[0] + parts[1], whole) and nz > 0
 
 
+@pytest.mark.parametrize("parts,wild", [(2, False), (3, True), (8, False)])
+def test_em_over_read_shards_equals_the_unsharded_em(gpu, orc, parts, wild):
+    """mmg_group_em_create's arithmetic on one device (mmg_selftest_em_shards: the exchange done by kernels instead of RCCL): the
+    stored rows of a problem with multiplicities and far rows cut into `parts` shards (mmg_shard_bounds), every phase of a sweep on
+    every shard, xe / accumulators / column counts exchanged -- mu, log-likelihood and the repeat decisions equal the unsharded
+    EM's bit for bit, also from start values that force passes to be repeated on measured exponents."""
+    rng = np.random.default_rng(3)
+    p, _ = orc.synth_problem(R=40000, T=3000, avg_hits=6, seed=41, sort=False, far_fraction=0.1)
+    k = rng.choice([1, 1, 1, 2, 7, 300], size=p.m).astype(np.uint32)
+    prob = gpu.Problem.from_csr(p.row_ptr, p.col_idx, p.l * 30, k=k)
+    rp, ci, kk = prob.download(with_k=True)
+    mu0, _ = prob.start_values()
+    if wild:
+        mu0[::7] *= 1e150
+        mu0[3] = 0.0
+    sweeps = 6
+    em = prob.em_stepper(mu0)
+    for _ in range(sweeps):
+        em.step()
+    want_mu, want_ll, want_rep = em.mu(), em.loglik, em.stats()["repeated_passes"]
+    em.close()
+    if wild:
+        assert want_rep >= 1
+    b = gpu.shard_bounds(rp, parts)
+    shards = []
+    for i in range(parts):
+        lo, hi = int(b[i]), int(b[i + 1])
+        a, e = int(rp[lo]), int(rp[hi])
+        if parts == 8:   # cut on the device (mmg_problem_shard), as `mmseq -gpus N` does
+            sh = prob.shard(lo, hi)
+            s_rp, s_ci, s_k = sh.download(with_k=True)
+            assert np.array_equal(s_rp, rp[lo:hi + 1] - rp[lo]) and np.array_equal(s_ci, ci[a:e]) and np.array_equal(s_k, kk[lo:hi])
+            assert sh.info.row_id_base == lo and sh.info.layout == 1 and sh.info.total_k == int(kk[lo:hi].astype(np.int64).sum())
+            shards.append(sh)
+        else:
+            shards.append(gpu.Problem.from_csr(rp[lo:hi + 1] - rp[lo], ci[a:e], prob.l(), k=kk[lo:hi], row_id_base=lo, keep_rows=True))
+    assert np.array_equal(prob.shard_bounds(parts), b)
+    mu, ll, rep = gpu.em_shards_selftest(shards, mu0, sweeps)
+    # the Gibbs counts of the shards add up to the unsharded sweep's
+    s = gpu.Sampler(prob, mu0 + 1e-3, seed=3, gibbs_iter=1, trace_len=1)
+    s.sample()
+    tot = np.zeros(prob.info.n, np.int64)
+    for sh in shards:
+        ss = gpu.Sampler(sh, mu0 + 1e-3, seed=3, gibbs_iter=1, trace_len=1)
+        ss.sample()
+        tot += ss.counts(0)
+        ss.close()
+    assert np.array_equal(tot, s.counts(0).astype(np.int64))
+    s.close()
+    assert np.array_equal(mu, want_mu, equal_nan=True) and ll == want_ll and rep == want_rep
+    for sh in shards:
+        sh.close()
+    prob.close()
+
+
 def test_chains_and_shards_reproduce_single_chain(gpu, orc):
     """(a) chain c of a multi-chain sampler == a single-chain sampler with chain_base=c;
     (b) read-sharding: two shards' counts summed (the all-reduce) == the unsharded chain."""
