@@ -10,16 +10,18 @@ run and reported in the `extra` block of the same JSON line.
 HIP events bracket K1 and K2 on every --time-every-th step INSIDE the timed region, on the stream the kernels are launched on
 (default 4: an event pair costs about 9 us of stream time); roofline.avg_launch_ms is the mean over those launches.
 
-roofline (K1 = k_sample_sell, the dominant kernel):
-  bound        "valu": the kernel is bound by VALU issue, not by HBM (profiles/*_sq_counters.md)
-  achieved     wave-level VALU issue passes per second = counted passes per launch / avg_launch_ms, passes = SQ_INSTS_VALU + 3 per
-               quarter-rate instruction (the v_mad_u64_u32 of Philox), from the committed PMC pass of this exact kernel build
-               (profiles/pmc_counters.json, stamped with a hash of the kernel sources; null if the sources changed since)
-  peak         1024 SIMDs x 2.4 GHz / 4 clocks per wave64 instruction = 614.4 G passes/s
-  frac         achieved / peak  (<= 1 by construction)
-  traffic      HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes (same file); hbm_frac = traffic / time / 8 TB/s
-  algorithmic_x_peak   SURVEY 8(d)'s figure: bytes of the u32 CSR / time / 8 TB/s.  The kernel streams a 1.1 byte-per-hit encoding of
-               that CSR, so this exceeds 1 -- it says how much faster than a CSR-streaming kernel at the HBM roofline this is.
+roofline (K1 = k_sample_sell, the dominant kernel; the same block for the chain-pair kernel and the EM kernel in `roofline_other`):
+  bound        "hbm".  K1 is bound by the stream it reads: with the same stream served from the caches it runs 21 % faster
+               (DESIGN.md section 4), and the instruction side (VALU issue) sits right behind it
+  traffic      HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes of this exact kernel build (profiles/pmc_counters.json,
+               written by tools/pmc_summary.py, stamped with a hash of the kernel sources and build flags; null if they changed since)
+  achieved     traffic / avg_launch_ms in GB/s;  peak 8000 GB/s (MI355X_MICROARCH.md);  frac = hbm_counter_frac = achieved / peak
+  pattern_read_peak_gbs   what a pure read with K1's access pattern reaches on this part (tools/stream_bench.hip: 6.5-6.7 TB/s)
+  algorithmic_x_peak      SURVEY 8(d)'s figure: bytes of the u32 CSR / time / 8 TB/s.  The kernel streams a 1.1 byte-per-hit encoding of
+               that CSR, so this exceeds 1 -- it says how much faster than a CSR-streaming kernel at the HBM roofline this is
+  valu         counted VALU instructions x 4.3 clocks (tools/issue_bench.hip: what a wave64 VALU instruction of K1's mix occupies its
+               SIMD for) / (1024 SIMDs x effective clock x time); effective_clock_ghz = GRBM_GUI_ACTIVE / 8 XCDs / time
+  lds          SQ_LDS_IDX_ACTIVE / 256 CUs / kernel cycles
 
   python bench.py --gpus 1 --steps 256 --warmup 16
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -37,35 +39,76 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-VALU_PEAK_GPASS = 1024 * 2.4 / 4   # 256 CUs x 4 SIMDs, 2.4 GHz, a wave64 VALU instruction occupies its SIMD for 4 clocks
-KERNEL_SOURCES = ["mmg_math.h", "mmg_types.h", "gibbs_kernels.h", "sell_kernels.h", "k1.hip"]
+PATTERN_READ_PEAK_GBS = 6600.0   # tools/stream_bench.hip on MI355X: single-wave workgroups reading contiguous ranges of 1.5 KB blocks
+VALU_CLOCKS_PER_INST = 4.3   # tools/issue_bench.hip (profiles/r03_issue_bench.txt): VOP3 / fp64 / compare / SDWA / 32-bit multiply
+                             # instructions occupy their SIMD for 4.2-4.5 clocks per wave64 instruction, and in a mixed stream the
+                             # cheap VOP1 / VOP2 class (2.3-2.9 clocks alone) costs the same; v_mad_u64_u32 5.1
+# everything that decides what the kernels do and how they are launched: sources of the device code, the host code that lays the
+# problem out and picks grids and ranges, and the build flags
+KERNEL_SOURCES = ["mmg_math.h", "mmg_types.h", "gibbs_kernels.h", "sell_kernels.h", "sell_multi_kernels.h", "em_kernels.h", "k1.hip", "em.hip",
+                  "mmgibbs.hip", "sampler.hip", "em_host.hip", "layout.hip", "Makefile"]
 
 
 def kernel_hash():
-    """Hash of the K1 kernel sources with comments and white space removed (what the compiler sees)."""
+    """Hash of the kernel and launch-geometry sources with comments and white space removed (what the compiler sees) + the Makefile."""
     import re
     h = hashlib.sha256()
     for f in KERNEL_SOURCES:
         src = open(os.path.join(ROOT, "mmseq_amd", "csrc", f)).read()
-        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-        src = re.sub(r"//[^\n]*", "", src)
+        if f != "Makefile":
+            src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+            src = re.sub(r"//[^\n]*", "", src)
         h.update(re.sub(r"\s+", "", src).encode())
     return h.hexdigest()[:16]
 
 
-def pmc_counters(rows, transcripts, avg_hits, chains, kernel):
-    """Counters per K1 launch from the committed rocprofv3 PMC passes of this same workload AND this same kernel build
-    (profiles/pmc_counters.json, written by tools/pmc_summary.py: FETCH_SIZE / WRITE_SIZE / SQ passes collected separately, FETCH
-    doubled per the gfx950 correction).  PMC counters cannot be collected from inside this process; any mismatch gives None."""
+def pmc_entry(entry):
+    """Counters per launch of one kernel from the committed rocprofv3 PMC passes of this same kernel build (profiles/pmc_counters.json,
+    written by tools/pmc_summary.py: FETCH_SIZE / WRITE_SIZE / SQ passes collected separately, FETCH doubled per the gfx950
+    correction).  PMC counters cannot be collected from inside this process; a stale stamp gives None."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "pmc_counters.json")))
-        w = d["workload"]
-        if (w["rows"], w["transcripts"], w["avg_hits"], w["chains"]) == (rows, transcripts, avg_hits, chains) \
-                and d["kernel"] == kernel and d["kernel_sources_sha16"] == kernel_hash():
-            return d
+        if d["kernel_sources_sha16"] == kernel_hash():
+            return d["entries"].get(entry)
     except Exception:
         pass
     return None
+
+
+def roofline_block(kernel_name, entry, t_s, launches, n_tiles, stream_bytes=None, algorithmic_bytes=None):
+    """The roofline object of one kernel: t_s = average launch duration in seconds (HIP events in this run), PMC figures from `entry`."""
+    pmc = pmc_entry(entry)
+    c = (pmc or {}).get("counters_per_launch", {})
+    traffic = ((pmc["hbm_read_bytes_per_launch"] or 0) + (pmc["hbm_write_bytes_per_launch"] or 0)) if pmc and pmc.get("hbm_read_bytes_per_launch") else None
+    ach = traffic / t_s / 1e9 if traffic else None
+    clk = c.get("GRBM_GUI_ACTIVE")
+    # effective clock of the profiled pass: its GRBM_GUI_ACTIVE (summed over the 8 XCDs) / its own mean kernel duration
+    dur = (pmc or {}).get("duration_ns_in_the_grbm_pass")
+    clock_ghz = clk / 8.0 / dur if clk and dur else None
+    valu = c.get("SQ_INSTS_VALU")
+    out = {"bound": "hbm", "kernel": kernel_name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic, "hbm_counter_frac": (ach / HBM_PEAK_GBS) if ach else None,
+           "pattern_read_peak_gbs": PATTERN_READ_PEAK_GBS, "frac_of_pattern_peak": (ach / PATTERN_READ_PEAK_GBS) if ach else None,
+           "avg_launch_ms": t_s * 1e3, "timed_launches": launches,
+           "effective_clock_ghz": clock_ghz,
+           "valu": ({"insts_per_launch": valu, "clocks_per_inst": VALU_CLOCKS_PER_INST,
+                     "busy_frac": valu * VALU_CLOCKS_PER_INST / (1024 * (clk / 8.0))} if valu and clk else None),
+           "lds": ({"busy_frac": c["SQ_LDS_IDX_ACTIVE"] / 256.0 / (clk / 8.0),
+                    "bank_conflict_frac_of_lds_cycles": c.get("SQ_LDS_BANK_CONFLICT", 0) / max(c["SQ_LDS_IDX_ACTIVE"], 1)}
+                   if c.get("SQ_LDS_IDX_ACTIVE") and clk else None),
+           "wave_cycles": ({"at_s_waitcnt": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], "waiting_to_issue": c.get("SQ_WAIT_INST_ANY", 0) / c["SQ_WAVE_CYCLES"]}
+                           if c.get("SQ_WAIT_ANY") and c.get("SQ_WAVE_CYCLES") else None),
+           "instructions_per_64_row_tile": ({k[9:].lower(): round(v / max(n_tiles, 1), 1) for k, v in c.items()
+                                             if k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_INSTS_SMEM")}
+                                            if c and n_tiles else None),
+           "pmc_source": (pmc or {}).get("source")}
+    if stream_bytes is not None:
+        out["stream_bytes_per_launch"] = stream_bytes
+        out["stream_frac_of_peak"] = stream_bytes / t_s / 1e9 / HBM_PEAK_GBS
+    if algorithmic_bytes is not None:
+        out["algorithmic_bytes_per_launch"] = algorithmic_bytes
+        out["algorithmic_x_peak"] = algorithmic_bytes / t_s / 1e9 / HBM_PEAK_GBS
+    return out
 
 
 def cpu_quota():
@@ -166,6 +209,27 @@ def side_measurement(name, rows, transcripts, avg_hits, chains=1, uniform=False,
     if note:
         out["note"] = note
     smp.close()
+    prob.close()
+    return out
+
+
+def em_measurement(rows, transcripts, avg_hits, seed=1234, device=0, sweeps=20):
+    """EM sweeps (src/mmseq.cpp:761-806) on the config-3 problem: wall time per sweep of mmg_em_step (the rows pass k_em_sell plus the
+    per-transcript kernels and one read-back of the log-likelihood)."""
+    import torch
+    from mmseq_amd import Problem
+    prob = Problem.synthetic(rows, transcripts, avg_hits, seed=seed, mapped_reads=rows, device=device)
+    mu0, _ = prob.start_values()
+    em = prob.em_stepper(mu0)
+    for _ in range(3):
+        em.step()
+    t0 = time.perf_counter()
+    for _ in range(sweeps):
+        em.step()
+    ms = (time.perf_counter() - t0) / sweeps * 1e3
+    out = {"name": "EM sweep, 50M x 200k", "ms_per_sweep": ms, "sweeps": sweeps, "stream_kernel": em.stats_raw()["stream_kernel"],
+           "n_tiles": prob.info.n_tiles, "stream_bytes": prob.info.stream_bytes}
+    em.close()
     prob.close()
     return out
 
@@ -293,19 +357,26 @@ def main():
         chains_total = C * (world if args.mode == "chains" else 1)
         iters_per_s = chains_total * args.steps / elapsed
         reads_per_chain = total_reads
-        k1_ms = tm["sample_ms"] / max(tm["sample_launches"], 1) / C   # per launch (chains are advanced by one launch each)
+        k1_ms = tm["sample_ms"] / max(tm["sample_launches"], 1) / C   # per chain: the sample() call of C chains / C
         k2_ms = tm["update_ms"] / max(tm["update_launches"], 1)
         # algorithmic bytes of one K1 launch (one GPU, one chain): u32 row_ptr + u32 col_idx streamed once, fp64 mu read + int32
         # count write (SURVEY 8d / DESIGN.md section 4)
         b_k1 = 4 * (inf.m + 1) + 4 * inf.nnz + 12 * inf.n
         b_sweep = 4 * (inf.m + 1) + 4 * inf.nnz + 28 * C * inf.n
         kname = {0: "k_sample", 2: "k_sample_sell"}[inf.sample_kernel]
-        pmc = pmc_counters(args.rows, args.transcripts, args.avg_hits, 1, kname)
         t_k1 = k1_ms * 1e-3
-        traffic = (pmc["hbm_read_bytes_per_launch"] + pmc["hbm_write_bytes_per_launch"]) if pmc else None
-        # VALU issue passes: every instruction one pass, the quarter-rate Philox multiplies three more (5 per register-path tile)
-        passes = (pmc["valu_insts_per_launch"] + 3 * pmc["quarter_rate_valu_per_fast_tile"] * inf.fast_tiles) if pmc and "valu_insts_per_launch" in pmc else None
-        ach = passes / t_k1 / 1e9 if passes else None
+        # chains > 1: one event pair brackets the whole sample() call -- pair launches plus the launches for the other tile lists;
+        # per-kernel PMC figures belong to the 1-chain run only (roofline_other carries the pair kernel's own block)
+        roof = roofline_block(kname + " (K1)", "k1_1chain" if C == 1 else "none", t_k1, tm["sample_launches"], inf.n_tiles,
+                              stream_bytes=inf.stream_bytes, algorithmic_bytes=b_k1)
+        roof["padded_slots_per_hit"] = (inf.padded_slots / inf.nnz) if inf.nnz else None
+        roof["k_update_avg_launch_ms"] = k2_ms
+        roof["sweep_bytes"] = b_sweep
+        roof["note"] = ("HBM: traffic / time against the 8 TB/s peak (and against the 6.6 TB/s a pure read with this access pattern reaches); "
+                        "valu.busy_frac = counted VALU instructions x 4.3 clocks / SIMD cycles; algorithmic_x_peak = SURVEY 8(d) u32-CSR bytes / "
+                        "time / 8 TB/s (> 1: the kernel streams a 1.1 B/hit encoding, not the CSR).  PMC figures are null when "
+                        "profiles/pmc_counters.json was collected on other kernel sources, and at chains > 1 (avg_launch_ms is then the "
+                        "sample() call of all chains divided by the chains)")
         out = {
             "metric": "gibbs_iterations_per_sec", "value": iters_per_s, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -323,24 +394,7 @@ def main():
                        "clock_settle_iters_before_warmup": args.settle_iters,
                        "cold_ms_per_step_first_64_iterations_after_start": cold_ms},
             "reads_iters_per_sec": iters_per_s * reads_per_chain,
-            "roofline": {"bound": "valu", "kernel": kname + " (K1)", "achieved": ach, "peak": VALU_PEAK_GPASS,
-                         "unit": "G wave-level VALU issue passes/s", "frac": (ach / VALU_PEAK_GPASS) if ach else None,
-                         "traffic": traffic, "hbm_frac": (traffic / t_k1 / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         "algorithmic_bytes_per_launch": b_k1, "algorithmic_x_peak": b_k1 / t_k1 / 1e9 / HBM_PEAK_GBS,
-                         "stream_bytes_per_launch": inf.stream_bytes, "stream_frac_of_peak": inf.stream_bytes / t_k1 / 1e9 / HBM_PEAK_GBS,
-                         "padded_slots_per_hit": (inf.padded_slots / inf.nnz) if inf.nnz else None,
-                         "avg_launch_ms": k1_ms, "timed_launches": tm["sample_launches"] * C,
-                         "valu_issue_passes_per_launch": passes,
-                         "instructions_per_64_row_tile": ({k[9:].lower(): round(v / max(inf.n_tiles, 1), 1) for k, v in pmc["counters_per_launch"].items()
-                                                           if k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_INSTS_SMEM")}
-                                                          if pmc else None),
-                         "pmc_source": (pmc or {}).get("source"),
-                         "note": "bound by instruction issue, not by HBM: a wave issues one instruction per 4-clock slot and a 64-row tile "
-                                 "costs ~140 VALU + ~150 scalar/branch + ~30 LDS instructions; frac = counted VALU issue passes / "
-                                 "(1024 SIMDs x 2.4 GHz / 4) / time; hbm_frac = PMC HBM bytes / time / 8 TB/s; algorithmic_x_peak = SURVEY "
-                                 "8(d) u32-CSR bytes / time / 8 TB/s (> 1: the kernel streams a 1.1 B/hit encoding, not the CSR).  PMC "
-                                 "figures are null when profiles/pmc_counters.json was collected on other kernel sources",
-                         "k_update_avg_launch_ms": k2_ms, "sweep_bytes": b_sweep},
+            "roofline": roof,
         }
         if world == 1 and not args.no_extra:
             prob.close()
@@ -366,6 +420,31 @@ def main():
                     extra.append({"name": kw["name"], "error": repr(e)})
                 torch.cuda.empty_cache()
             out["extra"] = extra
+            # the same roofline object for the two other hot kernels: the chain-pair kernel (BASELINE configs[2]) and the EM rows pass
+            other = []
+            c3 = next((e for e in extra if e.get("name", "").startswith("config 3") and "error" not in e), None)
+            if c3:
+                tiles = inf.n_tiles
+                rb = roofline_block("k_sample_sell_multi<2> (K1m: one launch advances two chains)", "k1m_8chains",
+                                    c3["k1_avg_launch_ms_all_chains"] * 1e-3 / (c3["chains"] // 2), (c3["chains"] // 2) * (c3["steps"] // 4 + 1), tiles,
+                                    stream_bytes=c3["stream_bytes"], algorithmic_bytes=4 * (c3["reads"] + 1) + 4 * c3["hits"] + 24 * c3["transcripts"])
+                rb["chain_iterations_per_sec"] = c3["chain_iterations_per_sec"]
+                rb["bound"] = "valu"
+                rb["note"] = ("the stream is read once per PAIR of chains: 3.4 TB/s of HBM traffic, not the bound; valu.busy_frac (counted VALU instructions x 4.3 "
+                              "clocks / SIMD cycles) and lds.busy_frac are -- see DESIGN.md section 4 for the instruction budget per tile")
+                other.append(rb)
+            try:
+                em = em_measurement(R3, T3, H3, seed=args.seed, device=local_rank)
+                rb = roofline_block("k_em_sell (K3: rows pass of one EM sweep)", "em_sweep", em["ms_per_sweep"] * 1e-3, em["sweeps"], em["n_tiles"],
+                                    stream_bytes=em["stream_bytes"])
+                rb["bound"] = "valu"
+                rb["note"] = ("avg_launch_ms is the wall time of one mmg_em_step (rows pass + per-transcript kernels + one read-back); bound by the "
+                              "fixed-point arithmetic per hit (valu.busy_frac), then by its LDS atomics (two 64-bit adds per hit, lds.busy_frac)")
+                other.append(rb)
+            except Exception as e:
+                other.append({"kernel": "k_em_sell", "error": repr(e)})
+            torch.cuda.empty_cache()
+            out["roofline_other"] = other
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, total_reads)
             out["speedup_vs_cpu_baseline"] = iters_per_s / out["cpu_baseline"]["value"]

@@ -242,6 +242,9 @@ typedef struct mmg_summary_desc {
     const int32_t *percentile_index;
 } mmg_summary_desc;
 enum { MMG_SERIES_TRANSCRIPT = 0, MMG_SERIES_VIRTUAL = 1, MMG_SERIES_IDENTICAL = 2, MMG_SERIES_GENE = 3 };
+/* LIMIT: the per-series kernel sorts and Fourier-transforms a series in LDS and exists for trace_len <= 2048 (the reference's
+ * trace length is 1024, src/mmseq.cpp:190); a sampler with a longer trace is refused here with MMG_ERR_ARG -- callers that want the
+ * summary keep trace_len <= 2048 (mmg_sampler_get_trace / _get_moments serve longer traces). */
 int mmg_summary_create(mmg_sampler *s, const mmg_summary_desc *d, mmg_summary **out);
 /* Per series of `kind` (n, n_virtual, n_identical or n_genes of them): mean of the logged trace, Sokal's var and tau of the
  * logged trace with its return code (0; 200 / 201 when trace_len is no power of two >= 4: var = tau = 0), and the

@@ -143,7 +143,7 @@ private:
                 if (rc == Z_STREAM_END) { end = true; break; }
                 if (rc != Z_OK && rc != Z_BUF_ERROR) {
                     std::cerr << "Error decompressing hits file (zlib error " << rc << ").\n";
-                    std::exit(1);
+                    hits_die();
                 }
             }
             sl.len = SLAB - zs.avail_out;
@@ -179,7 +179,7 @@ public:
             std::memset(&zs, 0, sizeof zs);
             if (deflateInit(&zs, Z_BEST_SPEED) != Z_OK) { // zlib::best_speed, src/hitsio.cpp:127
                 std::cerr << "Error initialising zlib.\n";
-                std::exit(1);
+                hits_die();
             }
         }
     }
@@ -196,7 +196,7 @@ public:
     {
         if (v > std::numeric_limits<uint32_t>::max()) {
             std::cerr << "Numeric value overflow when writing the hits file" << std::endl; // src/hitsio.cpp:24-27
-            std::exit(1);
+            hits_die();
         }
         unsigned char b[4] = {(unsigned char)v, (unsigned char)(v >> 8), (unsigned char)(v >> 16), (unsigned char)(v >> 24)};
         write(b, 4);
@@ -325,7 +325,7 @@ void HitsfileWriter::addReadMapRecord(std::string readName) { currentReadName = 
 void HitsfileWriter::addTranscriptToReadMapRecord(std::string name) { currentReadTranscripts.push_back(name); }
 void HitsfileWriter::addTranscriptIndexToReadMapRecord(uint32_t index)
 {
-    if (index >= transcriptName.size()) { std::cerr << "Error: transcript index " << index << " not in the header.\n"; std::exit(1); }
+    if (index >= transcriptName.size()) { std::cerr << "Error: transcript index " << index << " not in the header.\n"; hits_die(); }
     currentReadIndices.push_back(index);
 }
 
@@ -367,7 +367,7 @@ HitsfileReader::HitsfileReader(std::string fileName) : hitsfileSchema(-1), count
         ByteSource probe(fileName, ok);
         if (!ok) {
             std::cerr << "Error reading hits file \"" << fileName << "\".\n"; // src/hitsio.cpp:252-255
-            std::exit(1);
+            hits_die();
         }
         // schema detection from the first line, src/hitsio.cpp:263-276
         std::string line;
@@ -384,13 +384,13 @@ HitsfileReader::HitsfileReader(std::string fileName) : hitsfileSchema(-1), count
         }
         if (hitsfileSchema < 0 || hitsfileSchema > 4) {
             std::cerr << "Input file \"" << fileName << "\" does not seem to be a hits file.\n";
-            std::exit(1);
+            hits_die();
         }
     }
     src.reset(new ByteSource(fileName, ok)); // reopen from the start, src/hitsio.cpp:277-284
     if (!ok) {
         std::cerr << "Error reading hits file \"" << fileName << "\".\n";
-        std::exit(1);
+        hits_die();
     }
 }
 HitsfileReader::~HitsfileReader() {}
@@ -428,7 +428,7 @@ void HitsfileReader::readHeaderSchema0(std::vector<std::string> *transcriptName,
             identicalTranscripts->push_back(tids);
         } else {
             std::cerr << "Hits file looks malformed.\n"; // src/hitsio.cpp:324-327
-            std::exit(1);
+            hits_die();
         }
     }
 }
@@ -440,7 +440,7 @@ void HitsfileReader::readHeaderSchema1(std::vector<std::string> *transcriptName,
     std::string s, s2;
     uint32_t v = 0, n = 0;
     auto need = [&](bool ok) {
-        if (!ok) { std::cerr << "Hits file looks malformed.\n"; std::exit(1); }
+        if (!ok) { std::cerr << "Hits file looks malformed.\n"; hits_die(); }
     };
     need(src->getline(s)); // "MMSEQ_HITSFILE"
     need(src->readU32(v)); // schema
@@ -480,7 +480,7 @@ void HitsfileReader::readHeader(std::vector<std::string> *a, std::map<std::strin
 {
     if (hitsfileSchema == 0) readHeaderSchema0(a, b, c, d, e);
     else if (hitsfileSchema == 1) readHeaderSchema1(a, b, c, d, e);
-    else { std::cerr << "We should never get to this state!\n"; std::exit(1); }
+    else { std::cerr << "We should never get to this state!\n"; hits_die(); }
 }
 
 bool HitsfileReader::readReadMapRecordReadID(std::string &readID)
@@ -488,7 +488,7 @@ bool HitsfileReader::readReadMapRecordReadID(std::string &readID)
     if (hitsfileSchema == 0) {
         if (src->atEnd()) return false;
         src->getline(readID);
-        if (readID.empty() || readID[0] != '>') { std::cerr << "Hits file looks malformed.\n"; std::exit(1); }
+        if (readID.empty() || readID[0] != '>') { std::cerr << "Hits file looks malformed.\n"; hits_die(); }
         readID = readID.substr(1);
         if (src->atEnd()) { // src/hitsio.cpp:336-340
             std::cerr << "Warning: read record without any mapping transcripts found"
@@ -512,7 +512,7 @@ bool HitsfileReader::readReadMapRecordReadID(std::string &readID)
         if (!small(nBeg)) return false;
         if (!src->getline(s)) return false;
         if (!small(nEnd)) return false;
-        if (nBeg > deltaBuffer.size() || nEnd > deltaBuffer.size()) { std::cerr << "Hits file looks malformed.\n"; std::exit(1); }
+        if (nBeg > deltaBuffer.size() || nEnd > deltaBuffer.size()) { std::cerr << "Hits file looks malformed.\n"; hits_die(); }
         s = deltaBuffer.substr(0, nBeg) + s + deltaBuffer.substr(deltaBuffer.size() - nEnd, nEnd);
     }
     deltaBuffer = s;
@@ -570,6 +570,8 @@ bool HitsfileReader::readReadMapRecordTranscriptIndices(std::vector<uint32_t> &o
     }
     const size_t n = countReadMapRecord, at = out.size();
     if (n == 0) return true;
+    // a record cannot name more transcripts than the header has (distinct indices): a corrupt count must not become a 16 GB allocation
+    if (n > headerTranscriptName.size()) { std::cerr << "Hits file looks malformed.\n"; hits_die(); }
     out.resize(at + n);
     unsigned char *raw = (unsigned char *)(out.data() + at); // decoded in place: 4 little-endian bytes per index
     if (!src->read(raw, n * 4)) { out.resize(at); countReadMapRecord = 0; return false; }
@@ -589,7 +591,7 @@ bool HitsfileReader::readReadMapRecordTranscriptID(std::string &transcriptID)
     }
     uint32_t v = 0;
     if (!readReadMapRecordTranscriptIndex(v)) return false;
-    if (v >= headerTranscriptName.size()) { std::cerr << "Hits file looks malformed.\n"; std::exit(1); }
+    if (v >= headerTranscriptName.size()) { std::cerr << "Hits file looks malformed.\n"; hits_die(); }
     transcriptID = headerTranscriptName[v];
     return true;
 }

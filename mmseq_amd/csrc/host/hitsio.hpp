@@ -15,6 +15,12 @@
 #include <memory>
 #include <string>
 #include <vector>
+#include <cstdlib>
+#include <iostream>
+
+// Fatal input errors leave through here: the readers run on pipeline threads of the CLI, where std::exit would run static
+// destructors and stream flushes under threads that are still working.  Flush what was said, leave without unwinding.
+[[noreturn]] inline void hits_die() { std::cerr.flush(); std::cout.flush(); std::_Exit(1); }
 
 #define MMSEQ_HEADER "MMSEQ_HITSFILE"
 

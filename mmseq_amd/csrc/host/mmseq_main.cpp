@@ -90,10 +90,14 @@ static int powerof2(unsigned int x)
     return (x == 1);
 }
 
+// the background writer of .k / .M (if any) finishes its files before the process leaves on a device error: the reference has
+// written both by then (src/mmseq.cpp:682-695), and exit() must not run under a thread that is still formatting
+static std::thread *g_background_writer = nullptr;
 #define MMG_TRY(expr)                                                                     \
     do {                                                                                  \
         if ((expr) != 0) {                                                                \
             cerr << "Error: " << mmg_last_error() << " (" << #expr << ")" << endl;         \
+            if (g_background_writer && g_background_writer->joinable()) g_background_writer->join(); \
             exit(1);                                                                      \
         }                                                                                 \
     } while (0)
@@ -536,7 +540,7 @@ int main(int argc, char **argv)
                     const uint32_t hidx = x;
                     if (hidx >= nHeader) {
                         cerr << "Error: a read maps to a transcript that has no @TranscriptMetaData entry (no length).\n";
-                        exit(1);
+                        hits_die(); // (a pipeline thread: no static destructors under the other threads)
                     }
                     if (hdr2obs[hidx] < 0) {
                         hdr2obs[hidx] = (int32_t)obs2hdr.size(); obs2hdr.push_back(hidx);
@@ -721,9 +725,11 @@ int main(int argc, char **argv)
     }
 
     stage.mark("unique hits (sets, genes)");
-    // ---- .k and .M (src/mmseq.cpp:682-695)
+    // ---- .k and .M (src/mmseq.cpp:682-695): 14 GB of text at 50 M reads, written by a thread of its own while the device builds the
+    //      problem and runs EM and Gibbs (the arrays it reads are not touched again; joined before the run ends)
     ofstream ofs;
-    {   // integer tables: chunks of rows formatted in parallel (to_chars), written in order
+    std::thread km_writer([&, m, n]() {   // integer tables: chunks of rows formatted in parallel (to_chars), written in order
+        ofstream ofs;
         auto write_rows = [&](ofstream &o, const function<void(uint64_t, string &)> &fmt) {
             const uint64_t chunk = 1u << 16;
             const int64_t nchunks = (int64_t)((m + chunk - 1) / chunk);
@@ -756,7 +762,9 @@ int main(int argc, char **argv)
             for (uint64_t j = row_ptr[i]; j < row_ptr[i + 1]; ++j) { put(o, i, '\t'); put(o, col_idx[j], '\n'); }
         });
         ofs.close(); ofs.clear();
-    }
+    });
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } km_join{km_writer};
+    g_background_writer = &km_writer;
 
     if (debug) { // src/mmseq.cpp:697-731
         ofs.open((output_base + ".sharedcounts").c_str());
@@ -783,7 +791,7 @@ int main(int argc, char **argv)
         ofs.close(); ofs.clear();
     }
 
-    stage.mark("write .k .M");
+    stage.mark("start the .k .M writer");
     // ---- device problem.  Rows go up in first-seen order and observed-transcript numbering, exactly as src/mmseq.cpp:399-418 builds
     //      them; the library stores the rows in its own canonical order and -- given tx_order -- numbers the transcripts gene by gene
     //      (header order, the isoforms of a gene adjacent: the sample kernel keeps a window of consecutive transcripts in LDS and
@@ -1224,6 +1232,8 @@ int main(int argc, char **argv)
              << "  " << output_base << ".dupIDs" << endl;
     }
     stage.mark("write tables");
+    if (km_writer.joinable()) km_writer.join();
+    stage.mark("wait for the .k .M writer");
     stage.total();
     return 0;
 }

@@ -19,6 +19,10 @@ constexpr uint32_t K_SMALL = MMG_K_SMALL;   // rows with k <= K_SMALL draw k cat
 // Rows are exchangeable in the model (src/mmseq.cpp:857-891 visits them in file order only because that is how they were
 // read), and a row is a SET of transcripts (the reference walks it in ascending order, :871).  The library puts every row's hits in
 // ascending order and stores the rows sorted by row_key, ties by the tie word below, then by the caller's position.
+//   step 0  a row with 2 <= k <= K_SMALL is stored as k rows with k = 1 (layout.hip: layout_expand_rows): identical reads -- what every
+//           collapsed hits file carries (src/mmseq.cpp:409-418) -- then run on the register path and in fused chain pairs like any
+//           other read, instead of through the multiplicity kernel (50M-read file shape: 0.39 -> 0.34 ms per sweep, 8 chains 2.5k ->
+//           4.0k chain-iterations/s); an all-ones k array is dropped.  Rows with k > K_SMALL (conditional-binomial chain) and k = 0 stay.
 //   lead    = smallest transcript of the row >> LAYOUT_BAND_SHIFT       (bands of 64 consecutive transcripts)
 //   near    = every hit of the row lies in [lead * 64, lead * 64 + LAYOUT_NEAR_SPAN) and the row has <= 255 hits
 //   band    = lead for a near row; for a far row its HOME band: max(median hit >> LAYOUT_BAND_SHIFT, 1) - 1 (lower median,

@@ -1,7 +1,7 @@
 #!/bin/bash
 # End-to-end run of the drop-in CLI on a 50 M-read hits FILE (GPU box): synth_hits writes the benchmark workload (config 3 shape) as a
 # binary hits file, mmseq reads it, collapses, runs EM + 1024 Gibbs iterations and writes every output.  Stage timings to stdout.
-#   tools/cli_scale_50m.sh [ROWS [TRANSCRIPTS [AVG [FAR]]]]
+#   [ITER=16384] tools/cli_scale_50m.sh [ROWS [TRANSCRIPTS [AVG [FAR]]]]      (ITER: -gibbs_iter, default 1024; the reference default is 16384)
 set -u
 R=${1:-50000000}; T=${2:-200000}; A=${3:-20}; F=${4:-0.0}
 D=$(mktemp -d /tmp/mmseq_scale.XXXXXX)
@@ -13,10 +13,10 @@ echo "synth_hits: $(( (t1 - t0) / 1000000 )) ms, file $(stat -c %s $D/in.hits) b
 if [ -n "${PROFILE:-}" ]; then   # PROFILE=<dir under gpurun_out>: the same run under rocprofv3 --kernel-trace --stats
   export MMSEQ_TIMING=1
   REPO=$(pwd)
-  (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/$PROFILE -- $BIN/mmseq -gibbs_iter 1024 $D/in.hits $D/out > $D/stdout.log 2> $D/stderr.log)
+  (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/$PROFILE -- $BIN/mmseq -gibbs_iter ${ITER:-1024} $D/in.hits $D/out > $D/stdout.log 2> $D/stderr.log)
   rc=$?
 else
-  MMSEQ_TIMING=1 $BIN/mmseq -gibbs_iter 1024 $D/in.hits $D/out > $D/stdout.log 2> $D/stderr.log
+  MMSEQ_TIMING=1 $BIN/mmseq -gibbs_iter ${ITER:-1024} $D/in.hits $D/out > $D/stdout.log 2> $D/stderr.log
   rc=$?
 fi
 t2=$(date +%s%N)
