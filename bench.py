@@ -138,11 +138,14 @@ def cpu_baseline(args, total_reads):
     # the reference's per-thread count slabs (src/mmseq.cpp:850-855, :896-899) stop scaling at high thread
     # counts: probe a few and time the best one, so the baseline is the strongest this host offers.  A container's CPU quota
     # (16 CPUs' worth on the 256-core GPU boxes here) is a candidate of its own: more threads than that are throttled.
-    cands = sorted({t for t in (ncpu, ncpu // 2, 64, 32, 16, 8, 1, quota or 1, 2 * (quota or 1)) if 1 <= t <= ncpu}, reverse=True)
+    # (thread counts far above a quota are throttled erratically: a 2-iteration probe once picked 128 threads on a 16-CPU quota and the
+    # timed run then crawled; with a quota the candidates stop at twice its size and the probe runs 4 iterations)
+    cands = sorted({t for t in (ncpu, ncpu // 2, 64, 32, 16, 8, 1, quota or 1, 2 * (quota or 1))
+                    if 1 <= t <= ncpu and (quota is None or t <= 2 * quota)}, reverse=True)
     best_t, best_rate = 1, 0.0
     for t in cands:
-        r = B.gibbs_ref(p, mu0, seed=args.seed, n_iter=2, trace_len=2, threads=t, want_trace=False)
-        rate = Rs * 2 / r["seconds"]
+        r = B.gibbs_ref(p, mu0, seed=args.seed, n_iter=4, trace_len=4, threads=t, want_trace=False)
+        rate = Rs * 4 / r["seconds"]
         if rate > best_rate:
             best_t, best_rate = t, rate
     threads = best_t

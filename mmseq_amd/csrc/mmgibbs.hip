@@ -103,6 +103,7 @@ void mmg::weighted_chunks(const std::vector<uint64_t> &cum, uint64_t grid, std::
     chunk[grid] = nt;
 }
 // tile costs for the ranges of the persistent workgroups, in halves of a register-path tile (measured, tools/k1_ab.py --far)
+constexpr uint64_t SELL_TILES_PER_RANGE = 36; // target length of a workgroup's tile range once a launch has several generations
 constexpr uint64_t SELL_FAST_TILE_COST = 2;
 constexpr uint64_t SELL_FAR_TILE_COST = 2;   // plus SELL_FAR_ENTRY_COST per entry of the far list
 constexpr uint64_t SELL_FAR_ENTRY_COST = 4;
@@ -195,12 +196,14 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
         return std::max<uint64_t>(1, std::min<uint64_t>(nt, (uint64_t)p->cu_count * per_cu));
     };
     // As many workgroups as fit at once while a range is short (every workgroup pays for a window load and the fill of its prefetch
-    // pipeline: at config 2 a range is 10 tiles); once ranges are long, several generations of them with ranges of about 24 tiles --
-    // the later generations start as the first ones finish and even out the tail.  Measured at config 3: k_sample_sell 109 tiles per
-    // range in one generation -> 27 in four, -2 to -4 %; the pair kernel 190 -> 24 in eight, -8 %; shorter ranges lose again.
+    // pipeline: at config 2 a range is 10 tiles); once ranges are long, several generations of them -- the later generations start as
+    // the first ones finish and even out the tail.  Round 2 (K1 bound by instruction issue) measured ranges of about 24 tiles best
+    // (config 3: 109 tiles per range in one generation -> 27 in four, -2 to -4 %).  K1 is bound by HBM traffic now, and every range
+    // costs a window load and a flush of its counts (0.14 GB written per launch in five generations): 36 tiles per range (three
+    // generations at config 3) 0.2387 ms against 0.2467 at 24 and 0.2400 at 48; the pair kernel 1.617 / 1.630 / 1.617 ms.
     auto generations = [&](uint64_t resident) {
         if (opt(MMG_OPT_SELL_WAVES_PER_CU) >= 1) return resident;
-        const uint64_t g = (nt + resident * 12) / (resident * 24); // nearest
+        const uint64_t g = (nt + resident * (SELL_TILES_PER_RANGE / 2)) / (resident * SELL_TILES_PER_RANGE); // nearest
         return std::min<uint64_t>(nt, resident * std::min<uint64_t>(16, std::max<uint64_t>(1, g)));
     };
     const uint64_t grid = generations(resident_grid(false));
@@ -332,7 +335,7 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
                 if (pc > 32) pc = 32;
                 if (opt(MMG_OPT_SELL_WAVES_PER_CU) >= 1 && opt(MMG_OPT_SELL_WAVES_PER_CU) < pc) pc = opt(MMG_OPT_SELL_WAVES_PER_CU);
                 const uint64_t rq = std::max<uint64_t>(1, std::min<uint64_t>(nf, (uint64_t)p->cu_count * pc));
-                const uint64_t gen = opt(MMG_OPT_SELL_WAVES_PER_CU) >= 1 ? rq : std::min<uint64_t>(nf, rq * std::min<uint64_t>(16, std::max<uint64_t>(1, (nf + rq * 12) / (rq * 24))));
+                const uint64_t gen = opt(MMG_OPT_SELL_WAVES_PER_CU) >= 1 ? rq : std::min<uint64_t>(nf, rq * std::min<uint64_t>(16, std::max<uint64_t>(1, (nf + rq * (SELL_TILES_PER_RANGE / 2)) / (rq * SELL_TILES_PER_RANGE))));
                 std::vector<uint64_t> cq;
                 weighted_chunks_tapered(cf, gen, opt(MMG_OPT_SELL_WAVES_PER_CU) >= 1 ? 0 : rq, cq);
                 HIP_TRY(hipMalloc((void **)&p->d_sell_chunk_m[q], cq.size() * sizeof(uint64_t)));

@@ -313,6 +313,30 @@ class Group:
         check(self._lib.mmg_group_pool_moments(self._h, self._arr(samplers), _ptr(sl), _ptr(sl2), C.byref(ns)))
         return sl, sl2, ns.value
 
+    def em(self, shards, mu0, sweeps):
+        """mmg_group_em_create + `sweeps` x mmg_em_step on the leader: EM over the read shards shards[i] (on device i), exchanged
+        with RCCL.  Returns (mu, loglik)."""
+        assert len(shards) == self.size
+        arr = (C.c_void_p * self.size)(*[p._h for p in shards])
+        ems = (C.c_void_p * self.size)()
+        mu0 = np.ascontiguousarray(mu0, np.float64)
+        ll = C.c_double(0.0)
+        check(self._lib.mmg_group_em_create(self._h, arr, _ptr(mu0), ems, C.byref(ll)))
+        try:
+            for _ in range(sweeps):
+                check(self._lib.mmg_em_step(ems[0], C.byref(ll)))
+            mu = np.empty_like(mu0)
+            check(self._lib.mmg_em_get_mu(ems[0], _ptr(mu)))
+        finally:
+            for e in ems:
+                self._lib.mmg_em_destroy(e)
+        return mu, ll.value
+
+    def enqueue_us(self):
+        us = C.c_double(0.0)
+        check(self._lib.mmg_group_enqueue_us(self._h, C.byref(us)))
+        return us.value
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.mmg_group_destroy(self._h)

@@ -70,4 +70,11 @@ def test_group_through_ctypes(gpu, orc):
     a0, b0, _ = s.moments(0)
     a1, b1, _ = s.moments(1)
     assert ns == 32 and np.array_equal(sl, a0 + a1) and np.array_equal(sl2, b0 + b1)
+    sl_again, _, ns_again = grp.pool_moments([s])                 # into scratch buffers: pooling twice counts nothing twice
+    assert ns_again == 32 and np.array_equal(sl_again, sl)
+    assert grp.enqueue_us() > 0.0                                 # host time per device-iteration of the last run call
+    # EM over the group's (one) read shard = the problem's own EM, bit for bit (N shards: tests/test_gpu_parity.py, same-device exchange)
+    mu_g, ll_g = grp.em([prob], mu0, 5)
+    mu_o, _, ll_o = orc.em(p, mu0, max_iter=5, epsilon=-1e308)
+    assert np.array_equal(mu_g, mu_o) and ll_g == ll_o
     grp.close()
