@@ -14,6 +14,10 @@ __global__ __launch_bounds__(256) void k_update(UpdateArgs a)
     if (gid >= total) return;
     const uint32_t c = (uint32_t)(gid / a.n), t = (uint32_t)(gid % a.n);
     const int32_t x = a.cnt[gid];
+    // the moments are read-modify-write: their loads go out with the count's, not after the draw (a wave of this kernel is one long
+    // dependent chain -- at config 2 there is one wave per SIMD and nothing to hide a second memory round trip behind)
+    double sl = 0.0, sl2 = 0.0;
+    if (a.sample_idx >= 0) { sl = a.sum_log[gid]; sl2 = a.sum_log2[gid]; }
     a.cnt[gid] = 0;
     a.cnt_last[gid] = x;
     // the Gamma stream is keyed by the CALLER's transcript id: the chain does not depend on the device numbering
@@ -23,8 +27,8 @@ __global__ __launch_bounds__(256) void k_update(UpdateArgs a)
     if (a.sample_idx >= 0) {
         if (a.trace) a.trace[((uint64_t)c * a.trace_len + (uint32_t)a.sample_idx) * a.n + t] = m;
         const double lg = dlog(m);
-        a.sum_log[gid] += lg;
-        a.sum_log2[gid] += lg * lg;
+        a.sum_log[gid] = sl + lg;
+        a.sum_log2[gid] = sl2 + lg * lg;
     }
 }
 

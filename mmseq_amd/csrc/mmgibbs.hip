@@ -127,6 +127,30 @@ void mmg::weighted_chunks_tapered(const std::vector<uint64_t> &cum, uint64_t gri
     chunk[n] = nt;
 }
 
+// The ranges of a launch as the kernels read them: one 64-byte header per workgroup -- first tile, end tile and the descriptors of the
+// range's first two tiles -- so that ONE scalar load gives a workgroup everything it needs to request its window and its first blocks
+// (with a plain table of boundaries the descriptors are a second dependent memory round trip: 1-2 us per workgroup, which is what a
+// config-2 launch of 29 us is largely made of).
+static hipError_t upload_ranges(const std::vector<uint64_t> &chunk, const std::vector<SellTile> &tiles, uint64_t **d_out)
+{
+    static_assert(sizeof(SellTile) == 24, "three 64-bit words per descriptor");
+    const size_t n = chunk.size() - 1;
+    std::vector<uint64_t> h(n * 8 + 8, 0);
+    SellTile none;
+    none.off16 = 0; none.r0 = 0; none.wbase = 0; none.meta = sell_meta(0, 0, SELL_EMPTY);
+    for (size_t c = 0; c < n; ++c) {
+        h[c * 8] = chunk[c];
+        h[c * 8 + 1] = chunk[c + 1];
+        for (int j = 0; j < 2; ++j) {
+            const SellTile &d = chunk[c] + (uint64_t)j < chunk[c + 1] ? tiles[chunk[c] + j] : none;
+            std::memcpy(&h[c * 8 + 2 + 3 * j], &d, sizeof(SellTile));
+        }
+    }
+    hipError_t e = hipMalloc((void **)d_out, h.size() * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMemcpy(*d_out, h.data(), h.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
+    return e;
+}
+
 // Sliced-ELL stream: tiles of <= 64 rows that never cross a (near, band) boundary of the canonical order, one window per tile.
 static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_starts, const uint64_t *d_key)
 {
@@ -301,14 +325,13 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
         HIP_TRY(hipMemcpy(p->d_sell_tiles_1, s1.data(), s1.size() * sizeof(SellTile), hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void **)&p->d_sell_tiles_k, sk.size() * sizeof(SellTile)));
         HIP_TRY(hipMemcpy(p->d_sell_tiles_k, sk.data(), sk.size() * sizeof(SellTile), hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc((void **)&p->d_sell_chunk_k, rk.size() * sizeof(uint64_t)));
-        HIP_TRY(hipMemcpy(p->d_sell_chunk_k, rk.data(), rk.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        HIP_TRY(upload_ranges(rk, sk, &p->d_sell_chunk_k));
+        HIP_TRY(upload_ranges(r1, s1, &p->d_sell_chunk));
         p->grid_sell_k = (int)gk;
         p->grid_sell = (int)g1;
         p->device_bytes += (s1.size() + sk.size()) * sizeof(SellTile);
     }
-    HIP_TRY(hipMalloc((void **)&p->d_sell_chunk, chunk.size() * sizeof(uint64_t)));
-    HIP_TRY(hipMemcpy(p->d_sell_chunk, chunk.data(), chunk.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    if (!n_hask) HIP_TRY(upload_ranges(chunk, st, &p->d_sell_chunk)); // (with SELL_HASK tiles: uploaded above, over the list without them)
     { // chains in pairs (k_sample_sell_multi): the register-path tiles without multiplicities in their own ranges, the rest apart
         std::vector<SellTile> sf, sx;
         std::vector<uint64_t> cf(1, 0), cx(1, 0);
@@ -338,8 +361,7 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
                 const uint64_t gen = opt(MMG_OPT_SELL_WAVES_PER_CU) >= 1 ? rq : std::min<uint64_t>(nf, rq * std::min<uint64_t>(16, std::max<uint64_t>(1, (nf + rq * (SELL_TILES_PER_RANGE / 2)) / (rq * SELL_TILES_PER_RANGE))));
                 std::vector<uint64_t> cq;
                 weighted_chunks_tapered(cf, gen, opt(MMG_OPT_SELL_WAVES_PER_CU) >= 1 ? 0 : rq, cq);
-                HIP_TRY(hipMalloc((void **)&p->d_sell_chunk_m[q], cq.size() * sizeof(uint64_t)));
-                HIP_TRY(hipMemcpy(p->d_sell_chunk_m[q], cq.data(), cq.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+                HIP_TRY(upload_ranges(cq, sf, &p->d_sell_chunk_m[q]));
                 p->grid_sell_m[q] = (int)(cq.size() - 1);
             }
         }
@@ -348,8 +370,7 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
             HIP_TRY(hipMemcpy(p->d_sell_tiles_x, sx.data(), sx.size() * sizeof(SellTile), hipMemcpyHostToDevice));
             std::vector<uint64_t> rx;
             weighted_chunks(cx, std::max<uint64_t>(1, std::min<uint64_t>(sx.size(), resident_grid(false))), rx);
-            HIP_TRY(hipMalloc((void **)&p->d_sell_chunk_x, rx.size() * sizeof(uint64_t)));
-            HIP_TRY(hipMemcpy(p->d_sell_chunk_x, rx.data(), rx.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+            HIP_TRY(upload_ranges(rx, sx, &p->d_sell_chunk_x));
             p->grid_sell_x = (int)(rx.size() - 1);
             p->device_bytes += sx.size() * sizeof(SellTile);
         }

@@ -175,8 +175,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
     gcnt += (size_t)blockIdx.y * a.n;
     a.chain += blockIdx.y;
 
-    const uint64_t t_begin = chunk_tile[blockIdx.x], t_end = chunk_tile[blockIdx.x + 1];
+    // the range's header (mmgibbs.hip: upload_ranges): first tile, end tile, the descriptors of its first two tiles -- one scalar load
+    const uint64_t *__restrict__ hdr = chunk_tile + (size_t)blockIdx.x * 8;
+    const uint64_t t_begin = hdr[0], t_end = hdr[1];
     if (t_begin >= t_end) return;
+    SellTile d_first, d_second;
+    d_first.off16 = hdr[2]; d_first.r0 = hdr[3]; d_first.wbase = (uint32_t)hdr[4]; d_first.meta = (uint32_t)(hdr[4] >> 32);
+    d_second.off16 = hdr[5]; d_second.r0 = hdr[6]; d_second.wbase = (uint32_t)hdr[7]; d_second.meta = (uint32_t)(hdr[7] >> 32);
     // a range holds fewer than 2^31 tiles: 32-bit scalar loop arithmetic
     const uint32_t nt = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(t_end - t_begin));
     const SellTile *__restrict__ T = tiles + t_begin;
@@ -518,7 +523,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
         d.meta = i < nt ? d.meta : none.meta;
         return d;
     };
-    SellTile dA = tile_at(0), dB = tile_at(1);
+    SellTile dA = d_first, dB = d_second; // (the host marks the second descriptor empty in a range of one tile)
     Buf bufA, bufB;
     load_window(dA.wbase);
     uint32_t cur_base = dA.wbase;
