@@ -200,6 +200,8 @@ def side_measurement(name, rows, transcripts, avg_hits, chains=1, uniform=False,
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     tm = smp.timing()
+    for c in range(chains):   # every chain assigned every read exactly once in the last sweep
+        assert int(smp.counts(c).astype(np.int64).sum()) == inf.total_k, "count conservation, chain %d" % c
     out = {"name": name, "reads": inf.m, "transcripts": inf.n, "hits": inf.nnz, "chains": chains, "uniform": bool(uniform),
            "canonical_layout": bool(sort), "far_fraction": far_fraction, "steps": steps, "ms_per_step": el / steps * 1e3,
            "chain_iterations_per_sec": chains * steps / el,

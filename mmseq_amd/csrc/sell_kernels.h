@@ -297,14 +297,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
             if (i == 0) t = w0; else t += w0; /* 0.0 + w0 == w0 exactly */                                   \
             t += w1; t += w2; t += w3;                                                                       \
         }
+        // A boundary past the tile's last group is never looked at -- the sweep of the pick is entered at group ng - 1 -- except P7, the
+        // total the tail of a long row continues from: no copies for the others,
+        // an empty asm "defines" them (the sweep's operand list names all eight).
 #define SELL_SUM_U(i) SELL_ADD(i) P##i = t;
-#define SELL_SUM_C(i) if ((uint32_t)i < ng) SELL_ADD(i) P##i = t;
+#define SELL_SUM_C(i) if ((uint32_t)i < ng) { SELL_ADD(i) P##i = t; } else asm volatile("" : "=v"(P##i));
         if (ng >= 4) {
             SELL_SUM_U(0) SELL_SUM_U(1) SELL_SUM_U(2) SELL_SUM_U(3)
-            SELL_SUM_C(4) SELL_SUM_C(5) SELL_SUM_C(6) SELL_SUM_C(7)
+            SELL_SUM_C(4) SELL_SUM_C(5) SELL_SUM_C(6)
+            if (7u < ng) { SELL_ADD(7) }
+            P7 = t;
         } else {
             SELL_SUM_C(0) SELL_SUM_C(1) SELL_SUM_C(2)
-            P3 = t; P4 = t; P5 = t; P6 = t; P7 = t;
+            P7 = t;
+            asm volatile("" : "=v"(P3), "=v"(P4), "=v"(P5), "=v"(P6));
         }
 #undef SELL_SUM_U
 #undef SELL_SUM_C
@@ -373,12 +379,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
                              "s_cmp_eq_u32 %[ng], 7\n\t" "s_cbranch_scc1 .Lsell_b6_%=\n\t"
                              "s_cmp_eq_u32 %[ng], 6\n\t" "s_cbranch_scc1 .Lsell_b5_%=\n\t"
                              "s_cmp_eq_u32 %[ng], 5\n\t" "s_cbranch_scc1 .Lsell_b4_%=\n\t"
-                             "s_branch .Lsell_b3_%=\n"
+                             "s_cmp_eq_u32 %[ng], 4\n\t" "s_cbranch_scc1 .Lsell_b3_%=\n\t"
+                             "s_cmp_eq_u32 %[ng], 3\n\t" "s_cbranch_scc1 .Lsell_b2_%=\n\t"
+                             "s_cmp_eq_u32 %[ng], 2\n\t" "s_cbranch_scc1 .Lsell_b1_%=\n\t"
+                             "s_branch .Lsell_b0_%=\n"
                              ".Lsell_b7_%=:\n\t" SELL_STEP(7, "%[p6]")
                              ".Lsell_b6_%=:\n\t" SELL_STEP(6, "%[p5]")
                              ".Lsell_b5_%=:\n\t" SELL_STEP(5, "%[p4]")
                              ".Lsell_b4_%=:\n\t" SELL_STEP(4, "%[p3]")
-                             ".Lsell_b3_%=:\n\t" SELL_STEP(3, "%[p2]") SELL_STEP(2, "%[p1]") SELL_STEP(1, "%[p0]") SELL_STEP(0, "0")
+                             ".Lsell_b3_%=:\n\t" SELL_STEP(3, "%[p2]")
+                             ".Lsell_b2_%=:\n\t" SELL_STEP(2, "%[p1]")
+                             ".Lsell_b1_%=:\n\t" SELL_STEP(1, "%[p0]")
+                             ".Lsell_b0_%=:\n\t" SELL_STEP(0, "0")
                              "s_mov_b64 exec, %[sv]"
                              : [v] "=&v"(v), [acc] "=&v"(acc), [sv] "=&s"(sv), [tm] "=&s"(tm)
                              : [t] "v"(target), [ng] "s"(ng), [p0] "v"(P0), [p1] "v"(P1), [p2] "v"(P2), [p3] "v"(P3), [p4] "v"(P4), [p5] "v"(P5),

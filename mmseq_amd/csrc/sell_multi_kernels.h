@@ -133,16 +133,23 @@ __global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict
                 t[c] += w1.c[c]; t[c] += w2.c[c]; t[c] += w3.c[c];                                           \
             }                                                                                                \
         }
+        // boundaries past the tile's last group are never looked at (the pick enters its sweep at group ng - 1), except P7, the total a
+        // long row's tail continues from: no copies, an empty asm "defines" them (k_sample_sell)
 #define SM_SET(i) _Pragma("unroll") for (int c = 0; c < NCH; ++c) P##i[c] = t[c];
+#define SM_UNDEF(i) _Pragma("unroll") for (int c = 0; c < NCH; ++c) asm volatile("" : "=v"(P##i[c]));
 #define SM_SUM_U(i) SM_ADD(i) SM_SET(i)
-#define SM_SUM_C(i) if ((uint32_t)i < ng) SM_ADD(i) SM_SET(i)
+#define SM_SUM_C(i) if ((uint32_t)i < ng) { SM_ADD(i) SM_SET(i) } else { SM_UNDEF(i) }
         if (ng >= 4) {
             SM_SUM_U(0) SM_SUM_U(1) SM_SUM_U(2) SM_SUM_U(3)
-            SM_SUM_C(4) SM_SUM_C(5) SM_SUM_C(6) SM_SUM_C(7)
+            SM_SUM_C(4) SM_SUM_C(5) SM_SUM_C(6)
+            if (7u < ng) { SM_ADD(7) }
+            SM_SET(7)
         } else {
             SM_SUM_C(0) SM_SUM_C(1) SM_SUM_C(2)
-            SM_SET(3) SM_SET(4) SM_SET(5) SM_SET(6) SM_SET(7)
+            SM_UNDEF(3) SM_UNDEF(4) SM_UNDEF(5) SM_UNDEF(6)
+            SM_SET(7)
         }
+#undef SM_UNDEF
 #undef SM_SUM_U
 #undef SM_SUM_C
 #undef SM_SET
@@ -184,12 +191,18 @@ __global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict
                              "s_cmp_eq_u32 %[ng], 7\n\t" "s_cbranch_scc1 .Lsm_b6_%=\n\t"
                              "s_cmp_eq_u32 %[ng], 6\n\t" "s_cbranch_scc1 .Lsm_b5_%=\n\t"
                              "s_cmp_eq_u32 %[ng], 5\n\t" "s_cbranch_scc1 .Lsm_b4_%=\n\t"
-                             "s_branch .Lsm_b3_%=\n"
+                             "s_cmp_eq_u32 %[ng], 4\n\t" "s_cbranch_scc1 .Lsm_b3_%=\n\t"
+                             "s_cmp_eq_u32 %[ng], 3\n\t" "s_cbranch_scc1 .Lsm_b2_%=\n\t"
+                             "s_cmp_eq_u32 %[ng], 2\n\t" "s_cbranch_scc1 .Lsm_b1_%=\n\t"
+                             "s_branch .Lsm_b0_%=\n"
                              ".Lsm_b7_%=:\n\t" SM_STEP(7, "%[p6]")
                              ".Lsm_b6_%=:\n\t" SM_STEP(6, "%[p5]")
                              ".Lsm_b5_%=:\n\t" SM_STEP(5, "%[p4]")
                              ".Lsm_b4_%=:\n\t" SM_STEP(4, "%[p3]")
-                             ".Lsm_b3_%=:\n\t" SM_STEP(3, "%[p2]") SM_STEP(2, "%[p1]") SM_STEP(1, "%[p0]") SM_STEP(0, "0")
+                             ".Lsm_b3_%=:\n\t" SM_STEP(3, "%[p2]")
+                             ".Lsm_b2_%=:\n\t" SM_STEP(2, "%[p1]")
+                             ".Lsm_b1_%=:\n\t" SM_STEP(1, "%[p0]")
+                             ".Lsm_b0_%=:\n\t" SM_STEP(0, "0")
                              "s_mov_b64 exec, %[sv]"
                              : [v] "=&v"(v), [acc] "=&v"(acc), [sv] "=&s"(sv), [tm] "=&s"(tm)
                              : [t] "v"(target), [ng] "s"(ng), [p0] "v"(P0[c]), [p1] "v"(P1[c]), [p2] "v"(P2[c]), [p3] "v"(P3[c]), [p4] "v"(P4[c]),
