@@ -12,6 +12,11 @@ const void *k1_sell_kernel(bool idx64, bool has_k)
     return has_k ? (const void *)k_sample_sell<uint32_t, true, 8> : (const void *)k_sample_sell<uint32_t, false, 8>;
 }
 
+const void *k1_sell_far_kernel(bool idx64)
+{
+    return idx64 ? (const void *)k_sample_sell<uint64_t, false, 8, 1, true> : (const void *)k_sample_sell<uint32_t, false, 8, 1, true>;
+}
+
 const void *k1_sell_multi_kernel(bool idx64, int nch)
 {
     if (nch == 2) return idx64 ? (const void *)k_sample_sell_multi<uint64_t, 2> : (const void *)k_sample_sell_multi<uint32_t, 2>;

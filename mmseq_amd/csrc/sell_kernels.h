@@ -26,8 +26,9 @@ template <int K> struct IntTag { static constexpr int value = K; };
 // over-reads a quarter more HBM traffic).  Descriptor words, offsets and the block are wave-uniform: everything stays in SGPRs.
 struct SellBlock {
     __amdgpu_buffer_rsrc_t rs;
-    __device__ SellBlock(const uint8_t *blk, uint32_t meta)
-        : rs(__builtin_amdgcn_make_buffer_rsrc((void *)blk, 0, (int)((meta & 0xff00u) + 64u), 0x00020000)) {} // 0x00020000: gfx9 raw dword buffer
+    // extra: bytes behind the window part that the descriptor covers as well (the far list of a far tile)
+    __device__ SellBlock(const uint8_t *blk, uint32_t meta, uint32_t extra = 0)
+        : rs(__builtin_amdgcn_make_buffer_rsrc((void *)blk, 0, (int)((meta & 0xff00u) + 64u + extra), 0x00020000)) {} // 0x00020000: gfx9 raw dword buffer
     __device__ uint32_t len(uint32_t lane) const { return __builtin_amdgcn_raw_buffer_load_b8(rs, (int)lane, 0, 0); }
     // group i of the lane's row; the constant part of the offset folds into the instruction, aux 2 = nontemporal (streamed once)
     template <int I> __device__ uint32_t group(uint32_t lane) const
@@ -155,8 +156,11 @@ struct RowViewFarTile {
     }
 };
 
-template <typename IdxT, bool HAS_K, int NGC, int REP = 1>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 7, HAS_K ? 5 : 7))) void k_sample_sell(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
+// FARPF: the instantiation that walks the list of far (and CSR-walked) tiles: the far count and the first far transcript of every lane
+// travel with the block's prefetch, and the first far weight is gathered while the window part is walked.  Without it a far tile is
+// three dependent memory round trips in the middle of its walk (count -> transcript id -> weight): 10 x a register-path tile.
+template <typename IdxT, bool HAS_K, int NGC, int REP = 1, bool FARPF = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : (FARPF ? 6 : 7), HAS_K ? 5 : (FARPF ? 6 : 7)))) void k_sample_sell(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
                                                     const uint32_t *__restrict__ kmult, const SellTile *__restrict__ tiles, const uint64_t *__restrict__ chunk_tile,
                                                     const double *__restrict__ gmu /* [grid.y][n] */, const uint8_t *__restrict__ stream,
                                                     int32_t *gcnt /* [grid.y][n] */, SampleArgs a)
@@ -230,6 +234,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
         uint32_t g0, g1, g2, g3, g4, g5, g6, g7;
         uint32_t len;
         uint32_t kk; // multiplicity of the lane's row (HAS_K)
+        uint32_t lf, f0; // FARPF: entries in the lane's far list, the first of them
     };
     // request a tile's block: the lane's length byte and NGC groups, UNCONDITIONALLY (tiles without a block -- empty, slow, past
     // the end of the range -- ask for the head of the stream instead).  Loads retire in order and are waited for by count, so the
@@ -237,8 +242,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
     // waits for the prefetch issued just before it.  Groups beyond the tile's ng fail the descriptor's range check: no memory access.
     auto issue = [&](const SellTile &d, Buf &bf) {
         const bool fast = d.flags() & (SELL_FAST | SELL_FAR); // uniform: the tile has a block (a far tile's window part is a fast tile's)
-        const SellBlock blk(stream + (fast ? d.off16 * 16 : 0), d.meta);
+        const bool farb = FARPF && (d.flags() & SELL_FAR);
+        const SellBlock blk(stream + (fast ? d.off16 * 16 : 0), d.meta, farb ? 64u + d.nf() * 256u : 0u);
         bf.len = blk.len(lane);
+        if (FARPF) { // two more loads, whatever the tile (a tile without a far list reads its own head again)
+            const uint32_t fo = farb ? 64u + d.ng() * 256u : 0u; // the far part: 64 count bytes, then nf groups of 64 transcript ids
+            bf.lf = __builtin_amdgcn_raw_buffer_load_b8(blk.rs, (int)lane, (int)fo, 0);
+            bf.f0 = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(blk.rs, (int)(lane * 4u + 64u), (int)fo, 2);
+        }
         if (HAS_K) bf.kk = kmult[(fast ? d.r0 : 0) + min(lane, (fast ? d.nrows() : 1u) - 1u)];
 #define SELL_ISSUE(i) bf.g##i = blk.template group<i>(lane);
         SELL_GROUPS(SELL_ISSUE)
@@ -285,6 +296,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
         const uint32_t L = bf.len;
         const uint32_t xrow = which ? xrowB : xrowA;
         double t = 0.0;
+        double m0 = 0.0; // FARPF: the weight of the lane's first far hit, requested before the window part is walked
+        if (FARPF && FAR) { if (bf.lf) m0 = gmu[bf.f0]; }
         // Tiles of four or more groups (most: rows are sorted by length) run their first four groups without the per-group
         // test: a wave issues one instruction per slot, scalar compares and branches included, and they were a third of a tile's
         // instructions.
@@ -326,9 +339,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
         const uint32_t *__restrict__ farp = nullptr;
         if (FAR) {
             const uint8_t *__restrict__ fb = stream + d.off16 * 16 + 64 + (size_t)ng * 256;
-            Lf = fb[lane];
             farp = (const uint32_t *)(fb + 64) + lane;
-            for (uint32_t f = 0; f < Lf; ++f) t += gmu[farp[(size_t)f * 64]];
+            if (FARPF) {
+                Lf = bf.lf;
+                if (Lf) t += m0;
+                for (uint32_t f = 1; f < Lf; ++f) t += gmu[farp[(size_t)f * 64]];
+            } else {
+                Lf = fb[lane];
+                for (uint32_t f = 0; f < Lf; ++f) t += gmu[farp[(size_t)f * 64]];
+            }
         }
         if (HAS_K && L + Lf == 0) return; // (without multiplicities an empty row falls out of the draw's rare path: one test less per tile)
         uint32_t farc = 0; // the transcript of a pick from the far list (draw() then returns FAR_PICK)
@@ -438,8 +457,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
                         accl = r3;
                     }
                     for (uint32_t f = 0; FAR && f < Lf && !found; ++f) { // the far list continues the row
-                        const uint32_t c = farp[(size_t)f * 64];
-                        accl += gmu[c];
+                        const uint32_t c = (FARPF && f == 0) ? bf.f0 : farp[(size_t)f * 64];
+                        accl += (FARPF && f == 0) ? m0 : gmu[c];
                         if (target < accl) { farc = c; sel = FAR_PICK; found = true; }
                     }
                     if (!found) { // rounding left target >= total: the last real hit
