@@ -32,7 +32,10 @@ extern "C" {
  *      conflicts of the sample and EM kernels: -50 %).  The per-row random stream follows the stored position, so chains of
  *      problems stored in the canonical layout differ from version 3; MMG_LAYOUT_KEEP_ROWS problems (and the committed golden
  *      chain, which keeps its rows) do not.  The draw target is now specified as fma(x, t 2^-32, t 2^-33) (mmg_math.h:
- *      draw_target): the same real number rounded once, bit-identical to version 3 unless t 2^-33 underflows. */
+ *      draw_target): the same real number rounded once, bit-identical to version 3 unless t 2^-33 underflows.
+ *      EM (mmg_em_*): the LO limb of a term is the fraction of x 2^E truncated to sl bits (version 3: rounded to nearest through an
+ *      fp64 addition); both limbs of a term are now shifts of the significand of x.  mu after a sweep may differ from version 3 in
+ *      the last bit. */
 /* Layout.  The model does not care about the order of rows or the numbering of transcripts (src/mmseq.cpp:399-418 uses
  * first-seen order for both); the kernels do: they keep a window of consecutive transcripts in LDS and want the 64 rows of a
  * wave to have equal lengths.  mmg_problem_create therefore stores the rows in a CANONICAL order of its own (sorted on the

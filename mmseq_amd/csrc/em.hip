@@ -6,12 +6,11 @@
 
 namespace mmg {
 
-// k_em_sell runs as 2 waves per workgroup sharing one window, 4 accumulator replicas (measured at cfg 3: 1.93 ms per sweep;
-// 1 wave x 2 replicas 2.12, 2 x 2 2.01, 4 x 4 1.99, 2 x 1 2.34)
+// k_em_sell runs as 2 waves per workgroup sharing one window, 4 accumulator replicas (measured at cfg 3, round 3: 1.31 ms per
+// sweep; 4 waves x 8 replicas 1.31, 4 x 4 1.38, 2 x 2 1.45, 2 x 8 1.67)
 const void *em_sell_kernel(bool idx64, bool has_k, bool measure)
 {
-    static_assert(EM_SELL_BS == 128, "two waves per workgroup");
-#define EMS_PICK(IDX, HK) (measure ? (const void *)k_em_sell<IDX, HK, true, 1, 2> : (const void *)k_em_sell<IDX, HK, false, 4, 2>)
+#define EMS_PICK(IDX, HK) (measure ? (const void *)k_em_sell<IDX, HK, true, 1, EM_SELL_W> : (const void *)k_em_sell<IDX, HK, false, EM_SELL_REP, EM_SELL_W>)
     if (idx64) return has_k ? EMS_PICK(uint64_t, true) : EMS_PICK(uint64_t, false);
     return has_k ? EMS_PICK(uint32_t, true) : EMS_PICK(uint32_t, false);
 #undef EMS_PICK

@@ -17,12 +17,16 @@ constexpr int EM_DEAD = -32768;
 constexpr int EM_MARGIN = 8;
 constexpr int EM_SHRINK = 8;
 
-// packed per-transcript word: E (int16) | sl << 16 (6 bits) | cap << 22 (6 bits)
+// packed per-transcript word: 64 - sl in bits 0..5 (a 64-bit shift takes its count from the low six bits of the whole word),
+// cap in bits 8..15, E (int16) in bits 16..31
 __host__ __device__ __forceinline__ uint32_t em_pack(int E, int sl, int cap)
 {
-    return ((uint32_t)E & 0xffffu) | ((uint32_t)sl << 16) | ((uint32_t)cap << 22);
+    return ((uint32_t)E << 16) | ((uint32_t)cap << 8) | (uint32_t)(64 - sl);
 }
-constexpr uint32_t EM_WORD_DEAD = (0x8000u) | (63u << 22);
+__host__ __device__ __forceinline__ int em_word_E(uint32_t w) { return (int)w >> 16; }
+__host__ __device__ __forceinline__ int em_word_cap(uint32_t w) { return (int)((w >> 8) & 0xffu); }
+__host__ __device__ __forceinline__ int em_word_sl(uint32_t w) { return 64 - (int)(w & 63u); }
+constexpr uint32_t EM_WORD_DEAD = (0x8000u << 16) | (63u << 8) | 1u;
 
 __device__ __forceinline__ double block_sum_256(double v, double *red)
 {
@@ -87,7 +91,7 @@ __global__ void k_em_check(uint32_t n, const uint32_t *__restrict__ word, const 
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const uint32_t w = word[t];
-    const int E = (int)(int16_t)(w & 0xffffu), sl = (int)((w >> 16) & 63u);
+    const int E = em_word_E(w), sl = em_word_sl(w);
     if (E != EM_DEAD && (hi[t] >> (sl - 2 - EM_MARGIN - EM_SHRINK)) == 0) atomicOr((unsigned long long *)&ll[2], 1ull);
 }
 
@@ -108,7 +112,7 @@ __global__ void k_em_apply(uint32_t n, double *mu, const double *__restrict__ l,
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const uint32_t w = word[t];
-    const int E = (int)(int16_t)(w & 0xffffu), sl = (int)((w >> 16) & 63u);
+    const int E = em_word_E(w), sl = em_word_sl(w);
     const double S = E == EM_DEAD ? 0.0 : dscalbn((double)hi[t] + dscalbn((double)lo[t], -sl), -E);
     mu[t] = mu[t] * S / l[t];
     sexp[t] = (S > 0.0 && S < __builtin_huge_val()) ? dilogb(S) : INT32_MIN;
@@ -121,14 +125,16 @@ struct EmAcc {
     uint32_t viol = 0;
 };
 
-// Row head shared by all paths: returns false if the row is skipped.  x = k/d, xe = ilogb(x).
+// Row head shared by all paths: returns false if the row is skipped.  x = k/d = T * 2^(xe - 63): xe = ilogb(x), T the 53-bit
+// significand with its leading bit at bit 63.
 template <bool MEASURE>
-__device__ __forceinline__ bool em_row_head(double d, uint32_t kk, EmAcc &acc, double &x, int &xe)
+__device__ __forceinline__ bool em_row_head(double d, uint32_t kk, EmAcc &acc, uint64_t &T, int &xe)
 {
     if (kk == 0 || !(d >= 0x1p-900 && d <= 0x1p900)) return false;
     const double dk = (double)kk;
-    x = dk / d;
-    xe = (int)((bits_of(x) >> 52) & 0x7ff) - 1023; // x is normal here
+    const uint64_t xb = bits_of(dk / d);
+    xe = (int)((xb >> 52) & 0x7ff) - 1023; // x is normal here
+    T = (xb << 11) | (1ull << 63);
     if (!MEASURE) {
         const double v = dk * dlog(d) * 4096.0, fv = dfloor(v);
         acc.llh += (int64_t)fv;
@@ -137,16 +143,18 @@ __device__ __forceinline__ bool em_row_head(double d, uint32_t kk, EmAcc &acc, d
     return true;
 }
 
-// one term: returns false (and flags) if the check fails; yh / yl are the limbs to add
-__device__ __forceinline__ bool em_term(double x, int xe, uint32_t w, EmAcc &acc, uint64_t &yh, uint64_t &yl)
+// One term, Y = x * 2^E = T * 2^(p - 63) with p = xe + E: yh = floor(Y), yl = the top sl bits of its fraction (both exact: shifts of
+// the significand).  Returns false if nothing is to be added: a dead transcript, or a failed check (flagged: the pass is repeated).
+__device__ __forceinline__ bool em_term(uint64_t T, int xe, uint32_t w, EmAcc &acc, uint64_t &yh, uint64_t &yl)
 {
-    const int E = (int)(int16_t)(w & 0xffffu), sl = (int)((w >> 16) & 63u), cap = (int)((w >> 22) & 63u);
+    const int E = em_word_E(w);
     if (E == EM_DEAD) return false;
-    acc.viol |= (uint32_t)(xe + E >= cap); // no branch: a failed check repeats the whole pass, whatever is added here is discarded
-    const double Y = __builtin_ldexp(x, E);
-    const double tr = __builtin_trunc(Y);
-    yh = (uint64_t)tr;
-    yl = (uint64_t)(__builtin_ldexp(Y - tr, sl) + 0.5);
+    const int p = xe + E;
+    if (p >= em_word_cap(w)) { acc.viol |= 1u; return false; }
+    uint64_t fr; // the fraction of Y, left-aligned
+    if (p >= 0) { yh = T >> (63 - p); fr = (T << 1) << p; }
+    else { yh = 0; fr = p >= -64 ? T >> (-1 - p) : 0; }
+    yl = fr >> (w & 63u);
     return true;
 }
 
@@ -179,7 +187,7 @@ __global__ __launch_bounds__(256) void k_em_rows_global(const IdxT *__restrict__
         if (e > b) {
             double d = 0.0;
             for (uint64_t j = b; j < e; ++j) d += a.mu[col_idx[j]];
-            double x;
+            uint64_t x;
             int xe;
             if (em_row_head<MEASURE>(d, kmult ? kmult[r] : 1u, acc, x, xe)) {
                 for (uint64_t j = b; j < e; ++j) {
@@ -209,10 +217,16 @@ __global__ __launch_bounds__(64 * W) void k_em_sell(const IdxT *__restrict__ row
                                                 const uint64_t *__restrict__ chunk_tile, const uint8_t *__restrict__ stream, EmArgs a)
 {
     constexpr int WIN = (int)SELL_WIN;
-    constexpr int AST = WIN + 1;                                            // entries per replica; [WIN] is the pad slot
+    constexpr int AST = WIN + 1;                                            // entries per window array; [WIN] is the pad slot
+    constexpr int RST = AST + 8;                                            // entries per accumulator replica: 8 more than a multiple
+                                                                            // of 32, so that the same slot of the four replicas lies in four
+                                                                            // different quarters of the 64 banks (a window's most abundant
+                                                                            // transcript receives most of its terms)
     __shared__ __attribute__((aligned(16))) double s_mu[AST];              // [WIN] stays 0.0: what pad slots read
-    __shared__ uint32_t s_w[MEASURE ? 1 : AST];                            // scale words; [WIN] dead
-    __shared__ uint64_t s_hi[MEASURE ? 1 : REP * AST], s_lo[MEASURE ? 1 : REP * AST];
+    __shared__ uint32_t s_w[MEASURE ? 1 : 2 * AST];                        // scale words, one per 8 bytes (a hit's byte offset addresses s_mu, s_w and the accumulators alike); [WIN] dead
+    __shared__ uint64_t s_acc[MEASURE ? 1 : 2 * REP * RST];                // HI limbs of the REP replicas, then their LO limbs
+    uint64_t *const s_hi = s_acc, *const s_lo = s_acc + (MEASURE ? 0 : REP * RST);
+    constexpr uint32_t LO_OFF = (uint32_t)(REP * RST * 8);
     __shared__ int32_t s_xe[MEASURE ? AST : 1];
     __shared__ uint64_t s_ll[3];
     // W waves per workgroup share one window (mu, scale words, accumulators): the LDS per wave drops W-fold, more waves are
@@ -220,7 +234,7 @@ __global__ __launch_bounds__(64 * W) void k_em_sell(const IdxT *__restrict__ row
     // wave steps through EVERY window slide of the range in tile order (two barriers each), so the barrier counts match.
     constexpr int BS = 64 * W;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t rep_off = MEASURE ? 0u : (lane % REP) * (uint32_t)(AST * 8);
+    const uint32_t rep_off = MEASURE ? 0u : (lane % REP) * (uint32_t)(RST * 8);
 
     const uint64_t t_begin = chunk_tile[blockIdx.x], t_end = chunk_tile[blockIdx.x + 1];
     if (t_begin >= t_end) return;
@@ -230,9 +244,9 @@ __global__ __launch_bounds__(64 * W) void k_em_sell(const IdxT *__restrict__ row
     if (tid < 3) s_ll[tid] = 0;
     for (int i = tid; i < AST; i += BS) {
         if (MEASURE) s_xe[i] = INT32_MIN;
-        else { for (int r = 0; r < REP; ++r) { s_hi[r * AST + i] = 0; s_lo[r * AST + i] = 0; } }
+        else { for (int r = 0; r < REP; ++r) { s_hi[r * RST + i] = 0; s_lo[r * RST + i] = 0; } }
     }
-    if (tid == 0) { s_mu[WIN] = 0.0; if (!MEASURE) s_w[WIN] = EM_WORD_DEAD; }
+    if (tid == 0) { s_mu[WIN] = 0.0; if (!MEASURE) s_w[2 * WIN] = EM_WORD_DEAD; }
 
     auto flush_window = [&](uint32_t base) {
         for (int i = tid; i < WIN; i += BS) {
@@ -241,7 +255,7 @@ __global__ __launch_bounds__(64 * W) void k_em_sell(const IdxT *__restrict__ row
                 if (v != INT32_MIN) { atomicMax(&a.xe[base + (uint32_t)i], v); s_xe[i] = INT32_MIN; }
             } else {
                 uint64_t h = 0, l = 0;
-                for (int r = 0; r < REP; ++r) { h += s_hi[r * AST + i]; l += s_lo[r * AST + i]; s_hi[r * AST + i] = 0; s_lo[r * AST + i] = 0; }
+                for (int r = 0; r < REP; ++r) { h += s_hi[r * RST + i]; l += s_lo[r * RST + i]; s_hi[r * RST + i] = 0; s_lo[r * RST + i] = 0; }
                 if (h) atomicAdd((unsigned long long *)&a.hi[base + (uint32_t)i], (unsigned long long)h);
                 if (l) atomicAdd((unsigned long long *)&a.lo[base + (uint32_t)i], (unsigned long long)l);
             }
@@ -251,7 +265,7 @@ __global__ __launch_bounds__(64 * W) void k_em_sell(const IdxT *__restrict__ row
         for (int i = tid; i < WIN; i += BS) {
             const uint32_t c = base + (uint32_t)i;
             s_mu[i] = c < a.n ? a.mu[c] : 0.0;
-            if (!MEASURE) s_w[i] = c < a.n ? a.word[c] : EM_WORD_DEAD;
+            if (!MEASURE) s_w[2 * i] = c < a.n ? a.word[c] : EM_WORD_DEAD;
         }
     };
     auto wo = [&](uint32_t off) { return *(const double *)((const char *)s_mu + off); }; // off = window index * 8
@@ -295,29 +309,51 @@ __global__ __launch_bounds__(64 * W) void k_em_sell(const IdxT *__restrict__ row
             t += w0; t += w1; t += w2; t += w3;
         }
         if (bf.len == 0) return;
-        double x;
+        uint64_t x;
         int xe;
         if (!em_row_head<MEASURE>(t, HAS_K ? bf.kk : 1u, acc, x, xe)) return;
+        const uint64_t x2 = x << 1;
         // second half: every hit of the row receives x (pads point at the dead slot and add nothing)
-        auto give = [&](uint32_t off) {
-            if (MEASURE) {
-                atomicMax((int32_t *)((char *)s_xe + (off >> 1)), xe);
-            } else {
+        // the usual term (0 <= p < cap) is three 64-bit shifts whose counts are the low six bits of p, ~p (= 63 - p mod 64) and
+        // the scale word itself; anything else -- a pad or a dead transcript (p far below 0), a term below one unit, a failed
+        // check -- goes through em_term
+        auto term = [&](uint32_t off, uint32_t w) {
+            const int p = xe + em_word_E(w);
+            char *const slot = (char *)s_acc + rep_off + off;
+            if ((uint32_t)p < (uint32_t)em_word_cap(w)) {
+                const uint64_t yh = x >> (~(uint32_t)p & 63u), yl = (x2 << ((uint32_t)p & 63u)) >> (w & 63u);
+                atomicAdd((unsigned long long *)slot, (unsigned long long)yh);
+                atomicAdd((unsigned long long *)(slot + LO_OFF), (unsigned long long)yl);
+            } else if (p > -16384) {
                 uint64_t yh, yl;
-                if (em_term(x, xe, *(const uint32_t *)((const char *)s_w + (off >> 1)), acc, yh, yl)) {
-                    atomicAdd((unsigned long long *)((char *)s_hi + rep_off + off), (unsigned long long)yh);
-                    atomicAdd((unsigned long long *)((char *)s_lo + rep_off + off), (unsigned long long)yl);
+                if (em_term(x, xe, w, acc, yh, yl)) {
+                    atomicAdd((unsigned long long *)slot, (unsigned long long)yh);
+                    atomicAdd((unsigned long long *)(slot + LO_OFF), (unsigned long long)yl);
                 }
             }
         };
+        auto sw = [&](uint32_t off) { return *(const uint32_t *)((const char *)s_w + off); };
+        // one group of four hits: the four scale words are requested together, then the terms
+        auto give4 = [&](uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3) {
+            if (MEASURE) {
+                atomicMax((int32_t *)((char *)s_xe + (o0 >> 1)), xe);
+                atomicMax((int32_t *)((char *)s_xe + (o1 >> 1)), xe);
+                atomicMax((int32_t *)((char *)s_xe + (o2 >> 1)), xe);
+                atomicMax((int32_t *)((char *)s_xe + (o3 >> 1)), xe);
+            } else {
+                uint32_t w0 = sw(o0), w1 = sw(o1), w2 = sw(o2), w3 = sw(o3);
+                asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3)); // one wait for the four
+                term(o0, w0); term(o1, w1); term(o2, w2); term(o3, w3);
+            }
+        };
 #define EMS_GIVE(i)                                                                                          \
-        if ((uint32_t)i < ng) { const uint32_t v = bf.g##i; give(EMS_OFF0(v)); give(EMS_OFF1(v)); give(EMS_OFF2(v)); give(EMS_OFF3(v)); }
+        if ((uint32_t)i < ng) { const uint32_t v = bf.g##i; give4(EMS_OFF0(v), EMS_OFF1(v), EMS_OFF2(v), EMS_OFF3(v)); }
         EMS_GROUPS(EMS_GIVE)
 #undef EMS_GIVE
 #pragma unroll 1
         for (uint32_t g = 8; g < ng; ++g) {
             const uint32_t v = src[(size_t)g * 64];
-            give(EMS_OFF0(v)); give(EMS_OFF1(v)); give(EMS_OFF2(v)); give(EMS_OFF3(v));
+            give4(EMS_OFF0(v), EMS_OFF1(v), EMS_OFF2(v), EMS_OFF3(v));
         }
     };
 #undef EMS_GROUPS
@@ -338,7 +374,7 @@ __global__ __launch_bounds__(64 * W) void k_em_sell(const IdxT *__restrict__ row
             const uint32_t c = cl[j], dd = c - wbase;
             dsum += dd < (uint32_t)WIN ? s_mu[dd] : a.mu[c];
         }
-        double x;
+        uint64_t x;
         int xe;
         if (!em_row_head<MEASURE>(dsum, HAS_K ? kmult[d.r0 + lane] : 1u, acc, x, xe)) return;
         for (uint32_t j = 0; j < L; ++j) {
@@ -349,7 +385,7 @@ __global__ __launch_bounds__(64 * W) void k_em_sell(const IdxT *__restrict__ row
                 else atomicMax(&a.xe[c], xe);
             } else {
                 uint64_t yh, yl;
-                if (em_term(x, xe, in ? s_w[dd] : a.word[c], acc, yh, yl)) {
+                if (em_term(x, xe, in ? s_w[2 * dd] : a.word[c], acc, yh, yl)) {
                     if (in) {
                         atomicAdd((unsigned long long *)&s_hi[dd], (unsigned long long)yh);
                         atomicAdd((unsigned long long *)&s_lo[dd], (unsigned long long)yl);

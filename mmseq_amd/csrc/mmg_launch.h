@@ -22,7 +22,8 @@ void launch_encode_sell(bool idx64, const void *row_ptr, const uint32_t *col, co
 
 // ---- em.hip: EM sweeps (src/mmseq.cpp:741-811)
 const void *em_sell_kernel(bool idx64, bool has_k, bool measure); // k_em_sell, EM_SELL_BS threads per workgroup
-constexpr unsigned EM_SELL_BS = 128;
+constexpr int EM_SELL_W = 2, EM_SELL_REP = 4; // waves per workgroup (one window), accumulator replicas
+constexpr unsigned EM_SELL_BS = 64 * EM_SELL_W;
 void launch_em_rows_global(bool idx64, bool measure, const void *row_ptr, const uint32_t *col, const uint32_t *k, uint64_t m,
                            EmArgs a, hipStream_t s);
 void launch_em_colcount(const uint32_t *col, uint64_t nnz, uint64_t *cnt, unsigned grid, hipStream_t s);

@@ -842,12 +842,13 @@ int orc_em_seq(uint64_t m, uint32_t n, const uint64_t *row_ptr, const uint32_t *
  *                  the sum did not shrink by more than SHRINK bits); if any check fails anywhere, the whole pass is
  *                  repeated on measured exponents.
  *   row i: d_i in row order; rows with k_i = 0 or d_i outside [2^-900, 2^900] are skipped (degenerate state);
- *       for each hit t:  Y = ldexp(x_i, E_t);  HI_t += trunc(Y);  LO_t += trunc(ldexp(Y - trunc(Y), sl_t) + 0.5)
+ *       for each hit t:  Y = x_i * 2^E_t;  HI_t += floor(Y);  LO_t += floor((Y - floor(Y)) * 2^sl_t)     -- both exact: the 53-bit
+ *                        significand of x_i shifted into a 64.64 fixed-point number, integer part and the top sl_t fraction bits
  *       v = k_i*log(d_i)*2^12:  LLH += floor(v);  LLL += trunc((v - floor(v))*2^31)               (none can overflow 64 bits)
  *   S_t = ldexp((double)HI_t + ldexp((double)LO_t, -sl_t), -E_t);  mu_t <- mu_t*S_t/l_t
  *   loglik = ((double)LLH*2^-12 + (double)LLL*2^-43) - pen,  pen = sum_t mu_t l_t by 256-blocks (halving tree inside a
  *       block, blocks added in index order).
- * A term is rounded at 2^-(2 sl_t - 2) of the largest term (measured) or at most 2^-(2 sl_t - 18) of S_t (carried), with
+ * A term is truncated at 2^-(2 sl_t - 2) of the largest term (measured) or at most 2^-(2 sl_t - 18) of S_t (carried), with
  * sl_t >= 31 (>= 37 below 2^26 hits per transcript): below the fp64 rounding of the reference's own sums; tests pin this against orc_em_seq. */
 static inline int em_bitlen(uint64_t v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
 #define ORC_EM_DEAD (-32768)
@@ -880,6 +881,9 @@ static int em_rows_pass(int measure, uint64_t m, const uint64_t *row_ptr, const 
         if ((k && k[i] == 0) || !(d >= 0x1p-900 && d <= 0x1p900)) continue;
         const double kk = (double)(k ? k[i] : 1u), x = kk / d;
         const int xe = ilogb(x);
+        uint64_t T;
+        memcpy(&T, &x, 8);
+        T = (T << 11) | (1ull << 63); /* x is normal here (d in [2^-900, 2^900], 1 <= k < 2^32) */
         if (measure) {
             for (uint64_t j = b; j < e; ++j) if (xe > XE[col_idx[j]]) XE[col_idx[j]] = xe;
             continue;
@@ -891,10 +895,13 @@ static int em_rows_pass(int measure, uint64_t m, const uint64_t *row_ptr, const 
             const uint32_t t = col_idx[j];
             if (E[t] == ORC_EM_DEAD) continue;
             if (xe + E[t] >= cap[t]) { viol = 1; continue; }
-            const double Y = ldexp(x, E[t]);
-            const uint64_t yh = (uint64_t)Y;
+            /* x = T * 2^(xe - 63) with T the significand, leading bit at bit 63; Y = T * 2^(p - 63), p = xe + E_t <= 62 */
+            const int p = xe + E[t];
+            uint64_t yh, fr; /* fr: the fraction of Y, left-aligned (bit 63 = 2^-1) */
+            if (p >= 0) { yh = T >> (63 - p); fr = (T << 1) << p; }
+            else { yh = 0; fr = p >= -64 ? T >> (-1 - p) : 0; }
             HI[t] += yh;
-            LO[t] += (uint64_t)(ldexp(Y - (double)yh, sl[t]) + 0.5);
+            LO[t] += fr >> (64 - sl[t]);
         }
     }
     if (!measure) { *llh = h; *lll = lo; }

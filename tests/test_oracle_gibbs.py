@@ -211,6 +211,47 @@ def test_em_fixed_point_spec_tracks_reference_order(orc):
         assert abs(a[2] - b[2]) < 1e-4
 
 
+def test_em_term_limbs_are_exact_shifts(orc):
+    """One sweep of orc.em_x against a restatement in Python integers and fractions of its header (oracle/mmseq_oracle.c, 'EM with
+    order-independent accumulation'): measured exponents, HI += floor(x 2^E), LO += floor(frac(x 2^E) 2^sl), S from the two limbs."""
+    from fractions import Fraction
+    import math
+    p, _ = orc.synth_problem(R=3000, T=150, avg_hits=5, seed=11)
+    mu0, _ = orc.start_values(p)
+    mu0[::5] *= 1e-40                                    # terms far below one unit of their transcript's HI limb
+    n = p.n
+    rp, ci = p.row_ptr, p.col_idx
+    N = np.bincount(ci, minlength=n)
+    sl = [63 - int(v).bit_length() for v in N]
+    x = np.zeros(p.m)
+    for i in range(p.m):
+        d = 0.0
+        for j in range(int(rp[i]), int(rp[i + 1])): d += mu0[ci[j]]
+        x[i] = 1.0 / d if rp[i + 1] > rp[i] else 0.0
+    XE = [None] * n
+    for i in range(p.m):
+        for j in range(int(rp[i]), int(rp[i + 1])):
+            e = math.frexp(x[i])[1] - 1
+            XE[ci[j]] = e if XE[ci[j]] is None else max(XE[ci[j]], e)
+    HI, LO = [0] * n, [0] * n
+    for i in range(p.m):
+        for j in range(int(rp[i]), int(rp[i + 1])):
+            t = int(ci[j])
+            Y = Fraction(float(x[i])) * Fraction(2) ** (sl[t] - 2 - XE[t])
+            HI[t] += Y.numerator // Y.denominator
+            LO[t] += math.floor((Y - Y.numerator // Y.denominator) * 2 ** sl[t])
+    want = mu0.copy()
+    for t in range(n):
+        if XE[t] is None:
+            want[t] = mu0[t] * 0.0 / p.l[t]
+            continue
+        assert HI[t] < 2 ** 63 and LO[t] < 2 ** 63
+        S = math.ldexp(float(HI[t]) + math.ldexp(float(LO[t]), -sl[t]), -(sl[t] - 2 - XE[t]))
+        want[t] = mu0[t] * S / p.l[t]
+    got = orc.em_x(p, mu0, max_iter=1, epsilon=-1e308)[0]
+    assert np.array_equal(got, want)
+
+
 def _em_golden():
     import json
     gd = os.path.join(os.path.dirname(__file__), "golden")
