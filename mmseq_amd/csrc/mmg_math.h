@@ -325,20 +325,51 @@ MMG_HD double gamma_unit(Stream &s, double a_in)
     const double a = (a_in < 1.0) ? a_in + 1.0 : a_in;
     const double d = a - 1.0 / 3.0;
     const double c = (1.0 / 3.0) / dsqrt(d);
-    double v, x, ua, ub;
+    double v, x, ua;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // The same draws, four Philox blocks at a time.  The stream is counter-based: pair j of this lane is block c3 + j whatever
+    // was drawn before, so the blocks a sequential attempt MAY consume are computed side by side (four independent chains of 10
+    // rounds instead of one after the other -- a wave of K2 is one long dependent chain) and the attempt is then resolved from
+    // them: the first pair the polar method accepts (among the first three), the pair behind it for the acceptance test.  A wave
+    // used to run the polar loop until its unluckiest lane had a normal (about four passes), then the test, then everything
+    // again for the one lane in twenty the test rejects.
+    for (;;) {
+        const U4 r0 = philox4x32_10(U4{s.c0, s.c1, s.c2, s.c3}, s.k0, s.k1), r1 = philox4x32_10(U4{s.c0, s.c1, s.c2, s.c3 + 1u}, s.k0, s.k1),
+                 r2 = philox4x32_10(U4{s.c0, s.c1, s.c2, s.c3 + 2u}, s.k0, s.k1), r3 = philox4x32_10(U4{s.c0, s.c1, s.c2, s.c3 + 3u}, s.k0, s.k1);
+        const double a0 = 2.0 * u52(r0.x, r0.y) - 1.0, b0 = 2.0 * u52(r0.z, r0.w) - 1.0, q0 = a0 * a0 + b0 * b0;
+        const double a1 = 2.0 * u52(r1.x, r1.y) - 1.0, b1 = 2.0 * u52(r1.z, r1.w) - 1.0, q1 = a1 * a1 + b1 * b1;
+        const double a2 = 2.0 * u52(r2.x, r2.y) - 1.0, b2 = 2.0 * u52(r2.z, r2.w) - 1.0, q2 = a2 * a2 + b2 * b2;
+        const bool ok0 = !(q0 >= 1.0 || q0 == 0.0), ok1 = !(q1 >= 1.0 || q1 == 0.0), ok2 = !(q2 >= 1.0 || q2 == 0.0);
+        if (!(ok0 || ok1 || ok2)) { s.c3 += 3u; continue; } // (block 3 only ever serves as the pair behind block 2)
+        const uint32_t j1 = ok0 ? 0u : (ok1 ? 1u : 2u);
+        const double v1 = ok0 ? a0 : (ok1 ? a1 : a2), q = ok0 ? q0 : (ok1 ? q1 : q2);
+        ua = ok0 ? u52(r1.x, r1.y) : (ok1 ? u52(r2.x, r2.y) : u52(r3.x, r3.y)); // the first uniform of the pair behind it
+        x = v1 * dsqrt(-2.0 * dlog(q) / q);
+        v = 1.0 + c * x;
+        if (v <= 0.0) { s.c3 += j1 + 1u; continue; } // the polar method goes on with the next pair
+        v = v * v * v;
+        s.c3 += j1 + 2u;
+        const double x2 = x * x;
+        if (ua < 1.0 - 0.0331 * x2 * x2) break;
+        if (dlog(ua) < 0.5 * x2 + d * (1.0 - v + dlog(v))) break;
+    }
+#else
     for (;;) {
         do {
             x = normal(s);
             v = 1.0 + c * x;
         } while (v <= 0.0);
         v = v * v * v;
+        double ub;
         s.pair(ua, ub);
         const double x2 = x * x;
         if (ua < 1.0 - 0.0331 * x2 * x2) break;
         if (dlog(ua) < 0.5 * x2 + d * (1.0 - v + dlog(v))) break;
     }
+#endif
     double g = d * v;
     if (a_in < 1.0) {
+        double ub;
         s.pair(ua, ub);
         g = g * dexp(dlog(ua) / a_in);
     }
