@@ -276,13 +276,12 @@ __global__ __launch_bounds__(64 * W) void k_em_sell(const IdxT *__restrict__ row
 #define EMS_GROUPS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
     struct Buf {
         uint32_t g0, g1, g2, g3, g4, g5, g6, g7;
-        uint32_t len, kk;
+        uint32_t kk;
     };
     // unconditional, like k_sample_sell::issue (the number of loads per tile must not depend on the path)
     auto issue = [&](const SellTile &d, Buf &bf) {
         const bool fast = d.flags() & SELL_FAST; // uniform
         const SellBlock blk(stream + (fast ? d.off16 * 16 : 0), d.meta);
-        bf.len = blk.len(lane);
         if (HAS_K) bf.kk = kmult[(fast ? d.r0 : 0) + min(lane, (fast ? d.nrows() : 1u) - 1u)];
 #define EMS_ISSUE(i) bf.g##i = blk.template group<i>(lane);
         EMS_GROUPS(EMS_ISSUE)
@@ -292,7 +291,7 @@ __global__ __launch_bounds__(64 * W) void k_em_sell(const IdxT *__restrict__ row
     EmAcc acc;
     auto walk = [&](const SellTile &d, const Buf &bf) {
         const uint32_t ng = d.ng();                                    // uniform
-        const uint32_t *__restrict__ src = (const uint32_t *)(stream + d.off16 * 16 + 64) + lane; // groups beyond the cached ones
+        const uint32_t *__restrict__ src = (const uint32_t *)(stream + d.off16 * 16) + lane; // groups beyond the cached ones
         double t = 0.0;
 #define EMS_SUM(i)                                                                                          \
         if ((uint32_t)i < ng) {                                                                              \
@@ -308,7 +307,7 @@ __global__ __launch_bounds__(64 * W) void k_em_sell(const IdxT *__restrict__ row
             const double w0 = wo(EMS_OFF0(v)), w1 = wo(EMS_OFF1(v)), w2 = wo(EMS_OFF2(v)), w3 = wo(EMS_OFF3(v));
             t += w0; t += w1; t += w2; t += w3;
         }
-        if (bf.len == 0) return;
+        if ((bf.g0 & 0xffu) == 0xffu) return; // no hit in this lane: the first slot of a row is a pad (255) only then
         uint64_t x;
         int xe;
         if (!em_row_head<MEASURE>(t, HAS_K ? bf.kk : 1u, acc, x, xe)) return;

@@ -269,7 +269,7 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
                 const uint32_t ng = (far_nn[t] + 3) / 4;
                 q.meta = sell_meta(d.nrows, ng, SELL_FAR | hask, far_nf[t]);
                 q.off16 = pos;
-                pos += 4 + 16 * (uint64_t)ng + 4 + 16 * (uint64_t)far_nf[t];
+                pos += 16 * (uint64_t)ng + 4 + 16 * (uint64_t)far_nf[t];
                 slots += 256 * (uint64_t)ng + 64 * (uint64_t)far_nf[t];
                 ++n_far;
                 continue;
@@ -283,7 +283,7 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
                 const uint32_t ng = (d.maxlen + 3) / 4;
                 q.meta = sell_meta(d.nrows, ng, SELL_FAST | hask);
                 q.off16 = pos;
-                pos += 4 + 16 * (uint64_t)ng;
+                pos += 16 * (uint64_t)ng;
                 slots += 256 * (uint64_t)ng;
                 ++n_fast;
             } else {

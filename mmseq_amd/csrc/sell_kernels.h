@@ -28,14 +28,21 @@ struct SellBlock {
     __amdgpu_buffer_rsrc_t rs;
     // extra: bytes behind the window part that the descriptor covers as well (the far list of a far tile)
     __device__ SellBlock(const uint8_t *blk, uint32_t meta, uint32_t extra = 0)
-        : rs(__builtin_amdgcn_make_buffer_rsrc((void *)blk, 0, (int)((meta & 0xff00u) + 64u + extra), 0x00020000)) {} // 0x00020000: gfx9 raw dword buffer
-    __device__ uint32_t len(uint32_t lane) const { return __builtin_amdgcn_raw_buffer_load_b8(rs, (int)lane, 0, 0); }
+        : rs(__builtin_amdgcn_make_buffer_rsrc((void *)blk, 0, (int)((meta & 0xff00u) + extra), 0x00020000)) {} // 0x00020000: gfx9 raw dword buffer
     // group i of the lane's row; the constant part of the offset folds into the instruction, aux 2 = nontemporal (streamed once)
     template <int I> __device__ uint32_t group(uint32_t lane) const
     {
-        return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(lane * 4u + 64u + (uint32_t)I * 256u), 0, 2);
+        return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(lane * 4u + (uint32_t)I * 256u), 0, 2);
     }
 };
+
+// hits in a group word: pads (255) fill the tail of a row, a row's length is the number of bytes below 255 in its groups -- the stream
+// carries no length (only the rare paths of a draw and the multiplicity paths ask for it)
+__device__ __forceinline__ uint32_t sell_group_hits(uint32_t w)
+{
+    const uint32_t m = ~w;
+    return (uint32_t)((m & 0xffu) != 0u) + (uint32_t)((m & 0xff00u) != 0u) + (uint32_t)((m & 0xff0000u) != 0u) + (uint32_t)((m & 0xff000000u) != 0u);
+}
 
 // Far-tile facts the host needs before it can lay the stream out: the window base a tile's rows were sorted for (the band field of
 // the first non-empty row's key, mmg_types.h), the most window hits and the most other hits a row of the tile has -- or "not a far
@@ -80,9 +87,9 @@ __global__ __launch_bounds__(64) void k_tile_far(const IdxT *__restrict__ row_pt
     if (lane == 0) { out[blockIdx.x] = wbase; out[n_cand + blockIdx.x] = nn; out[2 * n_cand + blockIdx.x] = nf; }
 }
 
-// Block of a fast tile: 64 length bytes, then ng groups of 64 lanes x 4 u8 window indices (col - wbase), 255 = pad.
-// Block of a far tile: the same for the window hits at the head of every row (the length byte counts those), then 64 far-count bytes
-// and nf groups of 64 lanes x u32: the transcript ids of the lane's other hits in stored order (0 beyond the row's own count).
+// Block of a fast tile: ng groups of 64 lanes x 4 u8 window indices (col - wbase), 255 = pad (a row's length is what is not a pad).
+// Block of a far tile: the same for the window hits at the head of every row, then 64 far-count bytes and nf groups of 64 lanes x
+// u32: the transcript ids of the lane's other hits in stored order (0 beyond the row's own count).
 template <typename IdxT>
 __global__ __launch_bounds__(64) void k_encode_sell(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
                                                     const SellTile *__restrict__ tiles, uint64_t n_tiles, uint8_t *stream)
@@ -102,8 +109,7 @@ __global__ __launch_bounds__(64) void k_encode_sell(const IdxT *__restrict__ row
         if (d.flags() & SELL_FAR)
             for (Ln = 0; Ln < L && (col_idx[b + Ln] - d.wbase) < SELL_WIN; ++Ln) {}
     }
-    blk[lane] = (uint8_t)Ln; // these tiles hold rows of at most 255 hits
-    uint32_t *grp = (uint32_t *)(blk + 64) + lane;
+    uint32_t *grp = (uint32_t *)blk + lane; // (these tiles hold rows of at most 255 hits)
     for (uint32_t g = 0; g < d.ng(); ++g) {
         uint32_t w = 0;
         for (uint32_t j = 0; j < 4; ++j) {
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(64) void k_encode_sell(const IdxT *__restrict__ row
         grp[(size_t)g * 64] = w;
     }
     if (d.flags() & SELL_FAR) {
-        uint8_t *fb = blk + 64 + (size_t)d.ng() * 256;
+        uint8_t *fb = blk + (size_t)d.ng() * 256;
         fb[lane] = (uint8_t)(L - Ln);
         uint32_t *far = (uint32_t *)(fb + 64) + lane;
         for (uint32_t f = 0; f < d.nf(); ++f) far[(size_t)f * 64] = f < L - Ln ? col_idx[b + Ln + f] : 0u;
@@ -232,21 +238,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
     static_assert(NGC == 8, "the group list above is written out for 8 cached groups");
     struct Buf {
         uint32_t g0, g1, g2, g3, g4, g5, g6, g7;
-        uint32_t len;
         uint32_t kk; // multiplicity of the lane's row (HAS_K)
         uint32_t lf, f0; // FARPF: entries in the lane's far list, the first of them
     };
-    // request a tile's block: the lane's length byte and NGC groups, UNCONDITIONALLY (tiles without a block -- empty, slow, past
-    // the end of the range -- ask for the head of the stream instead).  Loads retire in order and are waited for by count, so the
+    // request a tile's block: the lane's NGC groups, UNCONDITIONALLY (for tiles without a block -- empty, slow, past the end of
+    // the range -- every request fails the range check).  Loads retire in order and are waited for by count, so the
     // number issued per tile must not depend on the path -- otherwise the compiler has to assume the fewest, and every walk
     // waits for the prefetch issued just before it.  Groups beyond the tile's ng fail the descriptor's range check: no memory access.
     auto issue = [&](const SellTile &d, Buf &bf) {
         const bool fast = d.flags() & (SELL_FAST | SELL_FAR); // uniform: the tile has a block (a far tile's window part is a fast tile's)
         const bool farb = FARPF && (d.flags() & SELL_FAR);
         const SellBlock blk(stream + (fast ? d.off16 * 16 : 0), d.meta, farb ? 64u + d.nf() * 256u : 0u);
-        bf.len = blk.len(lane);
         if (FARPF) { // two more loads, whatever the tile (a tile without a far list reads its own head again)
-            const uint32_t fo = farb ? 64u + d.ng() * 256u : 0u; // the far part: 64 count bytes, then nf groups of 64 transcript ids
+            const uint32_t fo = farb ? d.ng() * 256u : 0u; // the far part: 64 count bytes, then nf groups of 64 transcript ids
             bf.lf = __builtin_amdgcn_raw_buffer_load_b8(blk.rs, (int)lane, (int)fo, 0);
             bf.f0 = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(blk.rs, (int)(lane * 4u + 64u), (int)fo, 2);
         }
@@ -292,8 +296,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
     auto walk = [&](const SellTile &d, const Buf &bf, uint32_t which, auto far_tag) {
         constexpr bool FAR = decltype(far_tag)::value;
         const uint32_t ng = d.ng();                                    // uniform
-        const uint32_t *__restrict__ src = (const uint32_t *)(stream + d.off16 * 16 + 64) + lane; // groups beyond the cached ones
-        const uint32_t L = bf.len;
+        const uint32_t *__restrict__ src = (const uint32_t *)(stream + d.off16 * 16) + lane; // groups beyond the cached ones
+        // the row's window hits, counted when a path asks for them (never on the path of an ordinary draw)
+        auto row_len = [&]() -> uint32_t {
+            uint32_t n = 0;
+#define SELL_CNT(i) if ((uint32_t)i < ng) n += sell_group_hits(bf.g##i);
+            SELL_GROUPS(SELL_CNT)
+#undef SELL_CNT
+            for (uint32_t g = NGC; g < ng; ++g) n += sell_group_hits(src[(size_t)g * 64]);
+            return n;
+        };
         const uint32_t xrow = which ? xrowB : xrowA;
         double t = 0.0;
         double m0 = 0.0; // FARPF: the weight of the lane's first far hit, requested before the window part is walked
@@ -338,7 +350,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
         uint32_t Lf = 0;
         const uint32_t *__restrict__ farp = nullptr;
         if (FAR) {
-            const uint8_t *__restrict__ fb = stream + d.off16 * 16 + 64 + (size_t)ng * 256;
+            const uint8_t *__restrict__ fb = stream + d.off16 * 16 + (size_t)ng * 256;
             farp = (const uint32_t *)(fb + 64) + lane;
             if (FARPF) {
                 Lf = bf.lf;
@@ -349,6 +361,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
                 for (uint32_t f = 0; f < Lf; ++f) t += gmu[farp[(size_t)f * 64]];
             }
         }
+        const uint32_t L_k = HAS_K ? row_len() : 0u, L = L_k; // (without multiplicities only the draw's rare path needs it)
         if (HAS_K && L + Lf == 0) return; // (without multiplicities an empty row falls out of the draw's rare path: one test less per tile)
         uint32_t farc = 0; // the transcript of a pick from the far list (draw() then returns FAR_PICK)
         constexpr uint32_t FAR_PICK = 0xffffffffu;
@@ -438,6 +451,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
                              : [t] "v"(target), [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [o0] "v"(o0), [o1] "v"(o1), [o2] "v"(o2));
             }
             if (!hit) { // rare: an empty row, a degenerate total (0, inf, NaN never compare below anything), a row of more than 32 hits, rounding
+                const uint32_t L = HAS_K ? L_k : row_len();
                 if (L + Lf == 0) sel = (uint32_t)WIN * 8u; // no row in this lane: the count of the pad slot, which is never flushed
                 else if (degenerate) {
                     const uint32_t Lt = L + Lf;
@@ -519,14 +533,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
 
     auto far_tile = [&](const SellTile &d) {
         if (lane < d.nrows()) {
-            const uint8_t *__restrict__ blk = stream + d.off16 * 16, *__restrict__ fb = blk + 64 + (size_t)d.ng() * 256;
-            const uint32_t wbase = d.wbase, Ln = blk[lane];
+            const uint8_t *__restrict__ blk = stream + d.off16 * 16, *__restrict__ fb = blk + (size_t)d.ng() * 256;
+            const uint32_t wbase = d.wbase;
+            uint32_t Ln = 0;
+            for (uint32_t g = 0; g < d.ng(); ++g) Ln += sell_group_hits(((const uint32_t *)blk + lane)[(size_t)g * 64]);
             auto add = [&](uint32_t col, int32_t x) {
                 const uint32_t dd = col - wbase;
                 if (dd < (uint32_t)WIN) atomicAdd(&s_cnt[2 * dd], x);
                 else global_count_add(gcnt, col, x);
             };
-            const RowViewFarTile v{(const uint32_t *)(blk + 64) + lane, (const uint32_t *)(fb + 64) + lane, Ln, Ln + fb[lane], wbase, s_mu, gmu};
+            const RowViewFarTile v{(const uint32_t *)blk + lane, (const uint32_t *)(fb + 64) + lane, Ln, Ln + fb[lane], wbase, s_mu, gmu};
             allocate_row<HAS_K>(v, add, HAS_K ? kmult[d.r0 + lane] : 1u, a, a.row_id_base + d.r0 + lane);
         }
     };

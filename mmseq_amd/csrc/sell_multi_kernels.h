@@ -83,12 +83,10 @@ __global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict
 #define SM_GROUPS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
     struct Buf {
         uint32_t g0, g1, g2, g3, g4, g5, g6, g7;
-        uint32_t len;
     };
     auto issue = [&](const SellTile &d, Buf &bf) {
         const bool fast = d.flags() & SELL_FAST; // uniform
         const SellBlock blk(stream + (fast ? d.off16 * 16 : 0), d.meta);
-        bf.len = blk.len(lane);
 #define SM_ISSUE(i) bf.g##i = blk.template group<i>(lane);
         SM_GROUPS(SM_ISSUE)
 #undef SM_ISSUE
@@ -117,8 +115,15 @@ __global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict
 
     auto walk = [&](const SellTile &d, const Buf &bf, uint32_t which) {
         const uint32_t ng = d.ng();                                    // uniform
-        const uint32_t *__restrict__ src = (const uint32_t *)(stream + d.off16 * 16 + 64) + lane; // groups beyond the cached ones
-        const uint32_t L = bf.len;
+        const uint32_t *__restrict__ src = (const uint32_t *)(stream + d.off16 * 16) + lane; // groups beyond the cached ones
+        auto row_len = [&]() -> uint32_t { // the row's hits, counted on the rare paths only (sell_kernels.h: sell_group_hits)
+            uint32_t n = 0;
+#define SM_CNT(i) if ((uint32_t)i < ng) n += sell_group_hits(bf.g##i);
+            SM_GROUPS(SM_CNT)
+#undef SM_CNT
+            for (uint32_t g = 8; g < ng; ++g) n += sell_group_hits(src[(size_t)g * 64]);
+            return n;
+        };
         double t[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) t[c] = 0.0;
@@ -230,6 +235,7 @@ __global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict
                              : [t] "v"(target), [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [o0] "v"(o0), [o1] "v"(o1), [o2] "v"(o2));
             }
             if (!hit) { // rare: an empty row, a degenerate total, a row of more than 32 hits, rounding
+                const uint32_t L = row_len();
                 if (L == 0) sel = (uint32_t)WIN << SH; // no row in this lane: the count of the pad slot, which is never flushed
                 else if (degenerate) {
                     const uint32_t j = (uint32_t)(u32_unit(x) * (double)L);
