@@ -434,17 +434,18 @@ def main():
                                     c3["k1_avg_launch_ms_all_chains"] * 1e-3 / (c3["chains"] // 2), (c3["chains"] // 2) * (c3["steps"] // 4 + 1), tiles,
                                     stream_bytes=c3["stream_bytes"], algorithmic_bytes=4 * (c3["reads"] + 1) + 4 * c3["hits"] + 24 * c3["transcripts"])
                 rb["chain_iterations_per_sec"] = c3["chain_iterations_per_sec"]
-                rb["bound"] = "valu"
-                rb["note"] = ("the stream is read once per PAIR of chains: 3.4 TB/s of HBM traffic, not the bound; valu.busy_frac (counted VALU instructions x 4.3 "
-                              "clocks / SIMD cycles) and lds.busy_frac are -- see DESIGN.md section 4 for the instruction budget per tile")
+                rb["bound"] = "lds+valu"
+                rb["note"] = ("the stream is read once per PAIR of chains: about 3 TB/s of HBM traffic, not the bound; lds.busy_frac and valu.busy_frac "
+                              "(counted VALU instructions x 4.3 clocks / SIMD cycles) are -- see DESIGN.md section 4 for the instruction budget per tile")
                 other.append(rb)
             try:
                 em = em_measurement(R3, T3, H3, seed=args.seed, device=local_rank)
                 rb = roofline_block("k_em_sell (K3: rows pass of one EM sweep)", "em_sweep", em["ms_per_sweep"] * 1e-3, em["sweeps"], em["n_tiles"],
                                     stream_bytes=em["stream_bytes"])
-                rb["bound"] = "valu"
-                rb["note"] = ("avg_launch_ms is the wall time of one mmg_em_step (rows pass + per-transcript kernels + one read-back); bound by the "
-                              "fixed-point arithmetic per hit (valu.busy_frac), then by its LDS atomics (two 64-bit adds per hit, lds.busy_frac)")
+                rb["bound"] = "lds"
+                rb["note"] = ("avg_launch_ms is the wall time of one mmg_em_step (rows pass + per-transcript kernels + one read-back); bound by the LDS: "
+                              "per hit one 8-byte gather, one scale word and two 64-bit atomic adds on random window slots (lds.busy_frac, most of it "
+                              "bank conflicts); the limbs of a term are three 64-bit shifts (valu.busy_frac)")
                 other.append(rb)
             except Exception as e:
                 other.append({"kernel": "k_em_sell", "error": repr(e)})
