@@ -136,7 +136,7 @@ __device__ __forceinline__ bool em_row_head(double d, uint32_t kk, EmAcc &acc, u
     xe = (int)((xb >> 52) & 0x7ff) - 1023; // x is normal here
     T = (xb << 11) | (1ull << 63);
     if (!MEASURE) {
-        const double v = dk * dlog(d) * 4096.0, fv = dfloor(v);
+        const double v = dk * dlog_pn(d) * 4096.0, fv = dfloor(v); // d is normal here (the range test above)
         acc.llh += (int64_t)fv;
         acc.lll += (uint64_t)((v - fv) * 2147483648.0);
     }

@@ -240,6 +240,33 @@ MMG_HD double dlog(double x)
     return s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;
 }
 
+// dlog for a positive, normal, finite argument: the same arithmetic without the special cases (for x == 1.0 every term is +0.0, like
+// the early return) -- straight-line code the scheduler can interleave with independent work
+MMG_HD double dlog_pn(double x)
+{
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                 Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    const uint64_t ix = bits_of(x);
+    uint32_t hx = (uint32_t)(ix >> 32);
+    hx += 0x3ff00000u - 0x3fe6a09eu;
+    const int k = (int)(hx >> 20) - 0x3ff;
+    hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
+    x = double_of(((uint64_t)hx << 32) | (ix & 0xffffffffull));
+    const double f = x - 1.0;
+    const double hfsq = 0.5 * f * f;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double R = t2 + t1;
+    const double dk = (double)k;
+    return s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;
+}
+
 MMG_HD double dscalbn(double y, int n)
 {
     if (n > 1023) {
@@ -344,14 +371,14 @@ MMG_HD double gamma_unit(Stream &s, double a_in)
         const uint32_t j1 = ok0 ? 0u : (ok1 ? 1u : 2u);
         const double v1 = ok0 ? a0 : (ok1 ? a1 : a2), q = ok0 ? q0 : (ok1 ? q1 : q2);
         ua = ok0 ? u52(r1.x, r1.y) : (ok1 ? u52(r2.x, r2.y) : u52(r3.x, r3.y)); // the first uniform of the pair behind it
-        x = v1 * dsqrt(-2.0 * dlog(q) / q);
+        x = v1 * dsqrt(-2.0 * dlog_pn(q) / q); // 0 < q < 1, normal (a sum of squares of multiples of 2^-52)
         v = 1.0 + c * x;
         if (v <= 0.0) { s.c3 += j1 + 1u; continue; } // the polar method goes on with the next pair
         v = v * v * v;
         s.c3 += j1 + 2u;
         const double x2 = x * x;
         if (ua < 1.0 - 0.0331 * x2 * x2) break;
-        if (dlog(ua) < 0.5 * x2 + d * (1.0 - v + dlog(v))) break;
+        if (dlog_pn(ua) < 0.5 * x2 + d * (1.0 - v + dlog_pn(v))) break; // ua >= 2^-53; v = (1 + c x)^3 >= 2^-159
     }
 #else
     for (;;) {
@@ -371,7 +398,11 @@ MMG_HD double gamma_unit(Stream &s, double a_in)
     if (a_in < 1.0) {
         double ub;
         s.pair(ua, ub);
+#if defined(__HIP_DEVICE_COMPILE__)
+        g = g * dexp(dlog_pn(ua) / a_in); // ua >= 2^-53
+#else
         g = g * dexp(dlog(ua) / a_in);
+#endif
     }
     return g;
 }
