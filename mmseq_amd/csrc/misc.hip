@@ -6,8 +6,7 @@ namespace mmg {
 
 void launch_update(const UpdateArgs &a, hipStream_t s)
 {
-    const uint64_t total = (uint64_t)a.n * a.n_chains;
-    hipLaunchKernelGGL(k_update, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_update, dim3((a.n + 255u) / 256u, a.n_chains), dim3(256), 0, s, a);
 }
 
 void launch_transpose(const double *in, double *out, uint32_t n, uint32_t S, const uint32_t *int_of_ext, hipStream_t s)

@@ -9,10 +9,9 @@ namespace mmg {
 // K2: one lane per (chain, transcript).  HBM: 28 bytes per lane on kept iterations.
 __global__ __launch_bounds__(256) void k_update(UpdateArgs a)
 {
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t total = (uint64_t)a.n * a.n_chains;
-    if (gid >= total) return;
-    const uint32_t c = (uint32_t)(gid / a.n), t = (uint32_t)(gid % a.n);
+    const uint32_t c = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x; // grid.y = chains: no 64-bit division per lane
+    if (t >= a.n) return;
+    const uint64_t gid = (uint64_t)c * a.n + t;
     const int32_t x = a.cnt[gid];
     // the moments are read-modify-write: their loads go out with the count's, not after the draw (a wave of this kernel is one long
     // dependent chain -- at config 2 there is one wave per SIMD and nothing to hide a second memory round trip behind)
