@@ -152,16 +152,18 @@ extern "C" int mmg_sampler_sample(mmg_sampler *s)
             if (fuse == 4 && p->grid_sell_m[1] <= 0) fuse = 2;
             if (p->grid_sell_m[0] <= 0 || !p->d_sell_tiles_f) fuse = 1;
             const int n_fused = fuse > 1 ? (C / fuse) * fuse : 0, n_rest = fuse == 4 ? ((C - n_fused) / 2) * 2 : 0;
+            // one launch per fusion width: grid.y = the groups of `f` chains
             for (int c = 0; c < n_fused + n_rest; ) {
                 const int f = c < n_fused ? fuse : 2;
+                const int groups = (c < n_fused ? n_fused - c : n_fused + n_rest - c) / f;
                 SampleArgs a = args_of(c);
                 const SellTile *ts = p->d_sell_tiles_f;
                 const uint64_t *cs = p->d_sell_chunk_m[f == 4 ? 1 : 0];
                 const double *mu = s->d_mu + (size_t)c * p->n;
                 int32_t *cnt = s->d_cnt + (size_t)c * p->n;
                 void *kargs[] = {(void *)&rp, (void *)&ci, (void *)&ts, (void *)&cs, (void *)&mu, (void *)&ss, (void *)&cnt, (void *)&a};
-                HIP_TRY(hipLaunchKernel(k1_sell_multi_kernel(p->idx64, f), dim3(p->grid_sell_m[f == 4 ? 1 : 0]), dim3(64), kargs, 0, s->cur));
-                c += f;
+                HIP_TRY(hipLaunchKernel(k1_sell_multi_kernel(p->idx64, f), dim3(p->grid_sell_m[f == 4 ? 1 : 0], groups), dim3(64), kargs, 0, s->cur));
+                c += f * groups;
             }
             const int n_paired = n_fused + n_rest;
             if (n_paired > 0 && p->grid_sell_x > 0) { // their far / CSR-walked tiles: the far-list instantiation, all paired chains in one launch

@@ -25,6 +25,11 @@ __global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict
     // weights, plus 8 c, addresses chain c's count of it -- no address arithmetic per pick
     __shared__ int32_t s_cnt[2 * NCH * (WIN + 1)];
     const uint32_t lane = threadIdx.x;
+    // grid.y = group of NCH chains: one launch advances all the fused chains of a sampler (the tail of one group overlaps the head of
+    // the next instead of a launch boundary)
+    gmu += (size_t)blockIdx.y * NCH * a.n;
+    gcnt += (size_t)blockIdx.y * NCH * a.n;
+    a.chain += blockIdx.y * (uint32_t)NCH;
 
     // the range's header (mmgibbs.hip: upload_ranges): first tile, end tile, the descriptors of its first two tiles -- one scalar load
     const uint64_t *__restrict__ hdr = chunk_tile + (size_t)blockIdx.x * 8;
