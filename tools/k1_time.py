@@ -11,4 +11,4 @@ s = Sampler(prob, mu0, n_chains=C, gibbs_iter=1024, trace_len=1024, keep_trace=F
 s.run(300); s.sync(); s.reset_timing()
 s.run(100); s.sync()
 tm = s.timing()
-print("chains", C, "K1 %.4f ms" % (tm["sample_ms"] / tm["sample_launches"]), "K2 %.4f" % (tm["update_ms"] / tm["update_launches"]), os.environ.get("MMG_EXP_HOTSTREAM"))
+print("chains", C, "K1 %.4f ms" % (tm["sample_ms"] / tm["sample_launches"]), "K2 %.4f" % (tm["update_ms"] / tm["update_launches"]))
