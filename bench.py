@@ -439,9 +439,13 @@ def main():
             c3 = next((e for e in extra if e.get("name", "").startswith("config 3") and "error" not in e), None)
             if c3:
                 tiles = inf.n_tiles
-                rb = roofline_block("k_sample_sell_multi<2> (K1m: one launch advances two chains)", "k1m_8chains",
-                                    c3["k1_avg_launch_ms_all_chains"] * 1e-3 / (c3["chains"] // 2), (c3["chains"] // 2) * (c3["steps"] // 4 + 1), tiles,
-                                    stream_bytes=c3["stream_bytes"], algorithmic_bytes=4 * (c3["reads"] + 1) + 4 * c3["hits"] + 24 * c3["transcripts"])
+                pairs = c3["chains"] // 2
+                # ONE launch advances all the chains, pair by pair (grid.y = pair): its duration, its counters, `pairs` passes over the
+                # stream and `pairs` x tiles tile-visits (instructions_per_64_row_tile is per visit, i.e. per tile and PAIR of chains)
+                rb = roofline_block("k_sample_sell_multi<2> (K1m: one launch advances the %d chains in %d pairs)" % (c3["chains"], pairs), "k1m_8chains",
+                                    c3["k1_avg_launch_ms_all_chains"] * 1e-3, c3["steps"] // 4 + 1, tiles * pairs,
+                                    stream_bytes=c3["stream_bytes"] * pairs,
+                                    algorithmic_bytes=pairs * (4 * (c3["reads"] + 1) + 4 * c3["hits"] + 24 * c3["transcripts"]))
                 rb["chain_iterations_per_sec"] = c3["chain_iterations_per_sec"]
                 rb["bound"] = "lds+valu"
                 rb["note"] = ("the stream is read once per PAIR of chains: about 3 TB/s of HBM traffic, not the bound; lds.busy_frac and valu.busy_frac "
