@@ -425,6 +425,16 @@ int main(int argc, char **argv)
          << "  gpus:          " << gpus << endl
          << "  chains:        " << chains << endl;
 
+    // The HIP runtime, the device context and the library's code object are brought up while the hits file is read (they are first
+    // needed at the device problem build, where they used to cost about two seconds of an otherwise idle GPU): one tiny kernel
+    // launch on a thread of its own.  Its result is ignored -- a device that cannot be used is reported by mmg_problem_create.
+    std::thread device_warmup([device]() {
+        const uint32_t ctr[4] = {0, 0, 0, 0}, key[2] = {0, 0};
+        uint32_t out[6];
+        (void)mmg_selftest_philox(device, ctr, key, out);
+    });
+    struct WarmupJoiner { std::thread &t; ~WarmupJoiner() { if (t.joinable()) t.join(); } } device_warmup_join{device_warmup};
+
     // ---- header (src/mmseq.cpp:332-379)
     map<string, double> sidLen;
     map<string, int> sidSeqLen;
@@ -726,18 +736,22 @@ int main(int argc, char **argv)
 
     stage.mark("unique hits (sets, genes)");
     // ---- .k and .M (src/mmseq.cpp:682-695): 14 GB of text at 50 M reads, written by a thread of its own while the device builds the
-    //      problem and runs EM and Gibbs (the arrays it reads are not touched again; joined before the run ends)
+    //      problem and runs EM and Gibbs (the arrays it reads are not touched again; joined before the run ends).  Its formatting
+    //      threads leave three CPUs of the container's quota alone: with all of them busy the quota runs out and the main thread is
+    //      throttled with them -- the upload of the matrix (4 GB of pageable memory through the runtime's staging copies) took 2.8 s
+    //      instead of 0.3 s, and an EM sweep (a kernel and a read-back) 8 ms instead of 1.3.
     ofstream ofs;
-    std::thread km_writer([&, m, n]() {   // integer tables: chunks of rows formatted in parallel (to_chars), written in order
+    const int km_threads = max(1, omp_get_max_threads() - 3);
+    std::thread km_writer([&, m, n, km_threads]() {   // integer tables: chunks of rows formatted in parallel (to_chars), written in order
         ofstream ofs;
         auto write_rows = [&](ofstream &o, const function<void(uint64_t, string &)> &fmt) {
             const uint64_t chunk = 1u << 16;
             const int64_t nchunks = (int64_t)((m + chunk - 1) / chunk);
-            const int64_t batch = max<int64_t>(1, omp_get_max_threads() * 2);
+            const int64_t batch = max<int64_t>(1, km_threads * 2);
             for (int64_t c0 = 0; c0 < nchunks; c0 += batch) {
                 const int64_t nb = min(batch, nchunks - c0);
                 vector<string> out(nb);
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(km_threads)
                 for (int64_t c = 0; c < nb; ++c) {
                     const uint64_t r0 = (uint64_t)(c0 + c) * chunk, r1 = min<uint64_t>(m, r0 + chunk);
                     for (uint64_t i = r0; i < r1; ++i) fmt(i, out[c]);
@@ -819,6 +833,7 @@ int main(int argc, char **argv)
         memset(&pd, 0, sizeof pd);
         pd.m = m; pd.n = n; pd.row_ptr = row_ptr.data(); pd.col_idx = col_idx.data(); pd.k = k.data(); pd.l = l.data();
         pd.row_id_base = 0; pd.layout = MMG_LAYOUT_CANONICAL; pd.tx_order = tx_order.data();
+        if (device_warmup.joinable()) device_warmup.join();
         MMG_TRY(mmg_problem_create(&pd, device, &prob));
         if (stage.on) {
             mmg_problem_info inf;
