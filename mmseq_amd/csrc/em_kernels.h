@@ -280,7 +280,7 @@ __global__ __launch_bounds__(64 * W) void k_em_sell(const IdxT *__restrict__ row
     };
     // unconditional, like k_sample_sell::issue (the number of loads per tile must not depend on the path)
     auto issue = [&](const SellTile &d, Buf &bf) {
-        const bool fast = d.flags() & SELL_FAST; // uniform
+        const bool fast = d.flags() & (SELL_FAST | SELL_FAR); // uniform: the tile has a block (a far tile's window part is a fast tile's)
         const SellBlock blk(stream + (fast ? d.off16 * 16 : 0), d.meta);
         if (HAS_K) bf.kk = kmult[(fast ? d.r0 : 0) + min(lane, (fast ? d.nrows() : 1u) - 1u)];
 #define EMS_ISSUE(i) bf.g##i = blk.template group<i>(lane);
@@ -289,7 +289,9 @@ __global__ __launch_bounds__(64 * W) void k_em_sell(const IdxT *__restrict__ row
     };
 
     EmAcc acc;
-    auto walk = [&](const SellTile &d, const Buf &bf) {
+    // far (uniform): a far tile -- the hits of a row outside the window follow its window hits in the far list of the tile's block
+    // (k_encode_sell), in stored order; their weights come from global memory, their terms go to the global accumulators
+    auto walk = [&](const SellTile &d, const Buf &bf, bool far) {
         const uint32_t ng = d.ng();                                    // uniform
         const uint32_t *__restrict__ src = (const uint32_t *)(stream + d.off16 * 16) + lane; // groups beyond the cached ones
         double t = 0.0;
@@ -307,7 +309,15 @@ __global__ __launch_bounds__(64 * W) void k_em_sell(const IdxT *__restrict__ row
             const double w0 = wo(EMS_OFF0(v)), w1 = wo(EMS_OFF1(v)), w2 = wo(EMS_OFF2(v)), w3 = wo(EMS_OFF3(v));
             t += w0; t += w1; t += w2; t += w3;
         }
-        if ((bf.g0 & 0xffu) == 0xffu) return; // no hit in this lane: the first slot of a row is a pad (255) only then
+        uint32_t Lf = 0;
+        const uint32_t *__restrict__ farp = nullptr;
+        if (far) {
+            const uint8_t *__restrict__ fb = stream + d.off16 * 16 + (size_t)ng * 256;
+            Lf = fb[lane];
+            farp = (const uint32_t *)(fb + 64) + lane;
+            for (uint32_t f = 0; f < Lf; ++f) t += a.mu[farp[(size_t)f * 64]];
+        }
+        if ((bf.g0 & 0xffu) == 0xffu && Lf == 0) return; // no hit in this lane: the first slot of a row is a pad (255) only then
         uint64_t x;
         int xe;
         if (!em_row_head<MEASURE>(t, HAS_K ? bf.kk : 1u, acc, x, xe)) return;
@@ -353,6 +363,18 @@ __global__ __launch_bounds__(64 * W) void k_em_sell(const IdxT *__restrict__ row
         for (uint32_t g = 8; g < ng; ++g) {
             const uint32_t v = src[(size_t)g * 64];
             give4(EMS_OFF0(v), EMS_OFF1(v), EMS_OFF2(v), EMS_OFF3(v));
+        }
+        for (uint32_t f = 0; f < Lf; ++f) { // (Lf is 0 unless the tile is a far tile)
+            const uint32_t c = farp[(size_t)f * 64];
+            if (MEASURE) {
+                atomicMax(&a.xe[c], xe);
+            } else {
+                uint64_t yh, yl;
+                if (em_term(x, xe, a.word[c], acc, yh, yl)) {
+                    if (yh) atomicAdd((unsigned long long *)&a.hi[c], (unsigned long long)yh);
+                    if (yl) atomicAdd((unsigned long long *)&a.lo[c], (unsigned long long)yl);
+                }
+            }
         }
     };
 #undef EMS_GROUPS
@@ -418,7 +440,8 @@ __global__ __launch_bounds__(64 * W) void k_em_sell(const IdxT *__restrict__ row
             }
         }
         if (d.flags() & SELL_EMPTY) { issue(refill, bf); return; }
-        if (d.flags() & SELL_FAST) walk(d, bf);
+        if (d.flags() & SELL_FAST) walk(d, bf, false);
+        else if (d.flags() & SELL_FAR) walk(d, bf, true);
         else slow_tile(d);
         issue(refill, bf);
     };
