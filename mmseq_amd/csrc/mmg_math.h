@@ -410,22 +410,22 @@ MMG_HD double gamma_unit(Stream &s, double a_in)
 // log(k!) Stirling remainder used by the binomial rejection sampler
 MMG_HD double stirling_tail(double k)
 {
-    if (k <= 9.0) {
-        switch ((int)k) {
-        case 0: return 0.0810614667953272;
-        case 1: return 0.0413406959554092;
-        case 2: return 0.0276779256849983;
-        case 3: return 0.02079067210376509;
-        case 4: return 0.0166446911898211;
-        case 5: return 0.0138761288230707;
-        case 6: return 0.0118967099458917;
-        case 7: return 0.0104112652619720;
-        case 8: return 0.00925546218271273;
-        default: return 0.00833056343336287;
-        }
-    }
+    // k <= 9: tabulated.  A chain of selects, not a switch: the lanes of a wave ask for different k, and a switch is one branch
+    // target per case, run one after the other.
+    const int i = k <= 9.0 ? (int)k : 9;
+    double t = 0.0810614667953272;
+    t = i >= 1 ? 0.0413406959554092 : t;
+    t = i >= 2 ? 0.0276779256849983 : t;
+    t = i >= 3 ? 0.02079067210376509 : t;
+    t = i >= 4 ? 0.0166446911898211 : t;
+    t = i >= 5 ? 0.0138761288230707 : t;
+    t = i >= 6 ? 0.0118967099458917 : t;
+    t = i >= 7 ? 0.0104112652619720 : t;
+    t = i >= 8 ? 0.00925546218271273 : t;
+    t = i >= 9 ? 0.00833056343336287 : t;
     const double kp1sq = (k + 1.0) * (k + 1.0);
-    return (1.0 / 12.0 - (1.0 / 360.0 - 1.0 / 1260.0 / kp1sq) / kp1sq) / (k + 1.0);
+    const double f = (1.0 / 12.0 - (1.0 / 360.0 - 1.0 / 1260.0 / kp1sq) / kp1sq) / (k + 1.0);
+    return k <= 9.0 ? t : f;
 }
 
 // Binomial(n, p): sequential-search inversion below n*min(p,1-p) < 10, Hormann's BTRS above
@@ -441,7 +441,7 @@ MMG_HD uint32_t binomial(Src &q, uint32_t n, double p)
     if (dn * p < 10.0) {
         const double qq = 1.0 - p, s = p / qq, a = (dn + 1.0) * s;
         for (;;) {
-            double r = dexp(dn * dlog(qq));
+            double r = dexp(dn * dlog_pn(qq)); // 0.5 <= qq < 1
             double u = q.next();
             uint32_t x = 0;
             bool ok = true;
@@ -469,10 +469,11 @@ MMG_HD uint32_t binomial(Src &q, uint32_t n, double p)
             const double kf = dfloor((2.0 * a / us + b) * u + c);
             if (kf < 0.0 || kf > dn) continue;
             if (us >= 0.07 && v <= vr) { res = (uint32_t)kf; break; }
-            v = dlog(v * alpha / (a / (us * us) + b));
-            const double ub = (m + 0.5) * dlog((m + 1.0) / (r * (dn - m + 1.0))) +
-                              (dn + 1.0) * dlog((dn - m + 1.0) / (dn - kf + 1.0)) +
-                              (kf + 0.5) * dlog(r * (dn - kf + 1.0) / (kf + 1.0)) +
+            // (every argument below is a ratio of positive finite numbers far from the subnormal range: dlog_pn)
+            v = dlog_pn(v * alpha / (a / (us * us) + b));
+            const double ub = (m + 0.5) * dlog_pn((m + 1.0) / (r * (dn - m + 1.0))) +
+                              (dn + 1.0) * dlog_pn((dn - m + 1.0) / (dn - kf + 1.0)) +
+                              (kf + 0.5) * dlog_pn(r * (dn - kf + 1.0) / (kf + 1.0)) +
                               stirling_tail(m) + stirling_tail(dn - m) - stirling_tail(kf) - stirling_tail(dn - kf);
             if (v <= ub) { res = (uint32_t)kf; break; }
         }
