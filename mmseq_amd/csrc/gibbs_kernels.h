@@ -203,7 +203,7 @@ __device__ __forceinline__ void allocate_row(const View &v, Add add, uint32_t kk
     if (L == 1) { add(v.col(0), (int32_t)kk); return; }
     const double total = v.total();
     const bool degenerate = !(total > 0.0) || !(total < __builtin_huge_val());
-    if (!HAS_K || kk <= K_SMALL) {
+    if (!HAS_K || draws_categoricals(kk, L)) {
         Stream2 s(a.seed, a.chain, TAG_ROW, row_id, a.iter);
         const double ts = total * 0x1p-32, hs = ts * 0.5; // draw_target (mmg_math.h)
         for (uint32_t d = 0; d < kk; ++d) {

@@ -85,8 +85,9 @@ __global__ __launch_bounds__(256) void k_row_keys(uint64_t m, const uint64_t *__
             const uint64_t mid = med >> LAYOUT_BAND_SHIFT;
             band = (mid > 1 ? mid : 1) - 1;
         }
-        const uint64_t kclass = kk <= 1 ? 0 : (kk <= K_SMALL ? 1 : 2);
-        const uint64_t ksmall = kclass == 1 ? kk : 0; // rows that draw k times sort by k first: a tile draws max k times per lane
+        const uint64_t kclass = kk <= 1 ? 0 : (kk <= K_SMALL ? 1 : (draws_categoricals(kk, (uint32_t)(L > 1 ? L : 2)) ? 2 : 3));
+        const uint64_t ksmall = kclass == 1 ? kk : k_bucket(kk); // rows that draw k times sort by k first: a tile draws max k times per lane;
+                                                                 // rows of the binomial chain (class 3) never share more than one tile per band with them
         kv = ((uint64_t)(near ? 0 : 1) << 63) | (band << 18) | (kclass << 16) | (ksmall << 9) | (L < 0x1ff ? L : 0x1ff);
     }
     key[r] = kv;

@@ -13,7 +13,19 @@
 
 namespace mmg {
 
-constexpr uint32_t K_SMALL = MMG_K_SMALL;   // rows with k <= K_SMALL draw k categoricals; above, a conditional-binomial chain
+constexpr uint32_t K_SMALL = MMG_K_SMALL;   // rows with k <= K_SMALL draw k categoricals (and are stored k times by the canonical layout)
+constexpr uint32_t K_DRAWS_PER_HIT = MMG_K_DRAWS_PER_HIT;
+// k categorical draws, or the conditional-binomial chain (L - 1 binomials)?  L = hits of the row (>= 2 here)
+MMG_TYPES_HD inline bool draws_categoricals(uint32_t k, uint32_t L) { return k <= K_SMALL || (uint64_t)k <= (uint64_t)K_DRAWS_PER_HIT * (L - 1u); }
+// rows above K_SMALL sort by this bucket of k inside their class (7 bits: 8 steps per power of two from 64 on): the rows of a tile
+// draw about equally often
+MMG_TYPES_HD inline uint32_t k_bucket(uint32_t k)
+{
+    if (k <= K_SMALL) return 0;
+    const uint32_t e = 31u - (uint32_t)__builtin_clz(k);          // >= 6
+    const uint32_t b = 8u * (e - 6u) + ((k >> (e - 3u)) & 7u);
+    return b < 127u ? b : 127u;
+}
 
 // ---- canonical layout (restated in oracle/binding.py:canonical_layout) -----------------------------
 // Rows are exchangeable in the model (src/mmseq.cpp:857-891 visits them in file order only because that is how they were
@@ -27,8 +39,8 @@ constexpr uint32_t K_SMALL = MMG_K_SMALL;   // rows with k <= K_SMALL draw k cat
 //   near    = every hit of the row lies in [lead * 64, lead * 64 + LAYOUT_NEAR_SPAN) and the row has <= 255 hits
 //   band    = lead for a near row; for a far row its HOME band: max(median hit >> LAYOUT_BAND_SHIFT, 1) - 1 (lower median,
 //             hit[(len - 1) / 2] of the ascending row): the window starting one band below the row's middle holds its bulk
-//   kclass  = 0 (k <= 1), 1 (k <= K_SMALL), 2 (conditional-binomial chain)
-//   key     = !near << 63 | band << 18 | kclass << 16 | (kclass == 1 ? k : 0) << 9 | min(len, 0x1ff)      (an empty row: key 0)
+//   kclass  = 0 (k <= 1), 1 (k <= K_SMALL), 2 (above, k categorical draws: draws_categoricals), 3 (conditional-binomial chain)
+//   key     = !near << 63 | band << 18 | kclass << 16 | (kclass == 1 ? k : k_bucket(k)) << 9 | min(len, 0x1ff)      (an empty row: key 0)
 //   hash    = fold of (len, k, the ascending hits)
 //   csum    = sum of (hit - band * 64) over the hits inside the window [band * 64, band * 64 + SELL_WIN)  (<= 255 * 254 < 2^16)
 //   tie     = csum << 48 | hash >> 16: rows of equal key are ordered by their CENTRE first, then by content.  At every step of

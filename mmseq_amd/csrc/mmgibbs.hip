@@ -245,7 +245,8 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
         const bool hk = has_k_rows(t);
         n_hask += hk;
         cum1[t + 1] = cum1[t] + (hk ? 0 : c);
-        cumk[t + 1] = cumk[t] + (!hk ? 0 : 2 * c + (td[t].kmax <= K_SMALL ? (uint64_t)td[t].kmax : 3 * (uint64_t)td[t].maxlen));
+        // a draw costs about as much as a register-path tile per 64 rows (2), a step of the binomial chain 36 of them
+        cumk[t + 1] = cumk[t] + (!hk ? 0 : 2 * c + (draws_categoricals(td[t].kmax, td[t].maxlen > 1 ? td[t].maxlen : 2) ? 2 * (uint64_t)td[t].kmax : 36 * (uint64_t)td[t].maxlen));
     }
     std::vector<uint64_t> chunk;
     if (n_hask) weighted_chunks(p->h_sell_cum, grid, chunk); // (with SELL_HASK tiles: only the windows below follow these ranges)
@@ -315,7 +316,7 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
             if (st[t].flags() & SELL_HASK) { sk.push_back(st[t]); ck.push_back(ck.back() + (cumk[t + 1] - cumk[t])); }
             else { s1.push_back(st[t]); c1.push_back(c1.back() + (cum1[t + 1] - cum1[t])); }
         }
-        const uint64_t g1 = std::max<uint64_t>(1, std::min<uint64_t>(s1.size(), grid)), gk = std::max<uint64_t>(1, std::min<uint64_t>(sk.size(), resident_grid(true)));
+        const uint64_t g1 = std::max<uint64_t>(1, std::min<uint64_t>(s1.size(), grid)), gk = std::max<uint64_t>(1, std::min<uint64_t>(sk.size(), 4 * resident_grid(true))); // (a multiplicity tile costs tens of register-path tiles: short ranges, several generations, even out the tail)
         if (s1.empty()) { SellTile e; e.off16 = 0; e.r0 = 0; e.wbase = 0; e.meta = sell_meta(0, 0, SELL_EMPTY); s1.push_back(e); c1.push_back(0); }
         std::vector<uint64_t> r1, rk;
         weighted_chunks(c1, g1, r1);

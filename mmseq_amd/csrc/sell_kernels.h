@@ -484,7 +484,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
             return sel;
         };
         if (!HAS_K) { add(draw(xrow), 1); return; }
-        if (kk <= K_SMALL) {
+        if (draws_categoricals(kk, L)) {
             Stream2 s(a.seed, a.chain, TAG_ROW, row_id, a.iter);
             {
 #pragma unroll 1

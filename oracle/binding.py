@@ -281,6 +281,7 @@ def sokal_ref(x):
 LAYOUT_BAND_SHIFT = 6
 LAYOUT_NEAR_SPAN = 240
 K_SMALL = 64
+K_DRAWS_PER_HIT = 16
 
 
 SELL_WIN = 255  # transcripts per LDS window (mmg_types.h)
@@ -308,8 +309,15 @@ def row_keys(row_ptr, col_idx, k=None):
         mid = col[starts + (L[ne] - 1) // 2].astype(np.uint64) >> np.uint64(LAYOUT_BAND_SHIFT)
         band = np.where(near, band, np.maximum(mid, np.uint64(1)) - np.uint64(1))
         kn = kk[ne]
-        kclass = np.where(kn <= 1, 0, np.where(kn <= K_SMALL, 1, 2)).astype(np.uint64)
-        ksmall = np.where(kclass == 1, kn, 0).astype(np.uint64)
+        draws = kn.astype(np.uint64) <= np.uint64(K_DRAWS_PER_HIT) * (np.maximum(Ln, np.uint64(2)) - np.uint64(1))   # spec version 5
+        kclass = np.where(kn <= 1, 0, np.where(kn <= K_SMALL, 1, np.where(draws, 2, 3))).astype(np.uint64)
+        # class 2 rows sort by a logarithmic bucket of k (spec version 5; mmg_types.h: k_bucket)
+        kb = np.maximum(kn, 65).astype(np.uint64)
+        e = np.floor(np.log2(kb.astype(np.float64))).astype(np.uint64)      # exact for k < 2^32: log2 of an integer below 2^53
+        e = np.where((np.uint64(1) << e) > kb, e - np.uint64(1), e)
+        e = np.where((np.uint64(2) << e) <= kb, e + np.uint64(1), e)
+        bucket = np.minimum(np.uint64(8) * (e - np.uint64(6)) + ((kb >> (e - np.uint64(3))) & np.uint64(7)), np.uint64(127))
+        ksmall = np.where(kclass == 1, kn, np.where(kclass >= 2, bucket, 0)).astype(np.uint64)
         key[ne] = ((~near).astype(np.uint64) << np.uint64(63)) | (band << np.uint64(18)) | (kclass << np.uint64(16)) | \
             (ksmall << np.uint64(9)) | np.minimum(Ln, 0x1ff)
     with np.errstate(over="ignore"):

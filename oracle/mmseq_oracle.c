@@ -47,7 +47,8 @@
 #include <omp.h>
 #endif
 
-#define ORC_K_SMALL 64u /* rows with k <= this: k categorical draws; above: binomial chain */
+#define ORC_K_SMALL 64u /* rows with k <= this: k categorical draws */
+#define ORC_K_DRAWS_PER_HIT 16u /* ... and rows with k <= this * (hits - 1); above: binomial chain (spec version 5) */
 
 /* ------------------------------------------------------------------------- */
 /* Philox4x32-10 (Salmon et al., SC'11; Random123 reference constants)        */
@@ -424,7 +425,7 @@ static void keyed_row_allocate(const uint32_t *cols, uint32_t L, uint32_t k, con
     if (L == 1) { cnt[cols[0]] += (int32_t)k; return; }
     double total = 0.0;
     for (uint32_t j = 0; j < L; ++j) total += mu[cols[j]];
-    if (k <= ORC_K_SMALL) {
+    if (k <= ORC_K_SMALL || (uint64_t)k <= (uint64_t)ORC_K_DRAWS_PER_HIT * (L - 1u)) {
         orc_stream2 s = stream2_make(seed, chain, ORC_TAG_ROW, row_id, iter);
         for (uint32_t d = 0; d < k; ++d) {
             uint32_t x = stream2_next_word(&s);

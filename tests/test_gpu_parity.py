@@ -198,7 +198,7 @@ def test_full_chain_bit_exact(gpu, orc, R, T, avg, kernel):
 
 
 def test_rows_with_multiplicity_bit_exact(gpu, orc):
-    """k > 1 rows: k <= 64 (MMG_K_SMALL) -> repeated categorical draws; above -> conditional-binomial chain."""
+    """k > 1 rows: k <= 64 (MMG_K_SMALL) or k <= 16 (hits - 1) -> repeated categorical draws; above -> conditional-binomial chain."""
     p, mu0, _ = _mk(orc, 5000, 400, 5)
     rng = np.random.default_rng(7)
     k = rng.choice([1, 2, 3, 8, 9, 50, 1000, 20000], size=p.m).astype(np.uint32)
@@ -592,17 +592,19 @@ def test_errors_are_loud(gpu):
         s.update()
 
 
-def test_golden_tiny_chain_on_device(gpu):
-    """The committed golden fixture (tests/golden/keyed_chain_tiny.json): k up to 1000, all three row paths."""
+@pytest.mark.parametrize("name,seed", [("keyed_chain_tiny.json", 1234), ("keyed_chain_k_draws.json", 4321)])
+def test_golden_tiny_chain_on_device(gpu, name, seed):
+    """The committed golden fixtures: keyed_chain_tiny.json (k up to 1000, all three row paths) and keyed_chain_k_draws.json (spec
+    version 5: rows on either side of the boundary between k categorical draws and the conditional-binomial chain)."""
     import json, os
-    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "keyed_chain_tiny.json")))
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", name)))
     f = lambda hs: np.array([float.fromhex(h) for h in hs])
     prob = gpu.Problem.from_csr(np.array(g["row_ptr"], np.uint64), np.array(g["col_idx"], np.uint32), f(g["l"]),
                                 k=np.array(g["k"], np.uint32), keep_rows=True)   # the fixture pins the chain of THESE rows in THIS order
     mu0, uh = prob.start_values()
     assert uh.tolist() == g["unique_hits"]
     np.testing.assert_allclose(mu0, f(g["mu0"]), rtol=1e-14)
-    s = gpu.Sampler(prob, f(g["mu0"]), seed=1234, gibbs_iter=32, trace_len=16)
+    s = gpu.Sampler(prob, f(g["mu0"]), seed=seed, gibbs_iter=32, trace_len=16)
     s.run(32)
     assert np.array_equal(s.trace(0).ravel(), f(g["trace"]))
     assert s.counts(0).tolist() == g["cnt_last"]

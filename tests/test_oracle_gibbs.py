@@ -143,16 +143,36 @@ def test_degenerate_and_edge_rows(orc):
     assert int(cnt.sum()) == 13
 
 
-def test_golden_tiny_chain(orc):
-    g = json.load(open(GOLD))
+@pytest.mark.parametrize("name,seed", [("keyed_chain_tiny.json", 1234), ("keyed_chain_k_draws.json", 4321)])
+def test_golden_tiny_chain(orc, name, seed):
+    """keyed_chain_tiny.json: k up to 1000, single hits, small multiplicities, binomial chains.  keyed_chain_k_draws.json (spec version 5):
+    rows on either side of the boundary k <= 16 (hits - 1) between k categorical draws and the conditional-binomial chain."""
+    g = json.load(open(os.path.join(os.path.dirname(GOLD), name)))
     f = lambda hs: np.array([float.fromhex(h) for h in hs])
     p = orc.Problem(np.array(g["row_ptr"], np.uint64), np.array(g["col_idx"], np.uint32), f(g["l"]),
                     k=np.array(g["k"], np.uint32))
     mu0, uh = orc.start_values(p)
     assert np.array_equal(mu0, f(g["mu0"])) and uh.tolist() == g["unique_hits"]
-    r = orc.gibbs_keyed(p, mu0, seed=1234, n_iter=32, trace_len=16)
+    r = orc.gibbs_keyed(p, mu0, seed=seed, n_iter=32, trace_len=16)
     assert np.array_equal(r["trace"].ravel(), f(g["trace"]))
     assert r["cnt"].tolist() == g["cnt_last"] and np.array_equal(r["mu"], f(g["mu_last"]))
+
+
+@pytest.mark.parametrize("k", [96, 97])
+def test_multiplicity_rows_on_both_sides_of_the_draws_boundary_are_multinomial(orc, k):
+    """A row of 7 hits draws its categoricals one by one up to k = 16 * 6 = 96 and runs the conditional-binomial chain above
+    (src/mmseq.cpp:880 is a multinomial either way): 4000 such rows, one sweep at fixed weights, against k * p."""
+    R, L = 4000, 7
+    rp = (np.arange(R + 1) * L).astype(np.uint64)
+    ci = np.tile(np.arange(L, dtype=np.uint32), R)
+    p = orc.Problem(rp, ci, np.ones(L), k=np.full(R, k, np.uint32))
+    w = np.array([0.4, 0.25, 0.15, 0.1, 0.05, 0.03, 0.02])
+    r = orc.gibbs_keyed(p, w.copy(), seed=77 + k, n_iter=1, trace_len=1)
+    cnt = r["cnt"].astype(np.float64)
+    n = float(R * k)
+    assert cnt.sum() == n
+    z = (cnt - n * w) / np.sqrt(n * w * (1 - w))
+    assert np.abs(z).max() < 4.5, z
 
 
 def test_em_and_start_values(orc):

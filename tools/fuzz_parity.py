@@ -20,7 +20,7 @@ def one_case(seed, gpu, orc, verbose=True):
         p.col_idx[:] = p.col_idx[np.lexsort((rng.random(p.col_idx.size), rid))]
     k = None
     if rng.integers(0, 2):
-        k = rng.choice([1, 1, 1, 2, 3, 8, 9, 40, 5000], size=p.m).astype(np.uint32)
+        k = rng.choice([1, 1, 1, 2, 3, 8, 9, 40, 70, 150, 700, 5000], size=p.m).astype(np.uint32)   # 70 / 150 / 700: draws or binomial chain by row length
     rp, ci = p.row_ptr.copy(), p.col_idx
     if rng.integers(0, 3) == 0 and p.m > 10:            # a few empty rows
         cut = np.sort(rng.choice(np.arange(1, p.m), size=3, replace=False))

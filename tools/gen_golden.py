@@ -4,6 +4,7 @@ compiled reference sokal.cc in oracle/_ref; `make -C oracle` builds it).
   sokal_reference.json   inputs -> (rc, var, tau, m) produced by the REFERENCE's own sokal()
                          (src/sokal.cc, compiled unmodified)
   keyed_chain_tiny.json  a tiny problem and the keyed-stream Gibbs trace/counts it must produce
+  keyed_chain_k_draws.json  rows on either side of the draws / binomial-chain boundary of spec version 5
   em_fixed_tiny.json     the same problem through the exact-sum EM: mu and log-likelihood after 0/1/2/8 sweeps
                          (produced by the CPU oracle; guards oracle and kernels against co-drift)
 """
@@ -75,6 +76,27 @@ def gen_tiny_chain():
               open(os.path.join(OUT, "keyed_chain_tiny.json"), "w"), indent=0)
 
 
+def gen_k_draws_chain():
+    """Spec version 5: rows with K_SMALL < k <= K_DRAWS_PER_HIT * (hits - 1) draw their categoricals one by one; one row on either
+    side of the boundary for three row lengths.  A fixture of its own: keyed_chain_tiny.json has no such row and stays byte for byte what it was."""
+    rows = [[0, 1, 2, 3, 4, 5, 6, 7], [0, 1, 2, 3, 4, 5, 6, 7], [1, 2, 3, 4, 5, 6], [1, 2, 3, 4, 5, 6], [0, 1, 2, 3, 4, 5, 6], [1, 2, 3, 4, 5, 6, 7],
+            [0, 2, 4, 5, 6], [1, 7], [3, 5], [5, 6, 7], [6]]
+    # draws: 112 on 8 hits (= 16 * 7), 80 on 6 (= 16 * 5), 96 on 7 (= 16 * 6), 24, 48; binomial chain: 113 on 8, 81 on 6, 97 on 7, 65 on 5 and on 2 hits
+    k = [112, 113, 80, 81, 96, 97, 65, 24, 65, 48, 500]
+    l = [0.5, 1.5, 0.25, 2.0, 1.0, 0.75, 3.0, 0.1]
+    rp = np.cumsum([0] + [len(r) for r in rows]).astype(np.uint64)
+    ci = np.concatenate([np.asarray(r, np.uint32) for r in rows])
+    p = B.Problem(rp, ci, np.asarray(l), k=np.asarray(k, np.uint32))
+    mu0, uh = B.start_values(p)
+    r = B.gibbs_keyed(p, mu0, alpha=0.1, beta=0.1, seed=4321, chain=0, n_iter=32, trace_len=16)
+    json.dump(dict(source="oracle/mmseq_oracle.c orc_gibbs_keyed (keyed Philox streams, spec version 5), seed 4321, chain 0, "
+                          "alpha=beta=0.1, 32 iterations, 16 kept",
+                   row_ptr=[int(v) for v in rp], col_idx=[int(v) for v in ci], k=k, l=hexf(l), mu0=hexf(mu0),
+                   unique_hits=[int(v) for v in uh], trace=hexf(r["trace"]), cnt_last=[int(v) for v in r["cnt"]],
+                   mu_last=hexf(r["mu"])),
+              open(os.path.join(OUT, "keyed_chain_k_draws.json"), "w"), indent=0)
+
+
 def gen_tiny_em():
     """The tiny problem of keyed_chain_tiny.json through the exact-sum EM (orc_em): log-likelihoods and mu after 1, 2, 8
     sweeps, plus a start with one dead and one wildly scaled transcript (takes the measured-exponent repeat path)."""
@@ -97,5 +119,6 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gen_sokal()
     gen_tiny_chain()
+    gen_k_draws_chain()
     gen_tiny_em()
     print("wrote", os.listdir(OUT))
