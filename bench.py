@@ -181,10 +181,17 @@ def side_measurement(name, rows, transcripts, avg_hits, chains=1, uniform=False,
         rng = np.random.default_rng(seed)
         u = rng.random(rows)
         k = np.ones(rows, np.uint32)
-        for thr, val in ((0.064, 2), (0.011, 3), (0.0035, 4), (0.002, 6)):
-            k[u < thr] = val
-        big = u < 0.0012
-        k[big] = rng.integers(9, 37, size=int(big.sum())).astype(np.uint32)
+        if multiplicities == "heavy":
+            # a heavily collapsed file: most READS sit in hit sets shared by tens to thousands (half the rows k = 1, 30 % 2..8,
+            # 15 % 9..64, 4 % 65..300, 1 % 300..20000 log-uniform): all three row paths of spec version 5
+            for lo_u, hi_u, lo_k, hi_k in ((0.5, 0.8, 2, 8), (0.8, 0.95, 9, 64), (0.95, 0.99, 65, 300), (0.99, 1.0, 300, 20000)):
+                sel = (u >= lo_u) & (u < hi_u)
+                k[sel] = np.exp(rng.uniform(np.log(lo_k), np.log(hi_k + 1), size=int(sel.sum()))).astype(np.uint32).clip(lo_k, hi_k)
+        else:
+            for thr, val in ((0.064, 2), (0.011, 3), (0.0035, 4), (0.002, 6)):
+                k[u < thr] = val
+            big = u < 0.0012
+            k[big] = rng.integers(9, 37, size=int(big.sum())).astype(np.uint32)
         prob = Problem.from_csr(rp, ci, l, k=k, device=device)
         del rp, ci, k, u
     build_s = time.perf_counter() - t0
@@ -211,7 +218,7 @@ def side_measurement(name, rows, transcripts, avg_hits, chains=1, uniform=False,
     tm = smp.timing()
     for c in range(chains):   # every chain assigned every read exactly once in the last sweep
         assert int(smp.counts(c).astype(np.int64).sum()) == inf.total_k, "count conservation, chain %d" % c
-    out = {"name": name, "reads": inf.m, "transcripts": inf.n, "hits": inf.nnz, "chains": chains, "uniform": bool(uniform),
+    out = {"name": name, "reads": inf.m, "mapped_reads_total_k": inf.total_k, "transcripts": inf.n, "hits": inf.nnz, "chains": chains, "uniform": bool(uniform),
            "canonical_layout": bool(sort), "far_fraction": far_fraction, "steps": steps, "ms_per_step": el / steps * 1e3,
            "chain_iterations_per_sec": chains * steps / el,
            "k1_avg_launch_ms_all_chains": tm["sample_ms"] / max(tm["sample_launches"], 1),
@@ -423,6 +430,9 @@ def main():
                        dict(name="50M x 200k like a real hits file: multiplicities (k > 1 on 6.4 % of the rows) AND 2 % of the rows with a hit anywhere in the "
                                  "transcriptome, 8 chains in one GPU (pairs over the k = 1 register-path tiles, one launch each for the far and the multiplicity tiles)",
                             rows=R3, transcripts=T3, avg_hits=H3, multiplicities=True, far_fraction=0.02, chains=8, steps=16, warmup=4),
+                       dict(name="a heavily collapsed file: 5M hit sets x 200k transcripts, avg 20 hits, multiplicities from 1 to 20000 (mapped_reads_total_k reads; "
+                                 "k draws up to 16 per step of the binomial chain, the chain above)", rows=5_000_000, transcripts=T3, avg_hits=H3,
+                            multiplicities="heavy", steps=32),
                        dict(name="50M x 200k, 2 % of the rows with a hit anywhere in the transcriptome", rows=R3, transcripts=T3, avg_hits=H3, far_fraction=0.02, steps=32),
                        dict(name="50M x 200k, 20 % of the rows with a hit anywhere in the transcriptome", rows=R3, transcripts=T3, avg_hits=H3, far_fraction=0.2, steps=24),
                        dict(name="50M x 200k, hits uniform over all transcripts (SURVEY App. D worst case)", rows=R3, transcripts=T3, avg_hits=H3, uniform=True, steps=8, warmup=2),
