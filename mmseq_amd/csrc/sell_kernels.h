@@ -19,7 +19,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 template <bool B> struct BoolTag { static constexpr bool value = B; };
 template <int K> struct IntTag { static constexpr int value = K; };
 
-// A tile's block seen through a raw buffer descriptor of exactly its size (64 length bytes + ng groups of 256 bytes).  The sampler and
+// A tile's block seen through a raw buffer descriptor of exactly its size (ng groups of 256 bytes).  The sampler and
 // EM kernels request NGC groups per tile whatever its ng (loads retire in order and are waited for by count, so the number issued
 // must not depend on the tile): through the descriptor a request past the block's end returns 0 WITHOUT a memory access -- the
 // hardware's range check is the clamp, at no instruction per group (clamped scalar addresses cost 10 % of the kernel's time, plain
