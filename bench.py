@@ -126,40 +126,40 @@ def cpu_quota():
         return None
 
 
-def cpu_baseline(args, total_reads):
-    """Oracle ("port" of src/mmseq.cpp:851-918, reference-structured: per-thread MT19937, count slabs,
-    conditional-binomial multinomial) timed on this host's cores on a bounded sample of the same workload."""
+def cpu_baseline(args, prob, mu0):
+    """Oracle ("port" of src/mmseq.cpp:851-918, reference-structured: per-thread MT19937, count slabs of n x threads ints cleared and
+    reduced every iteration, conditional-binomial multinomial) timed on this host's cores on the FULL problem: the device CSR is
+    downloaded (stored order: sorted rows, which only helps the CPU's caches) and `--cpu-iters` iterations run at the best thread count;
+    the thread count is picked on a 2 M-row sample, where the single-thread figure is measured too."""
     from oracle import binding as B
-    Rs = min(args.cpu_sample_rows, args.rows)
-    p, _ = B.synth_problem(R=Rs, T=args.transcripts, avg_hits=args.avg_hits, seed=args.seed, mapped_reads=total_reads, sort=False)
-    mu0, _ = B.start_values(p)
+    inf = prob.info
+    rp, ci = prob.download()
+    l = prob.l()
+    p = B.Problem(rp, ci, l)
+    Rs = min(args.cpu_sample_rows, inf.m)
+    ps = B.Problem(rp[:Rs + 1].copy(), ci[:int(rp[Rs])].copy(), l)
     ncpu = os.cpu_count() or 1
     quota = cpu_quota()
-    # the reference's per-thread count slabs (src/mmseq.cpp:850-855, :896-899) stop scaling at high thread
-    # counts: probe a few and time the best one, so the baseline is the strongest this host offers.  A container's CPU quota
-    # (16 CPUs' worth on the 256-core GPU boxes here) is a candidate of its own: more threads than that are throttled.
-    # (thread counts far above a quota are throttled erratically: a 2-iteration probe once picked 128 threads on a 16-CPU quota and the
-    # timed run then crawled; with a quota the candidates stop at twice its size and the probe runs 4 iterations)
-    cands = sorted({t for t in (ncpu, ncpu // 2, 64, 32, 16, 8, 1, quota or 1, 2 * (quota or 1))
+    # the reference's per-thread count slabs (src/mmseq.cpp:850-855, :896-899) stop scaling at high thread counts, and thread counts
+    # far above a container's CPU quota are throttled erratically: candidates stop at twice the quota
+    cands = sorted({t for t in (ncpu, ncpu // 2, 64, 32, 16, 8, quota or 1, 2 * (quota or 1))
                     if 1 <= t <= ncpu and (quota is None or t <= 2 * quota)}, reverse=True)
     best_t, best_rate = 1, 0.0
     for t in cands:
-        r = B.gibbs_ref(p, mu0, seed=args.seed, n_iter=4, trace_len=4, threads=t, want_trace=False)
+        r = B.gibbs_ref(ps, mu0, seed=args.seed, n_iter=4, trace_len=4, threads=t, want_trace=False)
         rate = Rs * 4 / r["seconds"]
         if rate > best_rate:
             best_t, best_rate = t, rate
-    threads = best_t
     iters = args.cpu_iters
-    r = B.gibbs_ref(p, mu0, seed=args.seed, n_iter=iters, trace_len=iters, threads=threads, want_trace=False)
-    reads_it_s = Rs * iters / r["seconds"]
-    r1 = B.gibbs_ref(p, mu0, seed=args.seed, n_iter=max(1, iters // 8), trace_len=max(1, iters // 8), threads=1,
-                     want_trace=False)
-    reads_it_s_1 = Rs * max(1, iters // 8) / r1["seconds"]
-    return {"value": reads_it_s / args.rows, "unit": "iterations/s", "cores": threads, "kind": "port",
-            "sample": "first %d generator rows of the same workload (T=%d, avg %.0f hits), %d iterations on %d host threads "
-                      "(best of %s on this %d-CPU host, CPU quota %s); reads*iter/s scaled to the %d-read problem"
-                      % (Rs, args.transcripts, args.avg_hits, iters, threads, cands, ncpu, quota, args.rows),
-            "reads_iters_per_sec": reads_it_s, "single_thread_iterations_per_sec": reads_it_s_1 / args.rows}
+    r = B.gibbs_ref(p, mu0, seed=args.seed, n_iter=iters, trace_len=iters, threads=best_t, want_trace=False)
+    it_s = iters / r["seconds"]
+    r1 = B.gibbs_ref(ps, mu0, seed=args.seed, n_iter=2, trace_len=2, threads=1, want_trace=False)
+    return {"value": it_s, "unit": "iterations/s", "cores": best_t, "kind": "port",
+            "sample": "%d rows (the full problem, %d hits), %d iterations, %d threads (best of %s; %d CPUs, quota %s)"
+                      % (inf.m, inf.nnz, iters, best_t, cands, ncpu, quota),
+            "reads_iters_per_sec": it_s * inf.m, "seconds": r["seconds"],
+            "single_thread_iterations_per_sec": Rs * 2 / r1["seconds"] / inf.m,
+            "single_thread_sample": "first %d stored rows, 2 iterations, scaled by rows" % Rs}
 
 
 def side_measurement(name, rows, transcripts, avg_hits, chains=1, uniform=False, sort=True, far_fraction=0.0, steps=48, warmup=8,
@@ -218,17 +218,18 @@ def side_measurement(name, rows, transcripts, avg_hits, chains=1, uniform=False,
     tm = smp.timing()
     for c in range(chains):   # every chain assigned every read exactly once in the last sweep
         assert int(smp.counts(c).astype(np.int64).sum()) == inf.total_k, "count conservation, chain %d" % c
-    out = {"name": name, "reads": inf.m, "mapped_reads_total_k": inf.total_k, "transcripts": inf.n, "hits": inf.nnz, "chains": chains, "uniform": bool(uniform),
-           "canonical_layout": bool(sort), "far_fraction": far_fraction, "steps": steps, "ms_per_step": el / steps * 1e3,
-           "chain_iterations_per_sec": chains * steps / el,
-           "k1_avg_launch_ms_all_chains": tm["sample_ms"] / max(tm["sample_launches"], 1),
-           "k2_avg_launch_ms": tm["update_ms"] / max(tm["update_launches"], 1),
-           "sample_kernel": {0: "k_sample (CSR tiles)", 2: "k_sample_sell"}[inf.sample_kernel],
-           "fast_tile_fraction": (inf.fast_tiles / inf.n_tiles) if inf.sample_kernel == 2 and inf.n_tiles else 0.0,
-           "far_tile_fraction": (inf.far_tiles / inf.n_tiles) if inf.sample_kernel == 2 and inf.n_tiles else 0.0,
-           "stream_bytes": inf.stream_bytes, "problem_build_s": build_s}
-    if note:
-        out["note"] = note
+    ms = el / steps * 1e3
+    # the u32-CSR bytes of one sweep over the STORED problem for C chains, against 8 TB/s
+    b_sweep = 4 * (inf.m + 1) + 4 * inf.nnz + 28 * chains * inf.n
+    out = {"id": name, "reads": inf.m, "total_k": inf.total_k, "transcripts": inf.n, "hits": inf.nnz, "chains": chains,
+           "steps": steps, "ms_per_step": ms, "chain_it_s": chains * steps / el,
+           "k1_ms_all_chains": tm["sample_ms"] / max(tm["sample_launches"], 1),
+           "k2_ms": tm["update_ms"] / max(tm["update_launches"], 1),
+           "kernel": {0: "k_sample", 2: "k_sample_sell"}[inf.sample_kernel],
+           "fast_tiles": (inf.fast_tiles / inf.n_tiles) if inf.sample_kernel == 2 and inf.n_tiles else 0.0,
+           "far_tiles": (inf.far_tiles / inf.n_tiles) if inf.sample_kernel == 2 and inf.n_tiles else 0.0,
+           "stream_bytes": inf.stream_bytes, "n_tiles": inf.n_tiles, "alg_bytes": b_sweep, "alg_frac": b_sweep / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "build_s": round(build_s, 2)}
     smp.close()
     prob.close()
     return out
@@ -248,10 +249,39 @@ def em_measurement(rows, transcripts, avg_hits, seed=1234, device=0, sweeps=20):
     for _ in range(sweeps):
         em.step()
     ms = (time.perf_counter() - t0) / sweeps * 1e3
-    out = {"name": "EM sweep, 50M x 200k", "ms_per_sweep": ms, "sweeps": sweeps, "stream_kernel": em.stats_raw()["stream_kernel"],
+    out = {"id": "em", "ms_per_sweep": ms, "sweeps": sweeps, "stream_kernel": em.stats_raw()["stream_kernel"],
            "n_tiles": prob.info.n_tiles, "stream_bytes": prob.info.stream_bytes}
     em.close()
     prob.close()
+    return out
+
+
+# the side measurements of the default run: id -> (what it is, arguments).  BASELINE.json configs[1] = "cfg2", configs[2] = "cfg3x8".
+R3, T3, H3 = 50_000_000, 200_000, 20.0
+SIDE = [
+    ("cfg2", "BASELINE configs[1]: 5M reads x 50k transcripts, avg 8 hits, 1 chain", dict(rows=5_000_000, transcripts=50_000, avg_hits=8.0, steps=256, warmup=64)),
+    ("cfg3x8", "BASELINE configs[2]: 50M x 200k, 8 chains in one GPU", dict(rows=R3, transcripts=T3, avg_hits=H3, chains=8, steps=16, warmup=4)),
+    ("mult", "50M x 200k, multiplicities of a collapsed file (k > 1 on 6.4 % of the rows, up to 36; stored k times)", dict(rows=R3, transcripts=T3, avg_hits=H3, multiplicities=True, steps=32)),
+    ("real8", "50M x 200k like a real hits file: those multiplicities + 2 % far rows, 8 chains", dict(rows=R3, transcripts=T3, avg_hits=H3, multiplicities=True, far_fraction=0.02, chains=8, steps=16, warmup=4)),
+    ("heavy", "a heavily collapsed file: 5M hit sets, multiplicities 1..20000 (total_k reads)", dict(rows=5_000_000, transcripts=T3, avg_hits=H3, multiplicities="heavy", steps=32)),
+    ("far2", "50M x 200k, 2 % of the rows with a hit anywhere in the transcriptome", dict(rows=R3, transcripts=T3, avg_hits=H3, far_fraction=0.02, steps=32)),
+    ("far20", "50M x 200k, 20 % of the rows with a hit anywhere", dict(rows=R3, transcripts=T3, avg_hits=H3, far_fraction=0.2, steps=24)),
+    ("uniform", "50M x 200k, hits uniform over all transcripts (SURVEY App. D worst case)", dict(rows=R3, transcripts=T3, avg_hits=H3, uniform=True, steps=8, warmup=2)),
+    ("keeprows", "50M x 200k, rows kept in generator order (MMG_LAYOUT_KEEP_ROWS)", dict(rows=R3, transcripts=T3, avg_hits=H3, sort=False, steps=8, warmup=2)),
+]
+
+
+def compact(d, drop=()):
+    """JSON-line diet: floats to 5 significant digits, the given keys dropped (the driver keeps an 8 KB tail of stdout)."""
+    out = {}
+    for k, v in d.items():
+        if k in drop or v is None:
+            continue
+        if isinstance(v, float):
+            v = float("%.5g" % v)
+        elif isinstance(v, dict):
+            v = compact(v)
+        out[k] = v
     return out
 
 
@@ -270,9 +300,11 @@ def main():
                     "(a pair costs about 9 us of stream time; 1 = every step)")
     ap.add_argument("--settle-iters", type=int, default=256, help="iterations of a scratch chain before the warm-up steps (GPU clock ramp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the side measurements of the extra block")
-    ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
-    ap.add_argument("--cpu-iters", type=int, default=24)
+    ap.add_argument("--no-extra", action="store_true", help="skip the side measurements")
+    ap.add_argument("--only", default="", help="comma-separated ids of the side measurements to run (default: all)")
+    ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000, help="rows of the sample the CPU thread count is picked on")
+    ap.add_argument("--cpu-iters", type=int, default=8, help="iterations of the CPU baseline on the full problem")
+    ap.add_argument("--full-json", default="", help="also write the unabridged record (every field of every measurement) to this file")
     args = ap.parse_args()
 
     import numpy as np
@@ -295,20 +327,26 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # ---- workload (synthetic, generated straight into device CSR and laid out by the library; not timed)
-    if args.mode == "shard":
+    shard_rows = None
+    if args.mode == "shard" and world > 1:
+        # What `mmseq -gpus N` does (host/mmseq_main.cpp): ONE canonical problem of rows x N reads, cut where the library cuts it
+        # (mmg_problem_shard_bounds: contiguous ranges of the stored rows of equal modelled cost), shard `rank` kept.  Every rank builds
+        # the whole problem on its own device (the generator is keyed: the same rows everywhere) and keeps its range; no rank gets rows
+        # of "its own" generator stream, which would be balanced by construction.
         total_reads = args.rows * world
-        row0 = args.rows * rank
+        full = Problem.synthetic(total_reads, args.transcripts, args.avg_hits, seed=args.seed, mapped_reads=total_reads, device=local_rank)
+        mu0, _ = full.start_values()
+        b = full.shard_bounds(world)
+        shard_rows = [int(b[i + 1] - b[i]) for i in range(world)]
+        prob = full.shard(int(b[rank]), int(b[rank + 1]), device=local_rank)
+        full.close()
+        del full
+        torch.cuda.empty_cache()
     else:
         total_reads = args.rows
-        row0 = 0
-    prob = Problem.synthetic(args.rows, args.transcripts, args.avg_hits, seed=args.seed, row0=row0,
-                             mapped_reads=total_reads, device=local_rank)
+        prob = Problem.synthetic(args.rows, args.transcripts, args.avg_hits, seed=args.seed, mapped_reads=total_reads, device=local_rank)
+        mu0, _ = prob.start_values()
     inf = prob.info
-    mu0, _ = prob.start_values()
-    if args.mode == "shard" and world > 1:
-        t = torch.from_numpy(mu0 * prob.l()).cuda()       # shares k/|row| summed over ranks, then / l
-        dist.all_reduce(t)
-        mu0 = t.cpu().numpy() / prob.l()
     # every iteration is a kept sample (BASELINE.md B formula): the reference's 1024-iteration, 1024-sample run; a longer timed region
     # (--warmup + --steps > 1024) keeps every iteration as well, in a longer resident trace
     need = args.warmup + args.steps
@@ -362,122 +400,136 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    tm = smp.timing()
+    k1_own_ms = tm["sample_ms"] / max(tm["sample_launches"], 1)
+    k1_ranks = None
     if world > 1:
         te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
-    tm = smp.timing()
+        tk = torch.zeros(world, dtype=torch.float64, device="cuda")
+        tk[rank] = k1_own_ms
+        dist.all_reduce(tk)
+        k1_ranks = [float(x) for x in tk.cpu()]
 
     # sanity inside the bench: every read was allocated exactly once in the last sweep
     if args.mode == "chains":
         assert int(smp.counts(0).astype(np.int64).sum()) == inf.total_k
+    else:
+        assert int(smp.counts(0).astype(np.int64).sum()) == total_reads   # the all-reduced counts: every read of every shard
     smp.close()
 
     if rank == 0:
         C = args.chains
         chains_total = C * (world if args.mode == "chains" else 1)
         iters_per_s = chains_total * args.steps / elapsed
-        reads_per_chain = total_reads
-        k1_ms = tm["sample_ms"] / max(tm["sample_launches"], 1) / C   # per chain: the sample() call of C chains / C
+        k1_ms = k1_own_ms / C                                  # per chain: the sample() call of C chains / C
         k2_ms = tm["update_ms"] / max(tm["update_launches"], 1)
         # algorithmic bytes of one K1 launch (one GPU, one chain): u32 row_ptr + u32 col_idx streamed once, fp64 mu read + int32
         # count write (SURVEY 8d / DESIGN.md section 4)
         b_k1 = 4 * (inf.m + 1) + 4 * inf.nnz + 12 * inf.n
-        b_sweep = 4 * (inf.m + 1) + 4 * inf.nnz + 28 * C * inf.n
         kname = {0: "k_sample", 2: "k_sample_sell"}[inf.sample_kernel]
-        t_k1 = k1_ms * 1e-3
         # chains > 1: one event pair brackets the whole sample() call -- pair launches plus the launches for the other tile lists;
-        # per-kernel PMC figures belong to the 1-chain run only (roofline_other carries the pair kernel's own block)
-        roof = roofline_block(kname + " (K1)", "k1_1chain" if C == 1 else "none", t_k1, tm["sample_launches"], inf.n_tiles,
-                              stream_bytes=inf.stream_bytes, algorithmic_bytes=b_k1)
-        roof["padded_slots_per_hit"] = (inf.padded_slots / inf.nnz) if inf.nnz else None
-        roof["k_update_avg_launch_ms"] = k2_ms
-        roof["sweep_bytes"] = b_sweep
-        roof["note"] = ("HBM: traffic / time against the 8 TB/s peak (and against the 6.6 TB/s a pure read with this access pattern reaches); "
-                        "valu.busy_frac = counted VALU instructions x 4.3 clocks / SIMD cycles; algorithmic_x_peak = SURVEY 8(d) u32-CSR bytes / "
-                        "time / 8 TB/s (> 1: the kernel streams a 1.1 B/hit encoding, not the CSR).  PMC figures are null when "
-                        "profiles/pmc_counters.json was collected on other kernel sources, and at chains > 1 (avg_launch_ms is then the "
-                        "sample() call of all chains divided by the chains)")
+        # per-kernel PMC figures belong to the 1-chain run only
+        full_roof = roofline_block(kname + " (K1)", "k1_1chain" if C == 1 and world == 1 else "none", k1_ms * 1e-3, tm["sample_launches"], inf.n_tiles,
+                                   stream_bytes=inf.stream_bytes, algorithmic_bytes=b_k1)
+        full_roof["padded_slots_per_hit"] = (inf.padded_slots / inf.nnz) if inf.nnz else None
+        full_roof["k_update_avg_launch_ms"] = k2_ms
+        # the contract's six first, then one scalar per BASELINE config and side measurement (filled in below), then the detail
+        roof = {k: full_roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms")}
         out = {
             "metric": "gibbs_iterations_per_sec", "value": iters_per_s, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "50M-read x 200k-transcript synthetic CSR hits (BASELINE.json configs[2]/[3] shape)"
-                       if (args.rows, args.transcripts) == (50_000_000, 200_000) else "custom synthetic CSR hits",
+            "config": {"workload": ("50M-read x 200k-transcript synthetic CSR hits (BASELINE.json configs[2]/[3] shape)"
+                                    if (args.rows, args.transcripts) == (50_000_000, 200_000) else "custom synthetic CSR hits")
+                                   + ("" if shard_rows is None else ", x %d GPUs = configs[4]" % world),
                        "reads_per_gpu": inf.m, "transcripts": inf.n, "hits_per_gpu": inf.nnz,
                        "avg_hits_per_read": args.avg_hits, "chains_per_gpu": C, "mode": args.mode,
                        "parallelism": ("%d independent chains (1 all-reduce of posterior moments)" % chains_total)
-                       if args.mode == "chains" else ("read-sharded single chain over %d GPUs "
-                                                      "(int32 count all-reduce per iteration)" % world),
+                       if args.mode == "chains" else ("read-sharded single chain over %d GPUs (int32 count all-reduce per iteration), "
+                                                      "one canonical problem cut by modelled cost" % world),
                        "trace": "every iteration kept (fp64 mu trace resident in HBM)", "generator_seed": args.seed,
-                       "layout": "rows generated in generator order, stored in the library's canonical order (device radix sort)",
-                       "clock_settle_iters_before_warmup": args.settle_iters,
-                       "cold_ms_per_step_first_64_iterations_after_start": cold_ms},
-            "reads_iters_per_sec": iters_per_s * reads_per_chain,
+                       "layout": "generator order in, the library's canonical order stored (device radix sort)",
+                       "settle_iters": args.settle_iters, "cold_ms_per_step": cold_ms},
+            "reads_iters_per_sec": iters_per_s * total_reads,
             "roofline": roof,
         }
+        if shard_rows is not None:
+            out["config"]["rows_per_shard"] = shard_rows
+            out["config"]["k1_ms_per_rank"] = k1_ranks
+        record = {"headline": dict(out), "roofline_k1": full_roof}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, prob, mu0)
+            out["speedup_vs_cpu_baseline"] = iters_per_s / out["cpu_baseline"]["value"]
         if world == 1 and not args.no_extra:
             prob.close()
             prob = None
             torch.cuda.empty_cache()
-            extra = []
-            R3, T3, H3 = 50_000_000, 200_000, 20.0
-            for kw in (dict(name="config 2: 5M reads x 50k transcripts, avg 8 hits, 1 chain", rows=5_000_000, transcripts=50_000, avg_hits=8.0, steps=256, warmup=64),
-                       dict(name="config 3: 50M x 200k, 8 chains in one GPU", rows=R3, transcripts=T3, avg_hits=H3, chains=8, steps=16, warmup=4),
-                       dict(name="50M x 200k with multiplicities (k > 1 on 6.4 % of the rows, up to 36; such a row is stored k times)", rows=R3, transcripts=T3, avg_hits=H3,
-                            multiplicities=True, steps=32),
-                       dict(name="50M x 200k like a real hits file: multiplicities (k > 1 on 6.4 % of the rows) AND 2 % of the rows with a hit anywhere in the "
-                                 "transcriptome, 8 chains in one GPU (pairs over the k = 1 register-path tiles, one launch each for the far and the multiplicity tiles)",
-                            rows=R3, transcripts=T3, avg_hits=H3, multiplicities=True, far_fraction=0.02, chains=8, steps=16, warmup=4),
-                       dict(name="a heavily collapsed file: 5M hit sets x 200k transcripts, avg 20 hits, multiplicities from 1 to 20000 (mapped_reads_total_k reads; "
-                                 "k draws up to 16 per step of the binomial chain, the chain above)", rows=5_000_000, transcripts=T3, avg_hits=H3,
-                            multiplicities="heavy", steps=32),
-                       dict(name="50M x 200k, 2 % of the rows with a hit anywhere in the transcriptome", rows=R3, transcripts=T3, avg_hits=H3, far_fraction=0.02, steps=32),
-                       dict(name="50M x 200k, 20 % of the rows with a hit anywhere in the transcriptome", rows=R3, transcripts=T3, avg_hits=H3, far_fraction=0.2, steps=24),
-                       dict(name="50M x 200k, hits uniform over all transcripts (SURVEY App. D worst case)", rows=R3, transcripts=T3, avg_hits=H3, uniform=True, steps=8, warmup=2),
-                       dict(name="50M x 200k, rows kept in generator order (MMG_LAYOUT_KEEP_ROWS: what round 1 ran when the caller did not sort)",
-                            rows=R3, transcripts=T3, avg_hits=H3, sort=False, steps=8, warmup=2)):
+            only = [x for x in args.only.split(",") if x]
+            side = {}
+            for sid, what, kw in SIDE:
+                if only and sid not in only:
+                    continue
                 try:
-                    extra.append(side_measurement(seed=args.seed, device=local_rank, **kw))
+                    side[sid] = side_measurement(sid, seed=args.seed, device=local_rank, **kw)
+                    side[sid]["what"] = what
                 except Exception as e:                      # a side measurement must not take the headline down
-                    extra.append({"name": kw["name"], "error": repr(e)})
+                    side[sid] = {"id": sid, "error": repr(e)[:120]}
                 torch.cuda.empty_cache()
-            out["extra"] = extra
             # the same roofline object for the two other hot kernels: the chain-pair kernel (BASELINE configs[2]) and the EM rows pass
-            other = []
-            c3 = next((e for e in extra if e.get("name", "").startswith("config 3") and "error" not in e), None)
-            if c3:
-                tiles = inf.n_tiles
+            other = {}
+            c3 = side.get("cfg3x8")
+            if c3 and "error" not in c3:
                 pairs = c3["chains"] // 2
                 # ONE launch advances all the chains, pair by pair (grid.y = pair): its duration, its counters, `pairs` passes over the
                 # stream and `pairs` x tiles tile-visits (instructions_per_64_row_tile is per visit, i.e. per tile and PAIR of chains)
-                rb = roofline_block("k_sample_sell_multi<2> (K1m: one launch advances the %d chains in %d pairs)" % (c3["chains"], pairs), "k1m_8chains",
-                                    c3["k1_avg_launch_ms_all_chains"] * 1e-3, c3["steps"] // 4 + 1, tiles * pairs,
+                rb = roofline_block("k_sample_sell_multi<2> (K1m)", "k1m_8chains", c3["k1_ms_all_chains"] * 1e-3, c3["steps"] // 4 + 1, c3["n_tiles"] * pairs,
                                     stream_bytes=c3["stream_bytes"] * pairs,
                                     algorithmic_bytes=pairs * (4 * (c3["reads"] + 1) + 4 * c3["hits"] + 24 * c3["transcripts"]))
-                rb["chain_iterations_per_sec"] = c3["chain_iterations_per_sec"]
                 rb["bound"] = "lds+valu"
-                rb["note"] = ("the stream is read once per PAIR of chains: about 3 TB/s of HBM traffic, not the bound; lds.busy_frac and valu.busy_frac "
-                              "(counted VALU instructions x 4.3 clocks / SIMD cycles) are -- see DESIGN.md section 4 for the instruction budget per tile")
-                other.append(rb)
-            try:
-                em = em_measurement(R3, T3, H3, seed=args.seed, device=local_rank)
-                rb = roofline_block("k_em_sell (K3: rows pass of one EM sweep)", "em_sweep", em["ms_per_sweep"] * 1e-3, em["sweeps"], em["n_tiles"],
-                                    stream_bytes=em["stream_bytes"])
-                rb["bound"] = "lds"
-                rb["note"] = ("avg_launch_ms is the wall time of one mmg_em_step (rows pass + per-transcript kernels + one read-back); bound by the LDS: "
-                              "per hit one 8-byte gather, one scale word and two 64-bit atomic adds on random window slots (lds.busy_frac, most of it "
-                              "bank conflicts); the limbs of a term are three 64-bit shifts (valu.busy_frac)")
-                other.append(rb)
-            except Exception as e:
-                other.append({"kernel": "k_em_sell", "error": repr(e)})
-            torch.cuda.empty_cache()
-            out["roofline_other"] = other
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, total_reads)
-            out["speedup_vs_cpu_baseline"] = iters_per_s / out["cpu_baseline"]["value"]
-        print(json.dumps(out), flush=True)
+                other["k1m"] = rb
+            if not only or "em" in only:
+                try:
+                    em = em_measurement(R3, T3, H3, seed=args.seed, device=local_rank)
+                    rb = roofline_block("k_em_sell (K3, one mmg_em_step)", "em_sweep", em["ms_per_sweep"] * 1e-3, em["sweeps"], em["n_tiles"], stream_bytes=em["stream_bytes"])
+                    rb["bound"] = "lds"
+                    other["em"] = rb
+                    side["em"] = em
+                except Exception as e:
+                    other["em"] = {"kernel": "k_em_sell", "error": repr(e)[:120]}
+                torch.cuda.empty_cache()
+            # one scalar per configuration, directly under `roofline` (records that keep only an object's leading scalars still carry
+            # every BASELINE config): iterations/s, the SURVEY 8(d) fraction (u32-CSR bytes / time / 8 TB/s) and the counter fraction
+            g = lambda sid, key: (side.get(sid) or {}).get(key)
+            roof["cfg2_it_s"] = g("cfg2", "chain_it_s")
+            roof["cfg2_alg_frac"] = g("cfg2", "alg_frac")
+            roof["cfg3x8_chain_it_s"] = g("cfg3x8", "chain_it_s")
+            roof["cfg3x8_alg_frac"] = g("cfg3x8", "alg_frac")
+            roof["cfg3x8_hbm_frac"] = (other.get("k1m") or {}).get("frac")
+            roof["em_sweep_ms"] = g("em", "ms_per_sweep")
+            roof["em_hbm_frac"] = (other.get("em") or {}).get("frac")
+            roof["real8_chain_it_s"] = g("real8", "chain_it_s")
+            roof["far20_ms"] = g("far20", "ms_per_step")
+            roof["uniform_ms"] = g("uniform", "ms_per_step")
+            roof["keeprows_ms"] = g("keeprows", "ms_per_step")
+            roof["algorithmic_x_peak"] = full_roof["algorithmic_x_peak"]
+            keep = ("id", "chains", "ms_per_step", "chain_it_s", "k1_ms_all_chains", "k2_ms", "kernel", "alg_frac", "far_tiles", "total_k", "error", "ms_per_sweep")
+            roof["configs"] = [compact({k: v for k, v in r.items() if k in keep}) for r in side.values()]
+            roof["other"] = {k: compact(v, drop=("pmc_source", "pattern_read_peak_gbs", "peak", "unit", "timed_launches", "hbm_counter_frac")) for k, v in other.items()}
+            record["side"] = side
+            record["roofline_other"] = other
+        for k in ("hbm_counter_frac", "frac_of_pattern_peak", "effective_clock_ghz", "stream_bytes_per_launch", "algorithmic_bytes_per_launch",
+                  "padded_slots_per_hit", "k_update_avg_launch_ms", "valu", "lds", "wave_cycles", "instructions_per_64_row_tile", "pmc_source"):
+            roof.setdefault(k, full_roof.get(k))
+        roof.setdefault("algorithmic_x_peak", full_roof["algorithmic_x_peak"])
+        line = json.dumps(compact(out))
+        if args.full_json:
+            record["line"] = out
+            with open(args.full_json, "w") as f:
+                json.dump(record, f, indent=1)
+        print(line, flush=True)
     if prob is not None:
         prob.close()
     if world > 1:

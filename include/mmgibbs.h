@@ -164,8 +164,18 @@ int mmg_problem_download(const mmg_problem *p, uint64_t *row_ptr, uint32_t *col_
  * row_id_base + lo + i, like the rows of the parent) or, with lo = 0 and hi = m, a replica for chains mode.  Cut on the parent's
  * device and copied device to device (peer copy); rows, hit order and transcript numbering stay as stored. */
 int mmg_problem_shard(const mmg_problem *full, uint64_t lo, uint64_t hi, int device, mmg_problem **out);
-/* mmg_shard_bounds (below) on the stored rows of p: bounds[0..parts]. */
+/* Contiguous ranges of the stored rows of p for `parts` read shards: bounds[i] = first row of shard i, bounds[parts] = m.  The ranges
+ * have (nearly) equal modelled COST of a sweep, not equal hit counts: the library knows what its tiles cost (a register-path tile by
+ * the bytes of its block, a far tile three times that per far entry, multiplicity tiles by their draws), and the canonical order puts
+ * every far row behind every near row -- the reference's static split of the rows (src/mmseq.cpp:864) would give the last devices the
+ * expensive ones.  Boundaries are tile starts on even random-stream ids.  Problems on the CSR-tile kernel are cut by hits
+ * (mmg_shard_bounds). */
 int mmg_problem_shard_bounds(const mmg_problem *p, int parts, uint64_t *bounds);
+/* The same cut by MEASURED cost: the library runs a few one-chain sample sweeps over p with the weights mu (n doubles, the caller's
+ * numbering: the start values or the EM optimum) in which every workgroup times itself, and cuts the stored rows into ranges of equal
+ * measured time.  What a model cannot know -- what a far entry costs on this part, hit sets that give most of their reads to one
+ * transcript -- is in the measurement.  The chain does not depend on where the rows are cut. */
+int mmg_problem_shard_bounds_timed(const mmg_problem *p, const double *mu, int parts, uint64_t *bounds);
 int mmg_problem_get_l(const mmg_problem *p, double *l);
 /* Start values and the unique-hit column, src/mmseq.cpp:617-638: mu0[t] = sum_{i: t in row i}
  * k_i/|row i| / l[t]; unique_hits[t] = sum of k_i over rows {t} (bit-exact integer). Either
@@ -320,7 +330,8 @@ enum {
     MMG_OPT_EM_KERNEL = 3,         /* 0: row-per-thread EM kernel, 2: sliced-ELL EM kernel                           */
     MMG_OPT_EM_GRID = 4,           /* cap on the EM kernel's grid                                                    */
     MMG_OPT_FUSE_CHAINS = 5,       /* chains advanced per K1 launch: 1 (never fuse), 2 (the default), 4              */
-    MMG_OPT_COUNT_ = 6
+    MMG_OPT_CNT_REPLICAS = 6,      /* 1: one global count vector per chain, 8: replicated (default: by ranges per band) */
+    MMG_OPT_COUNT_ = 7
 };
 int mmg_selftest_option(int option, int value);
 /* The sharded EM of mmg_group_em_create with every shard on ONE device and the exchange done by plain kernels: `sweeps` sweeps from
@@ -328,6 +339,11 @@ int mmg_selftest_option(int option, int value);
  * unsharded problem. */
 int mmg_selftest_em_shards(const mmg_problem *const *shards, int n_shards, const double *mu0, int sweeps, double *mu, double *loglik,
                            int *repeated_passes);
+/* The sharded chain of mmg_group_run_sharded with every shard on ONE device and the count exchange done by a plain kernel: n_iter
+ * iterations of sample on every shard (src/mmseq.cpp:857-891), the count vectors summed over the shards into every sampler
+ * (:896-899), the identical update everywhere (:905-917) -- the same bits as mmg_sampler_run on the unsharded problem.  With
+ * cfg.timing set, mmg_sampler_get_timing of sampler i reports what shard i's sample kernels took. */
+int mmg_selftest_gibbs_shards(mmg_sampler *const *samplers, int n_shards, int n_iter);
 /* What the HIP runtime reports about the k == NULL sliced-ELL sample kernel on `device`: registers, LDS and scratch bytes per
  * thread, and resident 64-thread workgroups per CU (hipOccupancyMaxActiveBlocksPerMultiprocessor). */
 int mmg_selftest_kernel_info(int device, int *vgprs, int *lds_bytes, int *scratch_bytes, int *resident_per_cu);

@@ -20,7 +20,7 @@ class MMGError(RuntimeError):
 
 LAYOUT_CANONICAL, LAYOUT_KEEP_ROWS = 0, 1
 # mmg_selftest_option ids
-OPT_SAMPLE_KERNEL, OPT_FORCE_IDX64, OPT_SELL_WAVES_PER_CU, OPT_EM_KERNEL, OPT_EM_GRID, OPT_FUSE_CHAINS = range(6)
+OPT_SAMPLE_KERNEL, OPT_FORCE_IDX64, OPT_SELL_WAVES_PER_CU, OPT_EM_KERNEL, OPT_EM_GRID, OPT_FUSE_CHAINS, OPT_CNT_REPLICAS = range(7)
 
 
 class ProblemDesc(C.Structure):
@@ -113,8 +113,10 @@ SYMBOLS = {
     "mmg_group_enqueue_us": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "mmg_problem_shard": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_void_p)]),
     "mmg_problem_shard_bounds": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "mmg_problem_shard_bounds_timed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "mmg_group_em_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     "mmg_selftest_em_shards": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "mmg_selftest_gibbs_shards": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mmg_group_pool_moments": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
     "mmg_shard_bounds": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]),
     "mmg_host_gamma_trace": (C.c_int, [C.c_uint64, C.c_uint64, C.c_double, C.c_double, C.c_int, C.c_void_p]),

@@ -302,6 +302,7 @@ __global__ __launch_bounds__(BS) void k_sample(const IdxT *__restrict__ row_ptr,
 
     const uint64_t t_begin = chunk_tile[blockIdx.x], t_end = chunk_tile[blockIdx.x + 1];
     if (t_begin >= t_end) return;
+    gcnt += (size_t)(blockIdx.x & a.cnt_rep_mask) * a.cnt_rep_stride; // (mmg_types.h: CNT_REPLICAS)
 
     for (int i = tid; i < WIN; i += BS) s_cnt[i] = 0;
     if (tid < 2) s_mu[WIN + tid] = 0.0;

@@ -70,25 +70,34 @@ static void printUsage(ostream &out)
         << "  -gpus INT          number of devices, device .. device+gpus-1 (default: 1).  With one chain the reads are sharded" << endl
         << "                     over them (same results as on one device); with -chains >= gpus every device runs chains/gpus chains" << endl
         << "  -chains INT        independent Gibbs chains (default: 1); log_mu, sd and mcse pool all chains, traces are chain 0's" << endl
+        << "  -em_one_device     with -gpus > 1 and one chain: run the EM on the first device alone instead of over the read shards" << endl
         << endl;
 }
 
-static void tokenise(const string &str, vector<string> &tokens, const string &delimiters)
+// the fields of `text` between separators (empty fields dropped)
+static vector<string> split_fields(const string &text, char sep)
 {
-    string::size_type lastPos = str.find_first_not_of(delimiters, 0);
-    string::size_type pos = str.find_first_of(delimiters, lastPos);
-    while (string::npos != pos || string::npos != lastPos) {
-        tokens.push_back(str.substr(lastPos, pos - lastPos));
-        lastPos = str.find_first_not_of(delimiters, pos);
-        pos = str.find_first_of(delimiters, lastPos);
+    vector<string> out;
+    string cur;
+    for (char ch : text) {
+        if (ch != sep) { cur += ch; continue; }
+        if (!cur.empty()) out.push_back(cur);
+        cur.clear();
     }
+    if (!cur.empty()) out.push_back(cur);
+    return out;
 }
 
-static int powerof2(unsigned int x)
-{
-    while (((x & 1) == 0) && x > 1) x >>= 1;
-    return (x == 1);
-}
+static bool is_power_of_two(unsigned v) { return v != 0 && (v & (v - 1)) == 0; }
+
+// Command line: a table of options -- name, the variable it sets, how its value is read -- walked once.  Same flags, defaults,
+// messages and exit codes as the reference's loop at src/mmseq.cpp:206-276 (tests/test_cli.py holds them), plus -device / -gpus /
+// -chains / -em_one_device of this build.
+struct CliOption {
+    const char *name;
+    enum Kind { REAL, INT, FLAG, LIST, HELP, VERSION } kind;
+    void *target;
+};
 
 // the background writer of .k / .M (if any) finishes its files before the process leaves on a device error: the reference has
 // written both by then (src/mmseq.cpp:682-695), and exit() must not run under a thread that is still formatting
@@ -311,75 +320,52 @@ int main(int argc, char **argv)
     const int trace_length = 1024;
     int gibbs_ss = gibbs_iter / trace_length;
     vector<double> percentiles = {5.0, 25.0, 50.0, 75.0, 95.0};
-    vector<string> tokens;
     int seed = 1234;
     bool debug = false;
     int device = 0, gpus = 1, chains = 1;
 
-    vector<string> arguments;
-    for (int i = 1; i < argc; i++) arguments.push_back(string(argv[i]));
-    auto need_value = [&]() {
-        if (arguments.size() < 2) { cerr << "Error: mandatory arguments missing.\n"; printUsage(cerr); exit(1); }
+    bool em_one_device = false;
+    vector<string> percentile_fields;
+    const CliOption options[] = {
+        {"-alpha", CliOption::REAL, &alpha},        {"-beta", CliOption::REAL, &beta},
+        {"-max_em_iter", CliOption::INT, &max_em_iter}, {"-epsilon", CliOption::REAL, &epsilon},
+        {"-gibbs_iter", CliOption::INT, &gibbs_iter},   {"-gibbs_ss", CliOption::INT, &gibbs_ss},
+        {"-seed", CliOption::INT, &seed},           {"-device", CliOption::INT, &device},
+        {"-gpus", CliOption::INT, &gpus},           {"-chains", CliOption::INT, &chains},
+        {"-percentiles", CliOption::LIST, &percentile_fields},
+        {"-debug", CliOption::FLAG, &debug},        {"-em_one_device", CliOption::FLAG, &em_one_device},
+        {"-h", CliOption::HELP, nullptr},           {"-help", CliOption::HELP, nullptr},       {"--help", CliOption::HELP, nullptr},
+        {"-v", CliOption::VERSION, nullptr},        {"-version", CliOption::VERSION, nullptr}, {"--version", CliOption::VERSION, nullptr},
     };
-    while (true) {
-        if (arguments.size() > 0 && arguments[0] == "-alpha") {
-            need_value(); arguments.erase(arguments.begin());
-            alpha = strtod(arguments[0].c_str(), NULL); arguments.erase(arguments.begin());
-        } else if (arguments.size() > 0 && arguments[0] == "-beta") {
-            need_value(); arguments.erase(arguments.begin());
-            beta = strtod(arguments[0].c_str(), NULL); arguments.erase(arguments.begin());
-        } else if (arguments.size() > 0 && arguments[0] == "-max_em_iter") {
-            need_value(); arguments.erase(arguments.begin());
-            max_em_iter = atoi(arguments[0].c_str()); arguments.erase(arguments.begin());
-        } else if (arguments.size() > 0 && arguments[0] == "-epsilon") {
-            need_value(); arguments.erase(arguments.begin());
-            epsilon = strtod(arguments[0].c_str(), NULL); arguments.erase(arguments.begin());
-        } else if (arguments.size() > 0 && arguments[0] == "-gibbs_iter") {
-            need_value(); arguments.erase(arguments.begin());
-            gibbs_iter = atoi(arguments[0].c_str()); arguments.erase(arguments.begin());
-        } else if (arguments.size() > 0 && arguments[0] == "-gibbs_ss") {
-            need_value(); arguments.erase(arguments.begin());
-            gibbs_ss = atoi(arguments[0].c_str()); arguments.erase(arguments.begin());
-        } else if (arguments.size() > 0 && arguments[0] == "-seed") {
-            need_value(); arguments.erase(arguments.begin());
-            seed = atoi(arguments[0].c_str()); arguments.erase(arguments.begin());
-        } else if (arguments.size() > 0 && arguments[0] == "-device") {
-            need_value(); arguments.erase(arguments.begin());
-            device = atoi(arguments[0].c_str()); arguments.erase(arguments.begin());
-        } else if (arguments.size() > 0 && arguments[0] == "-gpus") {
-            need_value(); arguments.erase(arguments.begin());
-            gpus = atoi(arguments[0].c_str()); arguments.erase(arguments.begin());
-        } else if (arguments.size() > 0 && arguments[0] == "-chains") {
-            need_value(); arguments.erase(arguments.begin());
-            chains = atoi(arguments[0].c_str()); arguments.erase(arguments.begin());
-        } else if (arguments.size() > 0 && arguments[0] == "-percentiles") {
-            need_value(); arguments.erase(arguments.begin());
-            tokens.clear();
-            tokenise(arguments[0], tokens, ",");
-            percentiles.resize(tokens.size());
-            for (size_t i = 0; i < tokens.size(); i++) {
-                const double v = strtod(tokens[i].c_str(), NULL);
-                if (v >= 0 && v <= 100) percentiles[i] = v;
-                else { cerr << "Percentiles must be in (0,100)\n"; exit(1); }
-            }
-            arguments.erase(arguments.begin());
-        } else if (arguments.size() > 0 && arguments[0] == "-debug") {
-            debug = true; arguments.erase(arguments.begin());
-        } else if (arguments.size() > 0 && (arguments[0] == "-h" || arguments[0] == "--help" || arguments[0] == "-help")) {
-            cerr << "Calculate mmseq expression estimates.\n";
-            printUsage(cerr);
-            exit(1); // the reference exits 1 here too (src/mmseq.cpp:256-259)
-        } else if (arguments.size() > 0 && (arguments[0] == "-v" || arguments[0] == "--version" || arguments[0] == "-version")) {
-            cerr << "mmseq-" << MMSEQ_VERSION << endl;
-            exit(1);
-        } else {
-            if (arguments.size() == 2) break;
-            if (arguments.size() > 0 && arguments[0][0] == '-') cerr << "Error: unrecognised option " << arguments[0] << ".\n";
-            else cerr << "Error: mandatory arguments missing.\n";
-            printUsage(cerr);
-            exit(1);
+    auto usage_error = [&](const string &msg) { cerr << msg << "\n"; printUsage(cerr); exit(1); };
+    int pos = 1;                                   // next word of the command line
+    for (;;) {
+        const CliOption *opt = nullptr;
+        if (pos < argc) for (const CliOption &o : options) if (strcmp(argv[pos], o.name) == 0) opt = &o;
+        if (!opt) {                                // not an option: exactly the two positional arguments must be left
+            if (argc - pos == 2) break;
+            if (pos < argc && argv[pos][0] == '-') usage_error(string("Error: unrecognised option ") + argv[pos] + ".");
+            usage_error("Error: mandatory arguments missing.");
+        }
+        if (opt->kind == CliOption::HELP) { cerr << "Calculate mmseq expression estimates.\n"; printUsage(cerr); exit(1); } // exit code 1, as src/mmseq.cpp:256-259
+        if (opt->kind == CliOption::VERSION) { cerr << "mmseq-" << MMSEQ_VERSION << endl; exit(1); }
+        if (opt->kind == CliOption::FLAG) { *(bool *)opt->target = true; pos += 1; continue; }
+        if (pos + 1 >= argc) usage_error("Error: mandatory arguments missing.");
+        const char *value = argv[pos + 1];
+        if (opt->kind == CliOption::REAL) *(double *)opt->target = strtod(value, NULL);
+        else if (opt->kind == CliOption::INT) *(int *)opt->target = atoi(value);
+        else *(vector<string> *)opt->target = split_fields(value, ',');
+        pos += 2;
+    }
+    if (!percentile_fields.empty()) {
+        percentiles.resize(percentile_fields.size());
+        for (size_t i = 0; i < percentile_fields.size(); i++) {
+            const double v = strtod(percentile_fields[i].c_str(), NULL);
+            if (!(v >= 0 && v <= 100)) { cerr << "Percentiles must be in (0,100)\n"; exit(1); }
+            percentiles[i] = v;
         }
     }
+    const vector<string> arguments = {argv[pos], argv[pos + 1]};   // hits_file, output_base
     if (gibbs_ss == 0 || gibbs_iter % gibbs_ss != 0) { // :278 (gibbs_ss == 0 is a division by zero there)
         cerr << "Error: gibbs_iter must be divisible by gibbs_ss.\n";
         printUsage(cerr);
@@ -401,7 +387,7 @@ int main(int argc, char **argv)
         printUsage(cerr);
         exit(1);
     }
-    if (!powerof2(trace_length)) {
+    if (!is_power_of_two((unsigned)trace_length)) {
         cerr << "Error: gibbs_iter/gibbs_ss must be a power of 2.\n";
         printUsage(cerr);
         exit(1);
@@ -858,22 +844,32 @@ int main(int argc, char **argv)
         mmg_problem_info inf;
         MMG_TRY(mmg_problem_info_get(prob, &inf));
         vector<uint64_t> bounds(gpus + 1, 0);
-        if (shard) MMG_TRY(mmg_problem_shard_bounds(prob, gpus, bounds.data()));
+        // cut by measured cost: every candidate shard is timed on device 0 with the start values as weights (0.1 s), so that the devices
+        // finish their sweeps together whatever the mix of near rows, far rows and multiplicities (src/mmseq.cpp:864 splits the rows evenly)
+        if (shard) MMG_TRY(mmg_problem_shard_bounds_timed(prob, mu.data(), gpus, bounds.data()));
         part.resize(gpus);
         for (int i = 0; i < gpus; ++i) {
             if (!shard && i == 0) { part[0] = prob; continue; }
             MMG_TRY(mmg_problem_shard(prob, shard ? bounds[i] : 0, shard ? bounds[i + 1] : inf.m, devs[i], &part[i]));
             dprob.push_back(part[i]);
         }
+        if (stage.on && shard) {
+            fprintf(stderr, "[timing] read shards (rows):");
+            for (int i = 0; i < gpus; ++i) fprintf(stderr, " %llu", (unsigned long long)(bounds[i + 1] - bounds[i]));
+            fprintf(stderr, "\n");
+        }
         stage.mark(shard ? "read shards" : "replicas");
     }
+    const bool shard_em = shard && !em_one_device;
+    // the whole problem is needed on device 0 only while something runs on it: with sharded EM and Gibbs, not beyond this point
+    if (shard && shard_em) { mmg_problem_destroy(prob); prob = nullptr; }
     // ---- EM on the device(s) (src/mmseq.cpp:741-811): mu stays there; this loop owns the stopping rule and the output
     GzText *gz_em = debug ? new GzText(output_base + ".trace_em.gz") : nullptr;
     if (gz_em) { for (uint32_t t = 0; t < n; t++) { gz_em->str(sid(t)); gz_em->str(" "); } gz_em->str("\n"); }
     {
         double loglik = 0.0;
-        vector<mmg_em *> ems(shard ? gpus : 1, nullptr);
-        if (shard) MMG_TRY(mmg_group_em_create(grp, part.data(), mu.data(), ems.data(), &loglik)); // exact integer sums: the bits of the unsharded EM
+        vector<mmg_em *> ems(shard_em ? gpus : 1, nullptr);
+        if (shard_em) MMG_TRY(mmg_group_em_create(grp, part.data(), mu.data(), ems.data(), &loglik)); // exact integer sums: the bits of the unsharded EM
         else MMG_TRY(mmg_em_create(prob, mu.data(), &ems[0], &loglik));
         mmg_em *em = ems[0];
         stage.mark("EM set-up + first pass");
@@ -897,6 +893,7 @@ int main(int argc, char **argv)
         }
         MMG_TRY(mmg_em_get_mu(em, mu.data()));
         for (auto e : ems) mmg_em_destroy(e);
+        if (shard && prob) { mmg_problem_destroy(prob); prob = nullptr; }   // (-em_one_device: the whole problem has served)
         cout << endl;
         cout.unsetf(ios::floatfield);
         cout.precision(6);

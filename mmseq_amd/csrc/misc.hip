@@ -22,6 +22,33 @@ void launch_gather_rows(const void *in, void *out, uint32_t n, uint32_t rows, in
     else hipLaunchKernelGGL(k_gather_rows<uint32_t>, dim3(g), dim3(256), 0, s, (const uint32_t *)in, (uint32_t *)out, n, rows, int_of_ext);
 }
 
+// cnt[i] += sum over the replicas r >= 1 of cnt[r * stride + i], which are zeroed: after mmg_sampler_sample the public count vector
+// (replica 0: mmg_sampler_counts_devptr, the buffer a read-shard all-reduce works on) holds the device's column sums
+__global__ __launch_bounds__(256) void k_fold_counts(int32_t *__restrict__ cnt, uint64_t stride, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t x = cnt[i];
+#pragma unroll
+    for (uint32_t r = 1; r < CNT_REPLICAS; ++r) { x += cnt[(uint64_t)r * stride + i]; cnt[(uint64_t)r * stride + i] = 0; }
+    cnt[i] = x;
+}
+void launch_fold_counts(int32_t *cnt, uint64_t stride, size_t n, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(k_fold_counts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, cnt, stride, n);
+}
+
+// dst[i] += src[i]: the count exchange of the Gibbs self test that runs read shards side by side on ONE device
+__global__ __launch_bounds__(256) void k_add_i32(int32_t *__restrict__ dst, const int32_t *__restrict__ src, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+void launch_add_i32(int32_t *dst, const int32_t *src, size_t n, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(k_add_i32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, src, n);
+}
+
 void launch_start_values(bool idx64, const void *row_ptr, const uint32_t *col, const uint32_t *k, uint64_t m, uint32_t n,
                          uint64_t *acc3, int32_t *unique_hits, hipStream_t s)
 {

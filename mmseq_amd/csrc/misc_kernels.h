@@ -12,12 +12,24 @@ __global__ __launch_bounds__(256) void k_update(UpdateArgs a)
     const uint32_t c = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x; // grid.y = chains: no 64-bit division per lane
     if (t >= a.n) return;
     const uint64_t gid = (uint64_t)c * a.n + t;
-    const int32_t x = a.cnt[gid];
+    // the counts of the iteration: the sum over the replicas K1's workgroups added into (mmg_types.h: CNT_REPLICAS); all loads go out together
+    int32_t x = a.cnt[gid];
+    if (a.cnt_replicas > 1) { // uniform
+        int32_t xr[CNT_REPLICAS - 1];
+#pragma unroll
+        for (uint32_t r = 1; r < CNT_REPLICAS; ++r) xr[r - 1] = a.cnt[(uint64_t)r * a.cnt_rep_stride + gid];
+#pragma unroll
+        for (uint32_t r = 1; r < CNT_REPLICAS; ++r) x += xr[r - 1];
+    }
     // the moments are read-modify-write: their loads go out with the count's, not after the draw (a wave of this kernel is one long
     // dependent chain -- at config 2 there is one wave per SIMD and nothing to hide a second memory round trip behind)
     double sl = 0.0, sl2 = 0.0;
     if (a.sample_idx >= 0) { sl = a.sum_log[gid]; sl2 = a.sum_log2[gid]; }
     a.cnt[gid] = 0;
+    if (a.cnt_replicas > 1) {
+#pragma unroll
+        for (uint32_t r = 1; r < CNT_REPLICAS; ++r) a.cnt[(uint64_t)r * a.cnt_rep_stride + gid] = 0;
+    }
     a.cnt_last[gid] = x;
     // the Gamma stream is keyed by the CALLER's transcript id: the chain does not depend on the device numbering
     Stream s(a.seed, a.chain_base + c, TAG_GAMMA, (uint64_t)(a.ext_of_int ? a.ext_of_int[t] : t), a.iter);

@@ -47,6 +47,17 @@ struct mmg_problem {
     uint64_t n_x_tiles = 0;
     bool use_sell = false;
     std::vector<uint64_t> h_sell_cum;           // cumulative tile cost, kept for the EM kernel's own ranges
+    // read shards (mmg_problem_shard_bounds): first row of every tile and the cumulative modelled cost of a sweep over the tiles
+    // [0, t) -- multiplicities included, a register-path tile priced by its groups (the stream bounds K1: time follows bytes)
+    std::vector<uint64_t> h_tile_row, h_shard_cum;
+    // the tile lists of the one-chain sample launches as the host built them (mmg_problem_shard_bounds_timed launches the kernels over
+    // sub-intervals of them): entry e of the main list is tile h_list1_tile[e] (empty: the identity) and costs h_cum1[e + 1] - h_cum1[e]
+    // in the units of the launch's ranges; the same for the list of multiplicity tiles
+    std::vector<uint64_t> h_cum1, h_cumk;
+    std::vector<uint32_t> h_list1_tile, h_listk_tile;
+    uint64_t resident1 = 0, residentk = 0;      // workgroups of the two kernels the device holds at once
+    uint32_t cnt_replicas = 1;                  // replicas of a sampler's count vectors (mmg_types.h: CNT_REPLICAS), 1 or CNT_REPLICAS
+    bool canonical_rows = false;                // the rows are in canonical order: a canonical problem, or a shard cut from one
     // CSR tiles of the fallback kernel k_sample (built only when the sliced-ELL stream is not used)
     mmg::TileDesc *d_tiles = nullptr;
     uint64_t n_tiles = 0;

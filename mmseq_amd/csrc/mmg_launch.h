@@ -43,6 +43,8 @@ void launch_update(const UpdateArgs &a, hipStream_t s);
 void launch_transpose(const double *in, double *out, uint32_t n, uint32_t S, const uint32_t *int_of_ext, hipStream_t s);
 // out[r * n + t_ext] = in[r * n + int_of_ext[t_ext]] for r < rows (element size 4 or 8 bytes)
 void launch_gather_rows(const void *in, void *out, uint32_t n, uint32_t rows, int elem_bytes, const uint32_t *int_of_ext, hipStream_t s);
+void launch_fold_counts(int32_t *cnt, uint64_t stride, size_t n, hipStream_t s); // replicas 1.. of the count vectors added into replica 0, zeroed
+void launch_add_i32(int32_t *dst, const int32_t *src, size_t n, hipStream_t s); // dst[i] += src[i], one device
 void launch_start_values(bool idx64, const void *row_ptr, const uint32_t *col, const uint32_t *k, uint64_t m, uint32_t n,
                          uint64_t *acc3, int32_t *unique_hits, hipStream_t s);
 void launch_synth_len(const SynthArgs &a, double far_fraction, uint32_t *lens, hipStream_t s);

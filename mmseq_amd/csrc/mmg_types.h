@@ -95,16 +95,29 @@ struct SellTile {
 };  // dwords only: the descriptors are fetched with scalar loads
 MMG_TYPES_HD inline uint32_t sell_meta(uint32_t nrows, uint32_t ng, uint32_t flags, uint32_t nf = 0) { return nrows | (ng << 8) | (flags << 16) | (nf << 24); }
 
+// Replicas of the global count vectors.  A workgroup flushes the counts of its LDS window with one agent-scope atomic per touched
+// transcript, and the workgroups that walk one band run side by side: the counts of a popular transcript are hit by hundreds of
+// atomics to ONE address, which the memory side serialises (a read shard whose rows give a third of their reads to one transcript took
+// 2.7 x the time of its neighbours; with the flush disabled every shard took the same).  Workgroup b adds into replica
+// b % CNT_REPLICAS -- neighbouring ranges, different addresses -- and K2 sums the replicas (integer sums: any order, same bits).
+// Replicas cost K2 eight count loads and stores per transcript instead of one (+1.5 us at 200 k transcripts), and they pay only where
+// many ranges share a band -- read shards, small problems over many transcripts: a problem uses them when its launch has at least
+// CNT_REPLICA_RANGES_PER_BAND ranges per run of equal band (mmg_problem::cnt_replicas; the whole config-3 problem has 7: one vector).
+constexpr uint32_t CNT_REPLICAS = 8;
+constexpr uint64_t CNT_REPLICA_RANGES_PER_BAND = 12;
+
 struct SampleArgs {
     uint64_t seed;
     uint64_t row_id_base;
+    uint64_t cnt_rep_stride; // elements between two replicas of the count vectors ([replicas][chains][n])
+    uint32_t cnt_rep_mask;   // replicas - 1 (1 or CNT_REPLICAS replicas)
     uint32_t n;
     uint32_t chain;
     uint32_t iter;
 };
 
 struct UpdateArgs {
-    int32_t *cnt;          // [C][n]  read, then zeroed
+    int32_t *cnt;          // [cnt_replicas][C][n]  replicas summed, then zeroed
     int32_t *cnt_last;     // [C][n]
     const double *scale;   // n : 1/(beta + l[t])
     double *mu;            // [C][n]
@@ -113,6 +126,8 @@ struct UpdateArgs {
     double *sum_log2;      // [C][n]
     const uint32_t *ext_of_int; // n: the caller's id of device transcript t (keys the Gamma stream), or nullptr = identity
     uint64_t seed;
+    uint64_t cnt_rep_stride; // elements between two replicas of cnt (= n_chains * n)
+    uint32_t cnt_replicas;   // 1 or CNT_REPLICAS
     double alpha;
     uint32_t n;
     uint32_t n_chains;

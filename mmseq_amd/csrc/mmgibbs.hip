@@ -28,7 +28,7 @@ extern "C" const char *mmg_last_error(void) { return g_err.c_str(); }
 extern "C" int mmg_abi_version(void) { return MMG_ABI_VERSION; }
 
 // self-test overrides (mmg_selftest_option): -1 = the library decides
-static std::atomic<int> g_opt[MMG_OPT_COUNT_] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
+static std::atomic<int> g_opt[MMG_OPT_COUNT_] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
 int mmg::opt(int o) { return g_opt[o].load(std::memory_order_relaxed); }
 extern "C" int mmg_selftest_option(int option, int value)
 {
@@ -108,6 +108,11 @@ constexpr uint64_t SELL_FAST_TILE_COST = 2;
 constexpr uint64_t SELL_FAR_TILE_COST = 2;   // plus SELL_FAR_ENTRY_COST per entry of the far list
 constexpr uint64_t SELL_FAR_ENTRY_COST = 4;
 constexpr uint64_t SELL_SLOW_TILE_COST = 48; // a CSR-walked tile
+// the cut into read shards (h_shard_cum): a register-path tile of 5.4 groups (config 3) costs 1 + 2 * 5.4 = 11.8 of these units
+constexpr uint64_t SHARD_TILE_COST = 1, SHARD_GROUP_COST = 2;
+constexpr uint64_t SHARD_FAR_ENTRY_COST = 24;  // measured (tools/shard_balance.py): a far tile with one entry per lane takes 3 x a register-path tile
+constexpr uint64_t SHARD_SLOW_TILE_COST = 280; // 24 x a register-path tile
+constexpr uint64_t SHARD_DRAW_COST = 12, SHARD_BINOMIAL_COST = 210; // per draw of a tile's largest k / per hit of its binomial chains (as cumk: 2 and 36 halves of a tile)
 // k_sample (CSR tiles) costs 2.8 of these units per 64 hits (7.4 ms for 1.0 G uniform hits): a problem dearer on the stream kernel runs there
 
 // The same with a tapered end: the last `resident` ranges' worth of cost is cut into twice as many ranges of half the cost (the
@@ -212,13 +217,14 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
     auto is_far = [&](uint64_t t) { return far_nf[t] <= 255u; };
     cleanup();
 #undef SELL_TRY
-    auto resident_grid = [&](bool has_k) {
+    auto resident_raw = [&](bool has_k) { // workgroups of the kernel the device holds at once
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k1_sell_kernel(p->idx64, has_k), 64, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 16; }
         if (per_cu > 32) per_cu = 32;
         if (opt(MMG_OPT_SELL_WAVES_PER_CU) >= 1 && opt(MMG_OPT_SELL_WAVES_PER_CU) < per_cu) per_cu = opt(MMG_OPT_SELL_WAVES_PER_CU);
-        return std::max<uint64_t>(1, std::min<uint64_t>(nt, (uint64_t)p->cu_count * per_cu));
+        return (uint64_t)p->cu_count * per_cu;
     };
+    auto resident_grid = [&](bool has_k) { return std::max<uint64_t>(1, std::min<uint64_t>(nt, resident_raw(has_k))); };
     // As many workgroups as fit at once while a range is short (every workgroup pays for a window load and the fill of its prefetch
     // pipeline: at config 2 a range is 10 tiles); once ranges are long, several generations of them -- the later generations start as
     // the first ones finish and even out the tail.  Round 2 (K1 bound by instruction issue) measured ranges of about 24 tiles best
@@ -248,6 +254,22 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
         // a draw costs about as much as a register-path tile per 64 rows (2), a step of the binomial chain 36 of them
         cumk[t + 1] = cumk[t] + (!hk ? 0 : 2 * c + (draws_categoricals(td[t].kmax, td[t].maxlen > 1 ? td[t].maxlen : 2) ? 2 * (uint64_t)td[t].kmax : 36 * (uint64_t)td[t].maxlen));
     }
+    // What a sweep over the tiles [0, t) costs, for the cut into read shards (mmg_problem_shard_bounds).  The ranges of ONE launch get by
+    // with "2 per register-path tile": several generations of short ranges even out what the model misses.  A shard is one range per
+    // device and the slowest device sets the pace, so here a register-path tile is priced by what bounds it -- the bytes of its block,
+    // ng groups of 256 (K1's time per tile at 2.4 and 5.4 groups per tile: 2.0 and 4.7 us per million rows, i.e. proportional) -- a far
+    // tile by its block plus SHARD_FAR_ENTRY_COST per entry of the far list (64 gathers from L2), a CSR-walked tile by the model above.
+    p->h_shard_cum.assign(nt + 1, 0);
+    for (uint64_t t = 0; t < nt; ++t) {
+        uint64_t c = 0;
+        if (td[t].nnz) {
+            const uint64_t blk = SHARD_TILE_COST + SHARD_GROUP_COST * (qualifies(td[t]) ? (td[t].maxlen + 3) / 4 : is_far(t) ? (far_nn[t] + 3) / 4 : 0);
+            c = qualifies(td[t]) ? blk : is_far(t) ? blk + SHARD_FAR_ENTRY_COST * far_nf[t] : SHARD_SLOW_TILE_COST;
+            if (has_k_rows(t)) c = 2 * c + (draws_categoricals(td[t].kmax, td[t].maxlen > 1 ? td[t].maxlen : 2) ? SHARD_DRAW_COST * (uint64_t)td[t].kmax : SHARD_BINOMIAL_COST * (uint64_t)td[t].maxlen);
+        }
+        p->h_shard_cum[t + 1] = p->h_shard_cum[t] + c;
+    }
+    p->h_tile_row = tile_row;
     std::vector<uint64_t> chunk;
     if (n_hask) weighted_chunks(p->h_sell_cum, grid, chunk); // (with SELL_HASK tiles: only the windows below follow these ranges)
     else weighted_chunks_tapered(cum1, grid, opt(MMG_OPT_SELL_WAVES_PER_CU) >= 1 ? 0 : resident_grid(false), chunk);
@@ -295,7 +317,7 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
     // tiles that do not qualify are walked from their far lists or from the CSR inside the same kernel (far rows are sorted last:
     // a contiguous tail); a problem whose tiles cost more than the CSR kernel's on average -- hits uniform over all transcripts -- runs there
     p->use_sell = p->h_sell_cum[nt] <= p->nnz * 7 / 160 || opt(MMG_OPT_SAMPLE_KERNEL) == 2;
-    if (!p->use_sell) { p->h_sell_cum.clear(); return MMG_OK; }
+    if (!p->use_sell) { p->h_sell_cum.clear(); p->h_shard_cum.clear(); p->h_tile_row.clear(); return MMG_OK; }
     p->sell_bytes = pos * 16;
     p->n_sell_tiles = nt;
     p->n_fast_tiles = n_fast;
@@ -308,13 +330,15 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
     HIP_TRY(hipMemcpy(p->d_sell_tiles, st.data(), nt * sizeof(SellTile), hipMemcpyHostToDevice));
     p->grid_sell = (int)n_ranges;
     p->n_hask_tiles = n_hask;
+    // many ranges per band: the flushes of neighbouring workgroups meet at the same addresses (mmg_types.h: CNT_REPLICAS)
+    p->cnt_replicas = n_ranges >= CNT_REPLICA_RANGES_PER_BAND * segs.size() ? CNT_REPLICAS : 1u;
     if (n_hask) { // two launches, each over its own descriptor list and ranges
         std::vector<SellTile> s1, sk;
         std::vector<uint64_t> c1(1, 0), ck(1, 0);
         s1.reserve(nt - n_hask); sk.reserve(n_hask);
         for (uint64_t t = 0; t < nt; ++t) {
-            if (st[t].flags() & SELL_HASK) { sk.push_back(st[t]); ck.push_back(ck.back() + (cumk[t + 1] - cumk[t])); }
-            else { s1.push_back(st[t]); c1.push_back(c1.back() + (cum1[t + 1] - cum1[t])); }
+            if (st[t].flags() & SELL_HASK) { sk.push_back(st[t]); ck.push_back(ck.back() + (cumk[t + 1] - cumk[t])); p->h_listk_tile.push_back((uint32_t)t); }
+            else { s1.push_back(st[t]); c1.push_back(c1.back() + (cum1[t + 1] - cum1[t])); p->h_list1_tile.push_back((uint32_t)t); }
         }
         const uint64_t g1 = std::max<uint64_t>(1, std::min<uint64_t>(s1.size(), grid)), gk = std::max<uint64_t>(1, std::min<uint64_t>(sk.size(), 4 * resident_grid(true))); // (a multiplicity tile costs tens of register-path tiles: short ranges, several generations, even out the tail)
         if (s1.empty()) { SellTile e; e.off16 = 0; e.r0 = 0; e.wbase = 0; e.meta = sell_meta(0, 0, SELL_EMPTY); s1.push_back(e); c1.push_back(0); }
@@ -328,10 +352,13 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
         HIP_TRY(hipMemcpy(p->d_sell_tiles_k, sk.data(), sk.size() * sizeof(SellTile), hipMemcpyHostToDevice));
         HIP_TRY(upload_ranges(rk, sk, &p->d_sell_chunk_k));
         HIP_TRY(upload_ranges(r1, s1, &p->d_sell_chunk));
+        p->h_cum1 = c1; p->h_cumk = ck;
         p->grid_sell_k = (int)gk;
         p->grid_sell = (int)g1;
         p->device_bytes += (s1.size() + sk.size()) * sizeof(SellTile);
     }
+    if (!n_hask) p->h_cum1 = cum1;
+    p->resident1 = resident_raw(false); p->residentk = resident_raw(true);
     if (!n_hask) HIP_TRY(upload_ranges(chunk, st, &p->d_sell_chunk)); // (with SELL_HASK tiles: uploaded above, over the list without them)
     { // chains in pairs (k_sample_sell_multi): the register-path tiles without multiplicities in their own ranges, the rest apart
         std::vector<SellTile> sf, sx;
@@ -458,8 +485,11 @@ static int problem_build(mmg_problem *p, uint64_t *d_rp64)
             B_TRY(layout_row_keys(p->m, d_rp64, p->d_col, p->d_k, d_key, 0));
         }
         // kept rows may be in any order: band-aligned tiles only while the runs of equal band stay long
-        const uint64_t max_seg = p->layout == (int)MMG_LAYOUT_CANONICAL ? std::min<uint64_t>(p->m, 2 * ((uint64_t)p->n >> LAYOUT_BAND_SHIFT) + 4)
-                                                                          : std::max<uint64_t>(1024, p->m / 32);
+        // (a shard cut from a canonical problem is in canonical order whatever its size: the canonical bound, not the one for rows in any order)
+        if (p->layout == (int)MMG_LAYOUT_CANONICAL) p->canonical_rows = true;
+        const uint64_t canon_seg = std::min<uint64_t>(p->m, 2 * ((uint64_t)p->n >> LAYOUT_BAND_SHIFT) + 4);
+        const uint64_t max_seg = p->layout == (int)MMG_LAYOUT_CANONICAL ? canon_seg
+                                                                          : std::max<uint64_t>(p->canonical_rows ? canon_seg : 0, std::max<uint64_t>(1024, p->m / 32));
         B_TRY(layout_segments(p->m, d_key, max_seg, seg, 0));
         B_TRY(layout_max_row_len(p->m, d_rp64, &p->max_row_len, 0));
     }
@@ -476,7 +506,8 @@ static int problem_build(mmg_problem *p, uint64_t *d_rp64)
 #undef B_TRY
     int rc = problem_build_sell(p, seg, d_key);
     if (d_key) { (void)hipFree(d_key); d_key = nullptr; }
-    if (rc == MMG_OK && !p->use_sell) rc = problem_build_csr_tiles(p, d_rp64);
+    if (rc == MMG_OK && !p->use_sell) { p->cnt_replicas = 1; rc = problem_build_csr_tiles(p, d_rp64); }
+    if (opt(MMG_OPT_CNT_REPLICAS) >= 1) p->cnt_replicas = opt(MMG_OPT_CNT_REPLICAS) > 1 ? CNT_REPLICAS : 1u;
     if (!p->idx64) (void)hipFree(d_rp64);
     return rc;
 }
@@ -569,6 +600,7 @@ extern "C" int mmg_problem_shard(const mmg_problem *full, uint64_t lo, uint64_t 
     p->m = hi - lo; p->n = full->n; p->row_id_base = full->row_id_base + lo; p->layout = (int)MMG_LAYOUT_KEEP_ROWS;
     p->h_l = full->h_l;
     p->h_int_of_ext = full->h_int_of_ext; p->h_ext_of_int = full->h_ext_of_int;
+    p->canonical_rows = full->canonical_rows;
     uint64_t *src_rp = nullptr, *d_rp64 = nullptr;
     auto bail = [&](int code) {
         if (src_rp) { (void)hipSetDevice(full->device); (void)hipFree(src_rp); }
@@ -635,10 +667,31 @@ extern "C" int mmg_problem_shard(const mmg_problem *full, uint64_t lo, uint64_t 
     return MMG_OK;
 }
 
-// mmg_shard_bounds on the stored rows of a problem (only the row offsets are read back)
+// Contiguous ranges of the stored rows for `parts` read shards, of (nearly) equal modelled COST of a sweep (h_shard_cum): the sharded
+// chain advances at the pace of its slowest device, and the canonical order puts every far row behind every near row -- equal hit
+// counts (mmg_shard_bounds; the reference's schedule(static) over rows, src/mmseq.cpp:864, has the same weakness) would hand the last
+// devices nothing but far tiles at 3 x the cost.  Boundaries are tile starts rounded up to even rows (a Philox block serves rows 2q and
+// 2q + 1).  Problems on the CSR-tile kernel (its cost follows the hits) are cut by hits.
 extern "C" int mmg_problem_shard_bounds(const mmg_problem *p, int parts, uint64_t *bounds)
 {
     if (!p || !bounds || parts < 1) return fail(MMG_ERR_ARG, "bad argument");
+    if (p->use_sell && !p->h_shard_cum.empty() && p->h_shard_cum.back() > 0) {
+        const std::vector<uint64_t> &cum = p->h_shard_cum;
+        const uint64_t nt = cum.size() - 1, total = cum[nt];
+        bounds[0] = 0;
+        uint64_t t = 0;
+        for (int i = 1; i < parts; ++i) {
+            const uint64_t target = (uint64_t)(((unsigned __int128)total * (uint64_t)i) / (uint64_t)parts);
+            while (t < nt && cum[t] < target) ++t;
+            // the tile boundary nearest to the target in cost (cum[t - 1] < target <= cum[t])
+            const uint64_t tb = (t > 0 && target - cum[t - 1] < cum[t] - target) ? t - 1 : t;
+            uint64_t r = tb < nt ? p->h_tile_row[tb] : p->m;
+            r = std::min<uint64_t>(p->m, (r + ((p->row_id_base + r) & 1)));   // even random-stream id: a Philox block stays on one device
+            bounds[i] = std::max<uint64_t>(r, bounds[i - 1]);
+        }
+        bounds[parts] = p->m;
+        return MMG_OK;
+    }
     HIP_TRY(hipSetDevice(p->device));
     std::vector<uint64_t> rp(p->m + 1);
     if (p->idx64) HIP_TRY(hipMemcpy(rp.data(), p->d_row_ptr, (p->m + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
@@ -648,6 +701,173 @@ extern "C" int mmg_problem_shard_bounds(const mmg_problem *p, int parts, uint64_
         for (uint64_t i = 0; i <= p->m; ++i) rp[i] = rp32[i];
     }
     return mmg_shard_bounds(rp.data(), p->m, parts, bounds);
+}
+
+// The cut by MEASURED cost.  Every candidate shard is run as what it will be -- the one-chain sample kernels over ITS interval of the
+// tile lists, in ranges cut the way problem_build_sell cuts a problem of that size -- on the parent's device, with the weights mu
+// (the start values or the EM optimum: which transcripts are popular decides what the count flushes cost), timed with HIP events.
+// Tiles of a shard that ran long get dearer in proportion, the rows are cut again, and so on until the slowest shard is within 2 % of
+// the mean (at most 6 rounds; a round is parts x 7 launches).  What the model cannot know -- what a far entry costs on this part, hit
+// sets that give most of their reads to one transcript -- is in the measurement.  The chain does not depend on the cut (any cut gives
+// the same bits), so a cut that differs from run to run is harmless.
+extern "C" int mmg_problem_shard_bounds_timed(const mmg_problem *p, const double *mu, int parts, uint64_t *bounds)
+{
+    if (!p || !mu || !bounds || parts < 1) return fail(MMG_ERR_ARG, "bad argument");
+    if (parts == 1 || !p->use_sell || p->h_shard_cum.empty() || p->h_shard_cum.back() == 0 || p->h_cum1.size() < 2 || p->resident1 == 0)
+        return mmg_problem_shard_bounds(p, parts, bounds);
+    HIP_TRY(hipSetDevice(p->device));
+    const uint64_t nt = p->h_shard_cum.size() - 1;
+    const bool split = p->h_cumk.size() > 1;                          // a list of multiplicity tiles with a launch of its own
+    const size_t L1 = p->h_cum1.size() - 1, Lk = split ? p->h_cumk.size() - 1 : 0;
+    double *d_mu = nullptr;
+    int32_t *d_cnt = nullptr;
+    std::vector<uint64_t *> d_hdr;                                    // range headers of the round's launches
+    std::vector<hipEvent_t> ev;
+    auto cleanup = [&]() {
+        for (void *x : {(void *)d_mu, (void *)d_cnt}) if (x) (void)hipFree(x);
+        for (uint64_t *h : d_hdr) if (h) (void)hipFree(h);
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        d_hdr.clear(); ev.clear(); d_mu = nullptr; d_cnt = nullptr;
+    };
+#define T_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail(MMG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
+    std::vector<double> mu_int;
+    to_int(p, mu, mu_int);
+    T_TRY(hipMalloc((void **)&d_mu, p->n * sizeof(double)));
+    T_TRY(hipMalloc((void **)&d_cnt, (size_t)CNT_REPLICAS * p->n * sizeof(int32_t)));
+    T_TRY(hipMemcpy(d_mu, mu_int.data(), p->n * sizeof(double), hipMemcpyHostToDevice));
+    T_TRY(hipMemset(d_cnt, 0, (size_t)CNT_REPLICAS * p->n * sizeof(int32_t)));
+    // the tile lists as the device holds them (the range headers carry the first two descriptors of a range)
+    std::vector<SellTile> t1(std::max<size_t>(L1, 1)), tk(std::max<size_t>(Lk, 1));
+    const SellTile *d_t1 = split ? p->d_sell_tiles_1 : p->d_sell_tiles;
+    T_TRY(hipMemcpy(t1.data(), d_t1, L1 * sizeof(SellTile), hipMemcpyDeviceToHost));
+    if (split) T_TRY(hipMemcpy(tk.data(), p->d_sell_tiles_k, Lk * sizeof(SellTile), hipMemcpyDeviceToHost));
+    const int reps = 7;
+    ev.resize((size_t)parts * reps * 2);
+    for (auto &e : ev) { e = nullptr; T_TRY(hipEventCreate(&e)); }
+    // entries [lo, hi) of a list as ranges: what problem_build_sell does for a problem of hi - lo tiles
+    auto ranges_of = [&](const std::vector<uint64_t> &cum, uint64_t lo, uint64_t hi, bool klist, std::vector<uint64_t> &chunk) {
+        const uint64_t n = hi - lo;
+        std::vector<uint64_t> sub(n + 1);
+        for (uint64_t i = 0; i <= n; ++i) sub[i] = cum[lo + i] - cum[lo];
+        const uint64_t res = std::max<uint64_t>(1, std::min<uint64_t>(n, klist ? p->residentk : p->resident1));
+        if (klist) weighted_chunks(sub, std::max<uint64_t>(1, std::min<uint64_t>(n, 4 * res)), chunk);
+        else {
+            const uint64_t g = (n + res * (SELL_TILES_PER_RANGE / 2)) / (res * SELL_TILES_PER_RANGE);
+            const uint64_t grid = std::min<uint64_t>(n, res * std::min<uint64_t>(16, std::max<uint64_t>(1, g)));
+            if (split) weighted_chunks(sub, grid, chunk); else weighted_chunks_tapered(sub, grid, res, chunk);
+        }
+        for (auto &c : chunk) c += lo;
+    };
+    auto first_entry = [&](const std::vector<uint32_t> &list, size_t L, uint64_t tile) -> uint64_t { // first list entry whose tile is >= tile
+        if (list.empty()) return std::min<uint64_t>(tile, L);
+        return (uint64_t)(std::lower_bound(list.begin(), list.end(), (uint32_t)std::min<uint64_t>(tile, 0xffffffffull)) - list.begin());
+    };
+    std::vector<double> cost(nt);
+    for (uint64_t t = 0; t < nt; ++t) cost[t] = (double)(p->h_shard_cum[t + 1] - p->h_shard_cum[t]);
+    std::vector<uint64_t> tb(parts + 1, 0), best_tb;
+    double best_ratio = 1e300;
+    const void *rp = p->d_row_ptr;
+    const uint32_t *ci = p->d_col, *kk = p->d_k;
+    const uint8_t *ss = p->d_sell;
+    const double *mup = d_mu;
+    int32_t *cnt = d_cnt;
+    SampleArgs a;
+    a.seed = 0x5eed; a.row_id_base = p->row_id_base; a.n = p->n; a.chain = 1u << 30; a.iter = 0;
+    a.cnt_rep_stride = p->n; a.cnt_rep_mask = CNT_REPLICAS - 1u;     // (shards have many ranges per band: replicated count vectors)
+    auto launch_part = [&](const uint64_t *hdr1, unsigned g1, const uint64_t *hdrk, unsigned gk) -> hipError_t {
+        hipError_t e = hipSuccess;
+        if (g1) {
+            const SellTile *ts = d_t1;
+            void *kargs[] = {(void *)&rp, (void *)&ci, (void *)&kk, (void *)&ts, (void *)&hdr1, (void *)&mup, (void *)&ss, (void *)&cnt, (void *)&a};
+            e = hipLaunchKernel(k1_sell_kernel(p->idx64, false), dim3(g1), dim3(64), kargs, 0, 0);
+        }
+        if (e == hipSuccess && gk) {
+            const SellTile *ts = p->d_sell_tiles_k;
+            void *kargs[] = {(void *)&rp, (void *)&ci, (void *)&kk, (void *)&ts, (void *)&hdrk, (void *)&mup, (void *)&ss, (void *)&cnt, (void *)&a};
+            e = hipLaunchKernel(k1_sell_kernel(p->idx64, true), dim3(gk), dim3(64), kargs, 0, 0);
+        }
+        return e;
+    };
+    for (int round = 0; round < 6; ++round) {
+        // cut the tiles by the current cost
+        double total = 0.0;
+        for (double c : cost) total += c;
+        {
+            uint64_t t = 0;
+            double run = 0.0;
+            for (int i = 1; i < parts; ++i) {
+                const double target = total * (double)i / (double)parts;
+                while (t < nt && run + cost[t] <= target) run += cost[t++];
+                tb[i] = std::max<uint64_t>(t, tb[i - 1]);
+            }
+            tb[parts] = nt;
+        }
+        // the launches of every part
+        for (uint64_t *h : d_hdr) if (h) (void)hipFree(h);
+        d_hdr.assign((size_t)parts * 2, nullptr);
+        std::vector<unsigned> g1(parts, 0), gk(parts, 0);
+        for (int i = 0; i < parts; ++i) {
+            std::vector<uint64_t> chunk;
+            const uint64_t lo1 = first_entry(p->h_list1_tile, L1, tb[i]), hi1 = first_entry(p->h_list1_tile, L1, tb[i + 1]);
+            if (hi1 > lo1) { ranges_of(p->h_cum1, lo1, hi1, false, chunk); T_TRY(upload_ranges(chunk, t1, &d_hdr[2 * i])); g1[i] = (unsigned)(chunk.size() - 1); }
+            if (split) {
+                const uint64_t lok = first_entry(p->h_listk_tile, Lk, tb[i]), hik = first_entry(p->h_listk_tile, Lk, tb[i + 1]);
+                if (hik > lok) { ranges_of(p->h_cumk, lok, hik, true, chunk); T_TRY(upload_ranges(chunk, tk, &d_hdr[2 * i + 1])); gk[i] = (unsigned)(chunk.size() - 1); }
+            }
+        }
+        if (round == 0) { // clocks up: the whole problem for about 50 ms
+            for (int w = 0; w < 4; ++w) for (int i = 0; i < parts; ++i) { a.iter++; T_TRY(launch_part(d_hdr[2 * i], g1[i], d_hdr[2 * i + 1], gk[i])); }
+            T_TRY(hipDeviceSynchronize());
+            hipEvent_t &e0 = ev[0], &e1 = ev[1];
+            T_TRY(hipEventRecord(e0, 0));
+            for (int i = 0; i < parts; ++i) { a.iter++; T_TRY(launch_part(d_hdr[2 * i], g1[i], d_hdr[2 * i + 1], gk[i])); }
+            T_TRY(hipEventRecord(e1, 0));
+            T_TRY(hipEventSynchronize(e1));
+            float ms = 0.f;
+            T_TRY(hipEventElapsedTime(&ms, e0, e1));
+            const int more = ms > 0.f ? std::min(2000, (int)(50.0f / ms)) : 0;
+            for (int w = 0; w < more; ++w) for (int i = 0; i < parts; ++i) { a.iter++; T_TRY(launch_part(d_hdr[2 * i], g1[i], d_hdr[2 * i + 1], gk[i])); }
+        }
+        for (int r = 0; r < reps; ++r)
+            for (int i = 0; i < parts; ++i) {
+                a.iter++;
+                T_TRY(hipEventRecord(ev[((size_t)r * parts + i) * 2], 0));
+                T_TRY(launch_part(d_hdr[2 * i], g1[i], d_hdr[2 * i + 1], gk[i]));
+                T_TRY(hipEventRecord(ev[((size_t)r * parts + i) * 2 + 1], 0));
+            }
+        T_TRY(hipDeviceSynchronize());
+        std::vector<double> T(parts);
+        double mean = 0.0, worst = 0.0;
+        for (int i = 0; i < parts; ++i) {
+            std::vector<float> v(reps);
+            for (int r = 0; r < reps; ++r) T_TRY(hipEventElapsedTime(&v[r], ev[((size_t)r * parts + i) * 2], ev[((size_t)r * parts + i) * 2 + 1]));
+            std::sort(v.begin(), v.end());
+            T[i] = v[reps / 2];
+            mean += T[i] / parts;
+            worst = std::max(worst, T[i]);
+        }
+        const double ratio = mean > 0.0 ? worst / mean : 1.0;
+        if (ratio < best_ratio) { best_ratio = ratio; best_tb = tb; }
+        if (ratio <= 1.02 || !(mean > 0.0)) break;
+        // tiles of a part that ran long get dearer: the part's cost becomes proportional to its time
+        for (int i = 0; i < parts; ++i) {
+            double sum = 0.0;
+            for (uint64_t t = tb[i]; t < tb[i + 1]; ++t) sum += cost[t];
+            if (!(sum > 0.0)) continue;
+            const double f = T[i] * total / (mean * parts) / sum;
+            for (uint64_t t = tb[i]; t < tb[i + 1]; ++t) cost[t] *= f;
+        }
+    }
+    cleanup();
+#undef T_TRY
+    bounds[0] = 0;
+    for (int i = 1; i < parts; ++i) {
+        uint64_t r = best_tb[i] < nt ? p->h_tile_row[best_tb[i]] : p->m;
+        r = std::min<uint64_t>(p->m, (r + ((p->row_id_base + r) & 1)));
+        bounds[i] = std::max<uint64_t>(r, bounds[i - 1]);
+    }
+    bounds[parts] = p->m;
+    return MMG_OK;
 }
 
 extern "C" int mmg_problem_create_synthetic(const mmg_synth_desc *d, int device, mmg_problem **out)

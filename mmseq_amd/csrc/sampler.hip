@@ -67,7 +67,7 @@ extern "C" int mmg_sampler_create(const mmg_problem *p, const mmg_config *cfg, c
     S_TRY(hipMalloc((void **)&s->d_mu, C * n * sizeof(double)));
     S_TRY(hipMalloc((void **)&s->d_scale, n * sizeof(double)));
     S_TRY(hipMalloc((void **)&s->d_mom, 2 * C * n * sizeof(double)));
-    S_TRY(hipMalloc((void **)&s->d_cnt, C * n * sizeof(int32_t)));
+    S_TRY(hipMalloc((void **)&s->d_cnt, p->cnt_replicas * C * n * sizeof(int32_t))); // [replicas][C][n]; replica 0 is the public vector
     S_TRY(hipMalloc((void **)&s->d_cnt_last, C * n * sizeof(int32_t)));
     if (cfg->keep_trace) S_TRY(hipMalloc((void **)&s->d_trace, C * n * (size_t)cfg->trace_len * sizeof(double)));
     std::vector<double> scale_ext(n), scale, mu_int;
@@ -78,7 +78,7 @@ extern "C" int mmg_sampler_create(const mmg_problem *p, const mmg_config *cfg, c
     S_TRY(hipMemcpyAsync(s->d_scale, scale.data(), n * sizeof(double), hipMemcpyHostToDevice, s->own));
     for (size_t c = 0; c < C; ++c) S_TRY(hipMemcpyAsync(s->d_mu + c * n, mu_int.data(), n * sizeof(double), hipMemcpyHostToDevice, s->own));
     S_TRY(hipMemsetAsync(s->d_mom, 0, 2 * C * n * sizeof(double), s->own));
-    S_TRY(hipMemsetAsync(s->d_cnt, 0, C * n * sizeof(int32_t), s->own));
+    S_TRY(hipMemsetAsync(s->d_cnt, 0, p->cnt_replicas * C * n * sizeof(int32_t), s->own));
     S_TRY(hipMemsetAsync(s->d_cnt_last, 0, C * n * sizeof(int32_t), s->own));
     if (s->d_trace) S_TRY(hipMemsetAsync(s->d_trace, 0, C * n * (size_t)cfg->trace_len * sizeof(double), s->own));
     S_TRY(hipStreamSynchronize(s->own));
@@ -105,7 +105,9 @@ static int ev_get(mmg_sampler *s, int &idx)
     return MMG_OK;
 }
 
-extern "C" int mmg_sampler_sample(mmg_sampler *s)
+// K1 for every chain of the sampler.  fold: leave the device's column sums in the public count vector (replica 0) -- what a caller
+// that exchanges counts between sample and update needs; mmg_sampler_run skips it (K2 sums the replicas itself).
+static int sampler_sample(mmg_sampler *s, bool fold)
 {
     if (!s) return fail(MMG_ERR_ARG, "NULL sampler");
     if (s->sampled) return fail(MMG_ERR_STATE, "sample() already issued for this iteration; call update()");
@@ -123,6 +125,8 @@ extern "C" int mmg_sampler_sample(mmg_sampler *s)
         auto args_of = [&](int c) {
             SampleArgs a;
             a.seed = s->cfg.seed; a.row_id_base = p->row_id_base; a.n = p->n;
+            a.cnt_rep_stride = (uint64_t)C * p->n;
+            a.cnt_rep_mask = p->cnt_replicas - 1u;
             a.chain = (uint32_t)(s->cfg.chain_base + c);
             a.iter = (uint32_t)s->iter;
             return a;
@@ -195,9 +199,15 @@ extern "C" int mmg_sampler_sample(mmg_sampler *s)
         HIP_TRY(hipEventRecord(s->ev_pool[e1], s->cur));
         s->ev_sample.push_back({e0, e1});
     }
+    if (fold && p->m > 0 && p->cnt_replicas > 1) {
+        launch_fold_counts(s->d_cnt, (uint64_t)s->cfg.n_chains * p->n, (size_t)s->cfg.n_chains * p->n, s->cur);
+        HIP_TRY(hipGetLastError());
+    }
     s->sampled = true;
     return MMG_OK;
 }
+
+extern "C" int mmg_sampler_sample(mmg_sampler *s) { return sampler_sample(s, true); }
 
 extern "C" int mmg_sampler_update(mmg_sampler *s)
 {
@@ -214,6 +224,8 @@ extern "C" int mmg_sampler_update(mmg_sampler *s)
     a.sum_log = s->d_mom; a.sum_log2 = s->d_mom + C * n;
     a.ext_of_int = p->d_ext_of_int;
     a.seed = s->cfg.seed; a.alpha = s->cfg.alpha; a.n = p->n; a.n_chains = (uint32_t)C;
+    a.cnt_rep_stride = (uint64_t)C * n;
+    a.cnt_replicas = p->cnt_replicas;
     a.chain_base = (uint32_t)s->cfg.chain_base; a.iter = (uint32_t)s->iter; a.sample_idx = sample_idx;
     a.trace_len = (uint32_t)s->cfg.trace_len;
     int e0 = -1, e1 = -1;
@@ -239,12 +251,48 @@ extern "C" int mmg_sampler_run(mmg_sampler *s, int n_iter)
 {
     if (!s || n_iter < 0) return fail(MMG_ERR_ARG, "bad argument");
     for (int i = 0; i < n_iter; ++i) {
-        int rc = mmg_sampler_sample(s);
+        int rc = sampler_sample(s, false);
         if (rc) return rc;
         rc = mmg_sampler_update(s);
         if (rc) return rc;
     }
     return MMG_OK;
+}
+
+// The sharded chain of mmg_group_run_sharded with every shard on ONE device: per iteration K1 on every shard, the count vectors summed
+// by a plain kernel where the group runs ncclAllReduce(int32, sum), the identical K2 everywhere.  Everything is enqueued on the first
+// sampler's stream, so kernels and exchange stay ordered without host synchronisation.
+extern "C" int mmg_selftest_gibbs_shards(mmg_sampler *const *samplers, int n_shards, int n_iter)
+{
+    if (!samplers || n_shards < 1 || n_iter < 0) return fail(MMG_ERR_ARG, "bad argument");
+    for (int i = 0; i < n_shards; ++i) {
+        const mmg_sampler *s = samplers[i], *z = samplers[0];
+        if (!s) return fail(MMG_ERR_ARG, "NULL sampler");
+        if (s->device != z->device) return fail(MMG_ERR_ARG, "the self test runs its shards on one device");
+        if (s->p->n != z->p->n || s->cfg.n_chains != z->cfg.n_chains || s->cfg.seed != z->cfg.seed || s->cfg.chain_base != z->cfg.chain_base ||
+            s->iter != z->iter || s->cfg.gibbs_iter != z->cfg.gibbs_iter || s->cfg.trace_len != z->cfg.trace_len || s->sampled)
+            return fail(MMG_ERR_ARG, "read shards of one chain need the same transcripts, chains, seed, chain_base, iteration, gibbs_iter and trace_len");
+    }
+    HIP_TRY(hipSetDevice(samplers[0]->device));
+    std::vector<hipStream_t> saved(n_shards);
+    for (int i = 0; i < n_shards; ++i) { HIP_TRY(hipStreamSynchronize(samplers[i]->cur)); saved[i] = samplers[i]->cur; samplers[i]->cur = samplers[0]->cur; }
+    const hipStream_t st = samplers[0]->cur;
+    const size_t count = (size_t)samplers[0]->cfg.n_chains * samplers[0]->p->n;
+    int rc = MMG_OK;
+    for (int it = 0; it < n_iter && rc == MMG_OK; ++it) {
+        for (int i = 0; i < n_shards && rc == MMG_OK; ++i) rc = mmg_sampler_sample(samplers[i]);             // src/mmseq.cpp:857-891 on the shard's rows
+        for (int i = 1; i < n_shards && rc == MMG_OK; ++i) {                                                  // :896-899 across shards
+            launch_add_i32(samplers[0]->d_cnt, samplers[i]->d_cnt, count, st);
+            if (hipGetLastError() != hipSuccess) rc = fail(MMG_ERR_HIP, "count exchange");
+        }
+        for (int i = 1; i < n_shards && rc == MMG_OK; ++i)
+            if (hipMemcpyAsync(samplers[i]->d_cnt, samplers[0]->d_cnt, count * sizeof(int32_t), hipMemcpyDeviceToDevice, st) != hipSuccess) rc = fail(MMG_ERR_HIP, "count exchange");
+        for (int i = 0; i < n_shards && rc == MMG_OK; ++i) rc = mmg_sampler_update(samplers[i]);             // :905-917, identical everywhere
+    }
+    const hipError_t e = hipStreamSynchronize(st);
+    for (int i = 0; i < n_shards; ++i) samplers[i]->cur = saved[i];
+    if (rc == MMG_OK && e != hipSuccess) rc = fail(MMG_ERR_HIP, std::string("gibbs shards: ") + hipGetErrorString(e));
+    return rc;
 }
 
 extern "C" int mmg_sampler_counts_devptr(mmg_sampler *s, void **ptr, uint64_t *count)

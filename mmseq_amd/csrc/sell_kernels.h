@@ -182,7 +182,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
     // grid.y = chain: the tile lists that only some rows are on (multiplicities, far rows) are walked for every chain of a sampler
     // in one launch -- their launches are bound by a few long rows, eight of them side by side fill the GPU eight times better
     gmu += (size_t)blockIdx.y * a.n;
-    gcnt += (size_t)blockIdx.y * a.n;
+    gcnt += (size_t)blockIdx.y * a.n + (size_t)(blockIdx.x & a.cnt_rep_mask) * a.cnt_rep_stride; // (mmg_types.h: CNT_REPLICAS)
     a.chain += blockIdx.y;
 
     // the range's header (mmgibbs.hip: upload_ranges): first tile, end tile, the descriptors of its first two tiles -- one scalar load

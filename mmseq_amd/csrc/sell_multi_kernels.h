@@ -28,7 +28,7 @@ __global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict
     // grid.y = group of NCH chains: one launch advances all the fused chains of a sampler (the tail of one group overlaps the head of
     // the next instead of a launch boundary)
     gmu += (size_t)blockIdx.y * NCH * a.n;
-    gcnt += (size_t)blockIdx.y * NCH * a.n;
+    gcnt += (size_t)blockIdx.y * NCH * a.n + (size_t)(blockIdx.x & a.cnt_rep_mask) * a.cnt_rep_stride; // (mmg_types.h: CNT_REPLICAS)
     a.chain += blockIdx.y * (uint32_t)NCH;
 
     // the range's header (mmgibbs.hip: upload_ranges): first tile, end tile, the descriptors of its first two tiles -- one scalar load

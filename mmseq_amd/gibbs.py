@@ -86,6 +86,14 @@ class Problem:
         check(self._lib.mmg_problem_shard_bounds(self._h, int(parts), _ptr(b)))
         return b
 
+    def shard_bounds_timed(self, mu, parts):
+        """mmg_problem_shard_bounds_timed: the cut by measured cost (profiling sweeps with the weights mu)."""
+        mu = np.ascontiguousarray(mu, np.float64)
+        assert mu.size == self.info.n
+        b = np.empty(parts + 1, np.uint64)
+        check(self._lib.mmg_problem_shard_bounds_timed(self._h, _ptr(mu), int(parts), _ptr(b)))
+        return b
+
     def tx_perm(self):
         out = np.empty(self.info.n, np.uint32)
         check(self._lib.mmg_problem_tx_perm(self._h, _ptr(out)))
@@ -427,6 +435,13 @@ def em_shards_selftest(shards, mu0, sweeps):
     return mu, ll.value, rep.value
 
 
+def gibbs_shards_selftest(samplers, n_iter):
+    """mmg_selftest_gibbs_shards: the sharded chain of mmg_group_run_sharded with all shards on one device (count exchange by a
+    kernel); every sampler ends up holding the chain of the unsharded problem."""
+    arr = (C.c_void_p * len(samplers))(*[s._h for s in samplers])
+    check(_lib.load().mmg_selftest_gibbs_shards(arr, len(samplers), int(n_iter)))
+
+
 # ---- self-test hooks -----------------------------------------------------------------------
 def selftest_option(option, value):
     """Process-wide override of a choice the library normally makes itself (tests only); value < 0 restores the default."""
@@ -434,7 +449,7 @@ def selftest_option(option, value):
 
 
 OPT = dict(sample_kernel=_lib.OPT_SAMPLE_KERNEL, force_idx64=_lib.OPT_FORCE_IDX64, sell_waves_per_cu=_lib.OPT_SELL_WAVES_PER_CU,
-           em_kernel=_lib.OPT_EM_KERNEL, em_grid=_lib.OPT_EM_GRID, fuse_chains=_lib.OPT_FUSE_CHAINS)
+           em_kernel=_lib.OPT_EM_KERNEL, em_grid=_lib.OPT_EM_GRID, fuse_chains=_lib.OPT_FUSE_CHAINS, cnt_replicas=_lib.OPT_CNT_REPLICAS)
 
 
 class options:

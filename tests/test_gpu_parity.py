@@ -388,6 +388,117 @@ def test_shards_of_a_stored_problem_with_far_rows_and_tx_order(gpu, orc):
     assert np.array_equal(parts[0] + parts[1], whole) and nz > 0
 
 
+@pytest.mark.parametrize("parts", [2, 3, 8])
+def test_sharded_chain_on_one_device_equals_the_unsharded_chain(gpu, orc, parts):
+    """mmg_group_run_sharded's arithmetic on one device (mmg_selftest_gibbs_shards: the int32 count exchange done by a kernel instead of
+    RCCL): the stored rows of a problem with far rows, multiplicities of every class and a transcript order, cut where the LIBRARY cuts
+    (mmg_problem_shard_bounds, by modelled cost) with mmg_problem_shard -- trace, counts and mu of every shard's sampler equal the
+    unsharded chain's and the oracle's bit for bit (src/mmseq.cpp:864, :893-899: the reference's split of the rows and its reduction)."""
+    rng = np.random.default_rng(70 + parts)
+    p, _ = orc.synth_problem(R=60000, T=9000, avg_hits=7, seed=13, sort=False, far_fraction=0.25)
+    k = rng.choice([1, 1, 1, 1, 2, 5, 70, 300], size=p.m).astype(np.uint32)
+    scat = rng.permutation(p.n).astype(np.uint32)              # the caller numbers the transcripts at random; tx_order restores locality
+    l_ext = np.empty(p.n); l_ext[scat] = p.l
+    tx_order = np.empty(p.n, np.uint64); tx_order[scat] = np.arange(p.n, dtype=np.uint64)
+    prob = gpu.Problem.from_csr(p.row_ptr, scat[p.col_idx], l_ext, k=k, tx_order=tx_order)
+    assert prob.info.far_tiles > 0 and prob.info.sample_kernel == 2
+    rp, ci, kk = prob.download(with_k=True)
+    ps = orc.Problem(rp, ci, l_ext, k=kk)
+    mu0 = rng.gamma(0.7, 1.0, size=p.n)
+    iters = 6
+    ref = orc.gibbs_keyed(ps, mu0, seed=21, n_iter=iters, trace_len=iters)
+    whole = gpu.Sampler(prob, mu0, seed=21, gibbs_iter=iters, trace_len=iters)
+    whole.run(iters)
+    assert np.array_equal(whole.trace(0), ref["trace"]) and np.array_equal(whole.counts(0), ref["cnt"])
+    b = prob.shard_bounds(parts) if parts != 3 else prob.shard_bounds_timed(mu0, parts)   # modelled cost / measured cost: same bits wherever the cut
+    assert b[0] == 0 and b[-1] == prob.info.m and np.all(np.diff(b.astype(np.int64)) > 0) and np.all(b[:-1] % 2 == 0)
+    shards = [prob.shard(int(b[i]), int(b[i + 1])) for i in range(parts)]
+    assert sum(sh.info.total_k for sh in shards) == prob.info.total_k
+    assert all(sh.info.sample_kernel == 2 for sh in shards)      # a shard of a canonical problem stays on the stream kernel
+    smps = [gpu.Sampler(sh, mu0, seed=21, gibbs_iter=iters, trace_len=iters, keep_trace=(i in (0, parts - 1))) for i, sh in enumerate(shards)]
+    gpu.gibbs_shards_selftest(smps, 2)
+    gpu.gibbs_shards_selftest(smps, iters - 2)                    # the call may be repeated: the chain continues
+    for i in (0, parts - 1):
+        assert np.array_equal(smps[i].trace(0), ref["trace"])
+    for sm in smps:
+        assert sm.iteration == iters
+        assert np.array_equal(sm.counts(0), ref["cnt"]) and np.array_equal(sm.mu(0), ref["mu"])
+    with pytest.raises(gpu._lib.MMGError):                        # samplers that disagree on the iteration are refused
+        smps[0].run(1)
+        gpu.gibbs_shards_selftest(smps, 1)
+    for sm in smps:
+        sm.close()
+    for sh in shards:
+        sh.close()
+    whole.close(); prob.close()
+
+
+@pytest.mark.parametrize("kernel", [2, 0])
+def test_replicated_count_vectors_give_the_same_bits(gpu, orc, kernel):
+    """K1's workgroups flush their LDS counts into one of CNT_REPLICAS global vectors (workgroup index mod 8: neighbouring ranges meet at
+    different addresses) when many ranges share a band, and K2 sums them -- integer sums: the chain, the counts between sample and
+    update (folded into the public vector by mmg_sampler_sample) and the fused chains are the same bits with 1 and with 8 vectors."""
+    rng = np.random.default_rng(12)
+    p, _ = orc.synth_problem(R=50000, T=7000, avg_hits=6, seed=77, sort=False, far_fraction=0.1)
+    k = rng.choice([1, 1, 1, 3, 90], size=p.m).astype(np.uint32)
+    mu0 = rng.gamma(0.6, 1.0, size=p.n)
+    out = {}
+    for reps in (1, 8):
+        with gpu.options(cnt_replicas=reps, sample_kernel=kernel):
+            prob = gpu.Problem.from_csr(p.row_ptr, p.col_idx, p.l, k=k)
+            assert prob.info.sample_kernel == kernel
+            s = gpu.Sampler(prob, mu0, seed=5, n_chains=3, gibbs_iter=4, trace_len=4)
+            s.run(2)
+            s.sample()
+            mid = [s.counts(c) for c in range(3)]
+            s.update()
+            s.run(1)
+            out[reps] = (mid, [s.trace(c) for c in range(3)], [s.counts(c) for c in range(3)])
+            if reps == 8:
+                rp, ci, kk = prob.download(with_k=True)
+                ref = orc.gibbs_keyed(orc.Problem(rp, ci, p.l, k=kk), mu0, seed=5, chain=1, n_iter=4, trace_len=4)
+                assert np.array_equal(out[8][1][1], ref["trace"]) and np.array_equal(out[8][2][1], ref["cnt"])
+            s.close(); prob.close()
+    for a, b in zip(out[1], out[8]):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    assert int(out[8][0][0].astype(np.int64).sum()) == int(k.astype(np.int64).sum())
+
+
+def test_shard_bounds_balance_modelled_cost_not_hits(gpu, orc):
+    """The canonical order stores every far row behind every near row, and a far tile costs about three register-path tiles: the
+    library's cut (mmg_problem_shard_bounds) gives the shards that hold the far rows FEWER hits, where equal hit counts
+    (mmg_shard_bounds; the reference's static split of the rows, src/mmseq.cpp:864) would make them the slowest devices."""
+    p, _ = orc.synth_problem(R=200000, T=12000, avg_hits=8, seed=5, sort=False, far_fraction=0.2)
+    prob = gpu.Problem.from_csr(p.row_ptr, p.col_idx, p.l)
+    inf = prob.info
+    assert inf.sample_kernel == 2 and inf.far_tiles > 0
+    rp, _ = prob.download()
+    parts = 8
+    b = prob.shard_bounds(parts)
+    hits = np.diff(rp[b.astype(np.int64)].astype(np.int64))
+    by_hits = gpu.shard_bounds(rp, parts)
+    assert np.all(np.diff(by_hits.astype(np.int64)) > 0)
+    # the last shard is all far rows: markedly fewer hits than the first (all near rows)
+    assert hits[-1] < 0.6 * hits[0], hits
+    # near-only shards among themselves: equal cost = (nearly) equal hits
+    near_only = hits[:2]
+    assert near_only.max() <= 1.08 * near_only.min(), hits
+    # the measured cut sees the same thing
+    mu0, _ = prob.start_values()
+    bt = prob.shard_bounds_timed(mu0, parts)
+    ht = np.diff(rp[bt.astype(np.int64)].astype(np.int64))
+    assert bt[0] == 0 and bt[-1] == inf.m and np.all(np.diff(bt.astype(np.int64)) > 0) and np.all(bt[:-1] % 2 == 0)
+    assert ht[-1] < 0.75 * ht[0], ht
+    # a problem without far rows: the cost cut and the hit cut agree to within a tile's rounding
+    q, _ = orc.synth_problem(R=200000, T=12000, avg_hits=8, seed=5, sort=False)
+    pq = gpu.Problem.from_csr(q.row_ptr, q.col_idx, q.l)
+    rq, _ = pq.download()
+    hq = np.diff(rq[pq.shard_bounds(parts).astype(np.int64)].astype(np.int64))
+    assert hq.max() <= 1.10 * hq.min(), hq                       # (bands end in partly filled tiles, and a tile costs the same full or not)
+    pq.close(); prob.close()
+
+
 @pytest.mark.parametrize("parts,wild", [(2, False), (3, True), (8, False)])
 def test_em_over_read_shards_equals_the_unsharded_em(gpu, orc, parts, wild):
     """mmg_group_em_create's arithmetic on one device (mmg_selftest_em_shards: the exchange done by kernels instead of RCCL): the
@@ -424,7 +535,8 @@ def test_em_over_read_shards_equals_the_unsharded_em(gpu, orc, parts, wild):
             shards.append(sh)
         else:
             shards.append(gpu.Problem.from_csr(rp[lo:hi + 1] - rp[lo], ci[a:e], prob.l(), k=kk[lo:hi], row_id_base=lo, keep_rows=True))
-    assert np.array_equal(prob.shard_bounds(parts), b)
+    pb = prob.shard_bounds(parts)                # the library's own cut balances modelled cost, not hits (below): any cut gives the same bits
+    assert pb[0] == 0 and pb[-1] == prob.info.m and np.all(np.diff(pb.astype(np.int64)) >= 0) and np.all(pb[:-1] % 2 == 0)
     mu, ll, rep = gpu.em_shards_selftest(shards, mu0, sweeps)
     # the Gibbs counts of the shards add up to the unsharded sweep's
     s = gpu.Sampler(prob, mu0 + 1e-3, seed=3, gibbs_iter=1, trace_len=1)
