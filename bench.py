@@ -163,7 +163,7 @@ def cpu_baseline(args, prob, mu0):
 
 
 def side_measurement(name, rows, transcripts, avg_hits, chains=1, uniform=False, sort=True, far_fraction=0.0, steps=48, warmup=8,
-                     seed=1234, device=0, note="", multiplicities=False):
+                     seed=1234, device=0, note="", multiplicities=False, scatter=False):
     """One more workload, same protocol (inputs resident, HIP events on the launch stream), shorter: ms per sweep and which kernel ran.
     multiplicities: the rows get a k array with the distribution a collapsed 50 M-read file of this generator has (93.6 % k = 1,
     5.3 % k = 2, ... 0.12 % k in 9..36: tools/collapse_probe.py) -- what every real hits file produces (src/mmseq.cpp:409-418)."""
@@ -174,6 +174,19 @@ def side_measurement(name, rows, transcripts, avg_hits, chains=1, uniform=False,
     t0 = time.perf_counter()
     prob = Problem.synthetic(rows, transcripts, avg_hits, seed=seed, uniform=uniform, sort=sort, far_fraction=far_fraction,
                              mapped_reads=rows, device=device)
+    if scatter:
+        # the reference's first-seen numbering (src/mmseq.cpp:399-408): the transcripts get random ids, the rows come in generator order,
+        # and NO tx_order is passed -- the library has to find the locality itself (spec version 6: an order derived from the hit graph)
+        rp, ci = prob.download()
+        l = prob.l()
+        prob.close()
+        perm = np.random.default_rng(seed).permutation(transcripts).astype(np.uint32)
+        l_ext = np.empty_like(l)
+        l_ext[perm] = l
+        t1 = time.perf_counter()
+        prob = Problem.from_csr(rp, perm[ci], l_ext, device=device)
+        scatter_create_s = time.perf_counter() - t1
+        del rp, ci
     if multiplicities:
         rp, ci = prob.download()
         l = prob.l()
@@ -230,6 +243,9 @@ def side_measurement(name, rows, transcripts, avg_hits, chains=1, uniform=False,
            "far_tiles": (inf.far_tiles / inf.n_tiles) if inf.sample_kernel == 2 and inf.n_tiles else 0.0,
            "stream_bytes": inf.stream_bytes, "n_tiles": inf.n_tiles, "alg_bytes": b_sweep, "alg_frac": b_sweep / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "build_s": round(build_s, 2)}
+    if scatter:
+        out["tx_renumbered"] = inf.tx_renumbered
+        out["create_s"] = round(scatter_create_s, 2)
     smp.close()
     prob.close()
     return out
@@ -268,6 +284,8 @@ SIDE = [
     ("far20", "50M x 200k, 20 % of the rows with a hit anywhere", dict(rows=R3, transcripts=T3, avg_hits=H3, far_fraction=0.2, steps=24)),
     ("uniform", "50M x 200k, hits uniform over all transcripts (SURVEY App. D worst case)", dict(rows=R3, transcripts=T3, avg_hits=H3, uniform=True, steps=8, warmup=2)),
     ("keeprows", "50M x 200k, rows kept in generator order (MMG_LAYOUT_KEEP_ROWS)", dict(rows=R3, transcripts=T3, avg_hits=H3, sort=False, steps=8, warmup=2)),
+    ("scatter", "50M x 200k, transcripts numbered at random (first-seen numbering), rows in generator order, NO tx_order: order derived from the hit graph",
+     dict(rows=R3, transcripts=T3, avg_hits=H3, sort=False, scatter=True, steps=32)),
 ]
 
 
@@ -514,8 +532,10 @@ def main():
             roof["far20_ms"] = g("far20", "ms_per_step")
             roof["uniform_ms"] = g("uniform", "ms_per_step")
             roof["keeprows_ms"] = g("keeprows", "ms_per_step")
+            roof["scatter_no_tx_order_ms"] = g("scatter", "ms_per_step")
             roof["algorithmic_x_peak"] = full_roof["algorithmic_x_peak"]
-            keep = ("id", "chains", "ms_per_step", "chain_it_s", "k1_ms_all_chains", "k2_ms", "kernel", "alg_frac", "far_tiles", "total_k", "error", "ms_per_sweep")
+            keep = ("id", "chains", "ms_per_step", "chain_it_s", "k1_ms_all_chains", "k2_ms", "kernel", "alg_frac", "far_tiles", "total_k", "error", "ms_per_sweep",
+                    "tx_renumbered", "create_s")
             roof["configs"] = [compact({k: v for k, v in r.items() if k in keep}) for r in side.values()]
             roof["other"] = {k: compact(v, drop=("pmc_source", "pattern_read_peak_gbs", "peak", "unit", "timed_launches", "hbm_counter_frac")) for k, v in other.items()}
             record["side"] = side

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MMG_ABI_VERSION 5
+#define MMG_ABI_VERSION 6
 /* Version history of the SPEC behind the entry points: under one version a chain is a pure function of (problem, tx_order, seed,
  * chain, iteration); a bump means the same inputs may yield different bits (golden fixtures and the oracle move with it).
  *   3  (round 2) rows with 2 <= k <= 64 draw k categoricals (before: k <= 8), sorted by k inside their class.  The constant moved
@@ -41,7 +41,17 @@ extern "C" {
  *      steps whatever k (measured: 2 M rows of 20 hits with k = 65 in 0.32 instead of 1.9 ms per sweep, with k = 300 in 1.46 instead of
  *      2.0).  Rows above MMG_K_SMALL are
  *      ordered by a logarithmic bucket of k inside their class (a tile loops to its largest k).  Chains of problems with
- *      MMG_K_SMALL < k <= MMG_K_DRAWS_PER_HIT * (hits - 1) rows differ from version 4 (the golden chain has such rows: regenerated). */
+ *      MMG_K_SMALL < k <= MMG_K_DRAWS_PER_HIT * (hits - 1) rows differ from version 4.  The committed golden chain
+ *      (tests/golden/keyed_chain_tiny.json) has no such row and is byte for byte what it was; keyed_chain_k_draws.json was added for
+ *      the new range.  Also version 4/5 (recorded late): a row with 2 <= k <= MMG_K_SMALL stored as k rows changes
+ *      mmg_problem_info.m / mmg_problem_download (the STORED problem), the low bits of mmg_problem_start_values (k terms
+ *      floor(2^52 / hits) instead of floor(k 2^52 / hits)) and of EM sweeps (k terms 1/d instead of one term k/d) of such problems.
+ *   6  (round 4) a canonical problem WITHOUT tx_order whose rows do not fit LDS windows in the caller's numbering (modelled cost more
+ *      than 1.25 x that of register-path tiles alone) gets a transcript order derived from the hit graph (order.hip; a pure function
+ *      of the set of rows and the caller's numbering) when the model prices the result a fifth lower: stored order, and with it the
+ *      chain, of exactly those problems differ from version 5 (they ran the CSR-tile kernel at 1/29 of the speed).  Problems with
+ *      tx_order, kept rows, or locality in the caller's numbering are untouched.  New entry points: mmg_problem_shard_bounds_timed,
+ *      mmg_selftest_gibbs_shards; mmg_problem_shard_bounds cuts by modelled cost instead of hits (any cut gives the same chain). */
 /* Layout.  The model does not care about the order of rows or the numbering of transcripts (src/mmseq.cpp:399-418 uses
  * first-seen order for both); the kernels do: they keep a window of consecutive transcripts in LDS and want the 64 rows of a
  * wave to have equal lengths.  mmg_problem_create therefore stores the rows in a CANONICAL order of its own (sorted on the
@@ -88,7 +98,10 @@ typedef struct mmg_problem_desc {
                                 (key, index).  A caller that knows which transcripts share reads (the
                                 isoforms of a gene, src/mmseq.cpp:358) passes gene_ordinal << 32 | ordinal
                                 within the gene, so that a read's hits are neighbours.  NULL: the caller's
-                                numbering is the device numbering                         */
+                                numbering is the device numbering -- unless the rows do not fit LDS windows in it
+                                (first-seen numbering, src/mmseq.cpp:399-408) and the layout is canonical: the library
+                                then derives an order from the hit graph, a pure function of the set of rows
+                                (spec version 6), and uses it like a caller's                 */
 } mmg_problem_desc;
 
 /* Synthetic problem generated directly into device CSR (no reference counterpart; the
@@ -122,7 +135,7 @@ typedef struct mmg_problem_info {
                               (n_tiles - fast - far - empty) are walked from the CSR                         */
     uint64_t padded_slots; /* hit slots of the sliced-ELL stream incl. padding (>= nnz of the fast tiles) */
     int32_t layout;        /* MMG_LAYOUT_* in force                                       */
-    int32_t tx_renumbered; /* 1: tx_order was given                                       */
+    int32_t tx_renumbered; /* 1: tx_order was given; 2: the library derived an order from the hit graph */
     int32_t sample_grid;   /* workgroups of the sample kernel: the resident count (waves the runtime reports x CUs) times the
                               number of generations (1..16: tile ranges of about 24 tiles once the problem is large) */
     int32_t cu_count;
@@ -331,7 +344,9 @@ enum {
     MMG_OPT_EM_GRID = 4,           /* cap on the EM kernel's grid                                                    */
     MMG_OPT_FUSE_CHAINS = 5,       /* chains advanced per K1 launch: 1 (never fuse), 2 (the default), 4              */
     MMG_OPT_CNT_REPLICAS = 6,      /* 1: one global count vector per chain, 8: replicated (default: by ranges per band) */
-    MMG_OPT_COUNT_ = 7
+    MMG_OPT_GROUP_FAIL = 7,        /* v >= 0: member v % size of a group fails in its second iteration of the next run call (error path) */
+    MMG_OPT_DERIVE_ORDER = 8,      /* 0: never derive a transcript order from the hit graph, 1: try it on every canonical problem without tx_order */
+    MMG_OPT_COUNT_ = 9
 };
 int mmg_selftest_option(int option, int value);
 /* The sharded EM of mmg_group_em_create with every shard on ONE device and the exchange done by plain kernels: `sweeps` sweeps from

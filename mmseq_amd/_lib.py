@@ -20,7 +20,7 @@ class MMGError(RuntimeError):
 
 LAYOUT_CANONICAL, LAYOUT_KEEP_ROWS = 0, 1
 # mmg_selftest_option ids
-OPT_SAMPLE_KERNEL, OPT_FORCE_IDX64, OPT_SELL_WAVES_PER_CU, OPT_EM_KERNEL, OPT_EM_GRID, OPT_FUSE_CHAINS, OPT_CNT_REPLICAS = range(7)
+OPT_SAMPLE_KERNEL, OPT_FORCE_IDX64, OPT_SELL_WAVES_PER_CU, OPT_EM_KERNEL, OPT_EM_GRID, OPT_FUSE_CHAINS, OPT_CNT_REPLICAS, OPT_GROUP_FAIL, OPT_DERIVE_ORDER = range(9)
 
 
 class ProblemDesc(C.Structure):

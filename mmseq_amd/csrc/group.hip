@@ -30,6 +30,7 @@ struct Rccl {
     void *lib = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
@@ -46,6 +47,7 @@ struct Rccl {
 #define RSYM(field, sym) do { *(void **)&field = dlsym(lib, sym); if (!field) { err = std::string("librccl lacks ") + sym; lib = nullptr; return false; } } while (0)
         RSYM(CommInitAll, "ncclCommInitAll");
         RSYM(CommDestroy, "ncclCommDestroy");
+        RSYM(CommAbort, "ncclCommAbort");
         RSYM(AllReduce, "ncclAllReduce");
         RSYM(GroupStart, "ncclGroupStart");
         RSYM(GroupEnd, "ncclGroupEnd");
@@ -61,7 +63,22 @@ struct mmg_group {
     std::vector<int> devices;
     std::vector<ncclComm_t> comms;
     double last_enqueue_us = 0.0; // host time per device-iteration of the last run_* call (slowest driver thread)
+    bool aborted = false;         // a member failed inside a run call: the communicators were aborted, the group only remains to be destroyed
 };
+
+// After a failure on one device its peers may already have enqueued the collective of that iteration: their streams would wait on the
+// GPU for a rank that never arrives, and every later synchronisation -- a sampler's destructor, the runtime's teardown at exit --
+// with them.  ncclCommAbort makes the collectives in flight return; the group is unusable afterwards.
+static void abort_group(mmg_group *g)
+{
+    if (g->aborted) return;
+    g->aborted = true;
+    for (size_t i = 0; i < g->comms.size(); ++i) {
+        (void)hipSetDevice(g->devices[i]);
+        if (g->comms[i]) (void)g_rccl.CommAbort(g->comms[i]);
+        g->comms[i] = nullptr;
+    }
+}
 
 #define NCCL_TRY(expr)                                                                                                   \
     do {                                                                                                                 \
@@ -106,6 +123,7 @@ extern "C" void mmg_group_destroy(mmg_group *g)
 static int check_samplers(const mmg_group *g, mmg_sampler *const *s, std::vector<SamplerView> &v)
 {
     if (!g || !s) return fail(MMG_ERR_ARG, "NULL argument");
+    if (g->aborted) return fail(MMG_ERR_STATE, "a device of this group failed in an earlier call: its communicators were aborted, destroy the group");
     v.resize(g->devices.size());
     for (size_t i = 0; i < v.size(); ++i) {
         if (!s[i]) return fail(MMG_ERR_ARG, "NULL sampler in the group");
@@ -122,8 +140,9 @@ static int check_samplers(const mmg_group *g, mmg_sampler *const *s, std::vector
 // One driver thread per device: thread i binds device i once and enqueues that device's kernels and collectives in order.  A
 // single host thread that visits the devices in turn pays a hipSetDevice and three launches per device and iteration -- at
 // config-2 scale (40 us per iteration) eight devices would wait for the host.  RCCL accepts concurrent enqueues on the
-// communicators of one ncclCommInitAll from one thread each, without a group bracket.  f(i) returns an MMG code; the first
-// failure (with its message) is what the caller sees, and the other threads stop at their next iteration.
+// communicators of one ncclCommInitAll from one thread each, without a group bracket.  f(i, iteration) returns an MMG code; the first
+// failure (with its message) is what the caller sees, the other threads stop at their next iteration, and the communicators are
+// aborted: a peer that had already enqueued the iteration's collective must not wait for the failed device for ever (abort_group).
 template <typename F>
 static int drive_devices(mmg_group *g, size_t G, int n_iter, F body)
 {
@@ -135,7 +154,8 @@ static int drive_devices(mmg_group *g, size_t G, int n_iter, F body)
         if (hipSetDevice(g->devices[i]) != hipSuccess) { rc[i] = MMG_ERR_HIP; msg[i] = "hipSetDevice"; stop = true; return; }
         const auto t0 = std::chrono::steady_clock::now();
         for (int it = 0; it < n_iter && !stop.load(std::memory_order_relaxed); ++it) {
-            const int r = body(i);
+            int r = body(i);
+            if (r == MMG_OK && opt(MMG_OPT_GROUP_FAIL) >= 0 && (size_t)opt(MMG_OPT_GROUP_FAIL) % G == i && it == 1) r = fail(MMG_ERR_HIP, "injected failure (MMG_OPT_GROUP_FAIL)");
             if (r != MMG_OK) { rc[i] = r; msg[i] = mmg_last_error(); stop = true; return; }
         }
         us[i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
@@ -147,7 +167,7 @@ static int drive_devices(mmg_group *g, size_t G, int n_iter, F body)
         run(0);
         for (auto &t : th) t.join();
     }
-    for (size_t i = 0; i < G; ++i) if (rc[i] != MMG_OK) return fail(rc[i], msg[i]);
+    for (size_t i = 0; i < G; ++i) if (rc[i] != MMG_OK) { abort_group(g); return fail(rc[i], msg[i] + " (device " + std::to_string(g->devices[i]) + "; the group's communicators were aborted)"); }
     g->last_enqueue_us = n_iter > 0 ? *std::max_element(us.begin(), us.end()) / n_iter : 0.0;
     return MMG_OK;
 }
@@ -229,7 +249,7 @@ extern "C" int mmg_group_pool_moments(mmg_group *g, mmg_sampler *const *samplers
         for (size_t i = 0; i < G; ++i) {
             if (hipSetDevice(g->devices[i]) != hipSuccess || hipMalloc(&red[i], (size_t)count * sizeof(double)) != hipSuccess) { release(); return fail(MMG_ERR_HIP, "hipMalloc (pooled moments)"); }
         }
-        if ((rc = all_reduce(g, v, mom.data(), red.data(), (size_t)count, ncclDouble)) != MMG_OK) { release(); return rc; }
+        if ((rc = all_reduce(g, v, mom.data(), red.data(), (size_t)count, ncclDouble)) != MMG_OK) { const std::string why = mmg_last_error(); abort_group(g); release(); return fail(rc, why); }
         hipError_t e = hipSetDevice(g->devices[0]);
         if (e == hipSuccess) e = hipStreamSynchronize(v[0].stream);
         if (e == hipSuccess) e = hipMemcpy(pooled.data(), red[0], (size_t)count * sizeof(double), hipMemcpyDeviceToHost);
@@ -277,6 +297,7 @@ std::function<int(int)> make_rccl_reduce(const std::vector<mmg_em *> &es, void *
         }
         const ncclResult_t e = g_rccl.GroupEnd();
         if (rc == MMG_OK && e != ncclSuccess) rc = fail(MMG_ERR_HIP, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(e));
+        if (rc != MMG_OK) { const std::string why = mmg_last_error(); abort_group(g); return fail(rc, why); } // members that did enqueue must not wait for ever
         return rc;
     };
 }
@@ -285,6 +306,7 @@ std::function<int(int)> make_rccl_reduce(const std::vector<mmg_em *> &es, void *
 extern "C" int mmg_group_em_create(mmg_group *g, const mmg_problem *const *shards, const double *mu0, mmg_em **ems, double *loglik0)
 {
     if (!g || !shards || !mu0 || !ems) return fail(MMG_ERR_ARG, "NULL argument");
+    if (g->aborted) return fail(MMG_ERR_STATE, "a device of this group failed in an earlier call: its communicators were aborted, destroy the group");
     for (size_t i = 0; i < g->devices.size(); ++i)
         if (!shards[i] || shards[i]->device != g->devices[i]) return fail(MMG_ERR_ARG, "shard i must live on device i of the group");
     EmGroupCtx ctx{g};

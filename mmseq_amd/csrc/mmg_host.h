@@ -64,6 +64,7 @@ struct mmg_problem {
     uint64_t *d_chunk_tile = nullptr;
     int grid_sample = 1;
     uint64_t *d_colcnt = nullptr;               // hits per transcript, for the EM scale words (lazy)
+    bool order_derived = false;                 // the renumbering came from the hit graph (order.hip), not from the caller's tx_order
     bool renumbered() const { return !h_int_of_ext.empty(); }
 };
 

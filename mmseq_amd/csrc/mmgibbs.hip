@@ -28,7 +28,7 @@ extern "C" const char *mmg_last_error(void) { return g_err.c_str(); }
 extern "C" int mmg_abi_version(void) { return MMG_ABI_VERSION; }
 
 // self-test overrides (mmg_selftest_option): -1 = the library decides
-static std::atomic<int> g_opt[MMG_OPT_COUNT_] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
+static std::atomic<int> g_opt[MMG_OPT_COUNT_] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
 int mmg::opt(int o) { return g_opt[o].load(std::memory_order_relaxed); }
 extern "C" int mmg_selftest_option(int option, int value)
 {
@@ -512,6 +512,11 @@ static int problem_build(mmg_problem *p, uint64_t *d_rp64)
     return rc;
 }
 
+static int problem_create_checked(const mmg_problem_desc *d, int device, const uint64_t *tx_order, mmg_problem **out);
+
+// what a sweep over the problem costs in the units of the tile ranges (2 per register-path tile; the CSR-tile kernel 2.8 per 64 hits)
+static uint64_t modelled_sweep_cost(const mmg_problem *p) { return p->use_sell && !p->h_sell_cum.empty() ? p->h_sell_cum.back() : p->nnz * 7 / 160; }
+
 extern "C" int mmg_problem_create(const mmg_problem_desc *d, int device, mmg_problem **out)
 {
     if (!d || !out) return fail(MMG_ERR_ARG, "NULL argument");
@@ -532,6 +537,40 @@ extern "C" int mmg_problem_create(const mmg_problem_desc *d, int device, mmg_pro
         if (!(d->l[t] > 0.0)) return fail(MMG_ERR_ARG, "l[t] must be > 0 (src/mmseq.cpp:604)");
     int rc = require_device(device);
     if (rc) return rc;
+    mmg_problem *p = nullptr;
+    rc = problem_create_checked(d, device, d->tx_order, &p);
+    if (rc) return rc;
+    // No transcript order from the caller, and in the caller's numbering the rows do not fit LDS windows (first-seen numbering,
+    // src/mmseq.cpp:399-408: more than a quarter above what register-path tiles alone would cost): derive an order from the hit
+    // graph (order.hip) and keep the problem built on it if the model prices it at least a fifth lower.
+    if (!d->tx_order && d->layout == MMG_LAYOUT_CANONICAL && p->m > 0 && d->n > 1 && opt(MMG_OPT_DERIVE_ORDER) != 0) {
+        const uint64_t floor_cost = SELL_FAST_TILE_COST * (p->use_sell ? p->n_sell_tiles : (p->m + 63) / 64);
+        if (modelled_sweep_cost(p) > floor_cost + floor_cost / 4 || opt(MMG_OPT_DERIVE_ORDER) == 1) {
+            std::vector<uint64_t> edges;
+            hipError_t e = order_cooccurrence_edges(p->idx64, p->m, p->nnz, p->d_row_ptr, p->d_col, edges, 0); // (no tx_order: device ids are the caller's)
+            if (e != hipSuccess) { problem_free(p); return fail(MMG_ERR_HIP, std::string("transcript order from the hit graph: ") + hipGetErrorString(e)); }
+            if (!edges.empty()) {
+                std::vector<uint32_t> pos;
+                order_from_edges(d->n, edges, pos);
+                std::vector<uint64_t>().swap(edges);
+                std::vector<uint64_t> keys(pos.begin(), pos.end());
+                mmg_problem *q = nullptr;
+                rc = problem_create_checked(d, device, keys.data(), &q);
+                if (rc) { problem_free(p); return rc; }
+                if (modelled_sweep_cost(q) < modelled_sweep_cost(p) - modelled_sweep_cost(p) / 5) { problem_free(p); p = q; p->order_derived = true; }
+                else problem_free(q);
+            }
+        }
+    }
+    *out = p;
+    return MMG_OK;
+}
+
+// the upload and build behind mmg_problem_create, arguments checked; tx_order: the caller's, a derived one, or NULL
+static int problem_create_checked(const mmg_problem_desc *d, int device, const uint64_t *tx_order, mmg_problem **out)
+{
+    const uint64_t nnz = d->row_ptr[d->m];
+    int rc = MMG_OK;
     mmg_problem *p = new mmg_problem();
     p->device = device;
     p->m = d->m; p->n = d->n; p->nnz = nnz; p->row_id_base = d->row_id_base; p->layout = (int)d->layout;
@@ -545,10 +584,10 @@ extern "C" int mmg_problem_create(const mmg_problem_desc *d, int device, mmg_pro
     const uint32_t *col_src = d->col_idx;
     std::vector<double> l_int;
     const double *l_src = d->l;
-    if (d->tx_order) {
+    if (tx_order) {
         std::vector<uint32_t> order(d->n);
         for (uint32_t t = 0; t < d->n; ++t) order[t] = t;
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return d->tx_order[a] < d->tx_order[b]; });
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return tx_order[a] < tx_order[b]; });
         p->h_ext_of_int = order;
         p->h_int_of_ext.resize(d->n);
         for (uint32_t i = 0; i < d->n; ++i) p->h_int_of_ext[order[i]] = i;
@@ -600,7 +639,7 @@ extern "C" int mmg_problem_shard(const mmg_problem *full, uint64_t lo, uint64_t 
     p->m = hi - lo; p->n = full->n; p->row_id_base = full->row_id_base + lo; p->layout = (int)MMG_LAYOUT_KEEP_ROWS;
     p->h_l = full->h_l;
     p->h_int_of_ext = full->h_int_of_ext; p->h_ext_of_int = full->h_ext_of_int;
-    p->canonical_rows = full->canonical_rows;
+    p->canonical_rows = full->canonical_rows; p->order_derived = full->order_derived;
     uint64_t *src_rp = nullptr, *d_rp64 = nullptr;
     auto bail = [&](int code) {
         if (src_rp) { (void)hipSetDevice(full->device); (void)hipFree(src_rp); }
@@ -938,7 +977,7 @@ extern "C" int mmg_problem_info_get(const mmg_problem *p, mmg_problem_info *info
     info->far_tiles = p->n_far_tiles;
     info->padded_slots = p->padded_slots;
     info->layout = p->layout;
-    info->tx_renumbered = p->renumbered() ? 1 : 0;
+    info->tx_renumbered = p->renumbered() ? (p->order_derived ? 2 : 1) : 0;
     info->sample_grid = p->use_sell ? p->grid_sell : p->grid_sample;
     info->cu_count = p->cu_count;
     return MMG_OK;

@@ -4,6 +4,8 @@
 #include "mmg_launch.h"
 
 #include <algorithm>
+#include <array>
+#include <deque>
 
 using namespace mmg;
 
@@ -18,9 +20,11 @@ struct mmg_sampler {
     bool sampled = false;  // sample() issued for the current iteration, update() pending
     int64_t n_kept = 0;
     // timing
+    // HIP-event pairs around timed launches: a pair is harvested (its time added to the sums, its events back on the free list) as soon
+    // as it has completed, so the pool stays as large as the launches in flight however long the chain
     std::vector<hipEvent_t> ev_pool;
-    std::vector<std::pair<int, int>> ev_sample, ev_update; // indices into ev_pool
-    size_t ev_used = 0;
+    std::vector<int> ev_free;                              // indices into ev_pool
+    std::deque<std::array<int, 3>> ev_pending;             // {start, stop, 0 sample | 1 update} in enqueue order
     double acc_sample_ms = 0, acc_update_ms = 0;
     uint64_t acc_sample_n = 0, acc_update_n = 0;
 };
@@ -94,14 +98,36 @@ extern "C" int mmg_sampler_set_stream(mmg_sampler *s, void *hip_stream)
     return MMG_OK;
 }
 
+// pairs at the head of the queue that have completed (all of them after a synchronisation: wait == true)
+static int ev_harvest(mmg_sampler *s, bool wait)
+{
+    while (!s->ev_pending.empty()) {
+        const std::array<int, 3> pr = s->ev_pending.front();
+        if (!wait) {
+            const hipError_t q = hipEventQuery(s->ev_pool[pr[1]]);
+            if (q == hipErrorNotReady) { (void)hipGetLastError(); break; }
+            if (q != hipSuccess) return fail(MMG_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(q));
+        }
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, s->ev_pool[pr[0]], s->ev_pool[pr[1]]));
+        if (pr[2] == 0) { s->acc_sample_ms += ms; s->acc_sample_n++; } else { s->acc_update_ms += ms; s->acc_update_n++; }
+        s->ev_free.push_back(pr[0]); s->ev_free.push_back(pr[1]);
+        s->ev_pending.pop_front();
+    }
+    return MMG_OK;
+}
+
 static int ev_get(mmg_sampler *s, int &idx)
 {
-    if (s->ev_used == s->ev_pool.size()) {
+    if (s->ev_free.empty() && s->ev_pending.size() >= 64) { int rc = ev_harvest(s, false); if (rc) return rc; }
+    if (s->ev_free.empty()) {
         hipEvent_t e;
         HIP_TRY(hipEventCreate(&e));
         s->ev_pool.push_back(e);
+        s->ev_free.push_back((int)s->ev_pool.size() - 1);
     }
-    idx = (int)s->ev_used++;
+    idx = s->ev_free.back();
+    s->ev_free.pop_back();
     return MMG_OK;
 }
 
@@ -197,7 +223,7 @@ static int sampler_sample(mmg_sampler *s, bool fold)
     }
     if (timed) {
         HIP_TRY(hipEventRecord(s->ev_pool[e1], s->cur));
-        s->ev_sample.push_back({e0, e1});
+        s->ev_pending.push_back({e0, e1, 0});
     }
     if (fold && p->m > 0 && p->cnt_replicas > 1) {
         launch_fold_counts(s->d_cnt, (uint64_t)s->cfg.n_chains * p->n, (size_t)s->cfg.n_chains * p->n, s->cur);
@@ -239,7 +265,7 @@ extern "C" int mmg_sampler_update(mmg_sampler *s)
     HIP_TRY(hipGetLastError());
     if (timed) {
         HIP_TRY(hipEventRecord(s->ev_pool[e1], s->cur));
-        s->ev_update.push_back({e0, e1});
+        s->ev_pending.push_back({e0, e1, 1});
     }
     if (sample_idx >= 0) s->n_kept++;
     s->iter++;
@@ -414,18 +440,7 @@ static int drain_events(mmg_sampler *s)
 {
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipStreamSynchronize(s->cur));
-    for (auto &pr : s->ev_sample) {
-        float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, s->ev_pool[pr.first], s->ev_pool[pr.second]));
-        s->acc_sample_ms += ms; s->acc_sample_n++;
-    }
-    for (auto &pr : s->ev_update) {
-        float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, s->ev_pool[pr.first], s->ev_pool[pr.second]));
-        s->acc_update_ms += ms; s->acc_update_n++;
-    }
-    s->ev_sample.clear(); s->ev_update.clear(); s->ev_used = 0;
-    return MMG_OK;
+    return ev_harvest(s, true);
 }
 
 extern "C" int mmg_sampler_get_timing(mmg_sampler *s, mmg_timing *t)

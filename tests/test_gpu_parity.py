@@ -80,9 +80,35 @@ def test_first_seen_numbering_with_tx_order_takes_the_fast_kernel(gpu, orc):
     l_ext = np.empty(p.n); l_ext[scat] = p.l
     tx_order = np.empty(p.n, np.uint64)
     tx_order[scat] = (np.arange(p.n, dtype=np.uint64) // np.uint64(7)) << np.uint64(32) | (np.arange(p.n, dtype=np.uint64) % np.uint64(7))
+    with gpu.options(derive_order=0):                        # what every caller without tx_order got up to spec version 5
+        plain = gpu.Problem.from_csr(p.row_ptr, ci_ext, l_ext)
+        assert plain.info.sample_kernel == 0 and plain.info.tx_renumbered == 0
+        plain.close()
+    # spec version 6: the library derives an order from the hit graph -- which transcripts share rows -- and uses it like a caller's
+    # tx_order: the stream kernel, nearly every tile on the register path, every array still in the caller's numbering, the chain the
+    # oracle's replay of the downloaded rows; and the order is a function of the SET of rows (any upload order, the same problem)
     plain = gpu.Problem.from_csr(p.row_ptr, ci_ext, l_ext)
-    assert plain.info.sample_kernel == 0 and plain.info.tx_renumbered == 0
-    plain.close()
+    pin = plain.info
+    assert pin.sample_kernel == 2 and pin.tx_renumbered == 2 and pin.fast_tiles >= 0.9 * pin.n_tiles, (pin.fast_tiles, pin.far_tiles, pin.n_tiles)
+    perm = plain.tx_perm()
+    assert np.array_equal(np.sort(perm), np.arange(p.n))
+    q_rp, q_ci = plain.download()
+    ci_q = perm[ci_ext]
+    for r in range(p.m):
+        ci_q[rp[r]:rp[r + 1]].sort()
+    cq_rp, cq_ci, _, _ = orc.canonical_layout(p.row_ptr, ci_q)
+    assert np.array_equal(q_rp, cq_rp) and np.array_equal(perm[q_ci], cq_ci)       # the canonical layout of the renumbered rows
+    mu_q, _ = plain.start_values()
+    sq = gpu.Sampler(plain, mu_q, seed=3, gibbs_iter=8, trace_len=8)
+    sq.run(8)
+    refq = orc.gibbs_keyed(orc.Problem(q_rp, q_ci, l_ext), mu_q, seed=3, n_iter=8, trace_len=8)
+    assert np.array_equal(sq.trace(0), refq["trace"]) and np.array_equal(sq.counts(0), refq["cnt"])
+    shuffled = rng.permutation(p.m)
+    s_rp, s_ci, _ = orc.permute_rows(p.row_ptr, ci_ext, None, shuffled)
+    again = gpu.Problem.from_csr(s_rp, s_ci, l_ext)
+    a_rp, a_ci = again.download()
+    assert np.array_equal(again.tx_perm(), perm) and np.array_equal(a_rp, q_rp) and np.array_equal(a_ci, q_ci)
+    sq.close(); again.close(); plain.close()
     prob = gpu.Problem.from_csr(p.row_ptr, ci_ext, l_ext, tx_order=tx_order)
     inf = prob.info
     assert inf.sample_kernel == 2 and inf.tx_renumbered == 1 and inf.fast_tiles == inf.n_tiles

@@ -78,3 +78,30 @@ def test_group_through_ctypes(gpu, orc):
     mu_o, _, ll_o = orc.em(p, mu0, max_iter=5, epsilon=-1e308)
     assert np.array_equal(mu_g, mu_o) and ll_g == ll_o
     grp.close()
+
+
+@pytest.mark.gpu
+def test_group_failure_aborts_the_communicators_and_long_chains_recycle_their_timing_events(gpu, orc):
+    """A member that fails inside a run call (injected: MMG_OPT_GROUP_FAIL) stops the others, the communicators are aborted
+    (ncclCommAbort: a peer already inside the iteration's all-reduce must not wait for ever -- src/mmseq.cpp:278-296 fails early and
+    loudly too), the caller gets the member's message, and the group refuses further work instead of hanging.  Also: a sampler timed
+    on every iteration harvests its HIP events as they complete -- thousands of timed iterations, a bounded pool, the same sums."""
+    from mmseq_amd._lib import MMGError
+    p, _ = orc.synth_problem(R=20000, T=900, avg_hits=5, seed=9)
+    mu0, _ = orc.start_values(p)
+    prob = gpu.Problem.from_csr(p.row_ptr, p.col_idx, p.l)
+    grp = gpu.Group([0])
+    s = gpu.Sampler(prob, mu0, seed=5, gibbs_iter=4096, trace_len=1, keep_trace=False, timing=1)
+    grp.run_sharded([s], 3000)
+    s.sync()
+    t = s.timing()
+    assert t["sample_launches"] == 3000 and t["update_launches"] == 3000 and t["sample_ms"] > 0.0
+    with gpu.options(group_fail=0):
+        with pytest.raises(MMGError) as e:
+            grp.run_sharded([s], 8)
+    assert "injected failure" in str(e.value) and "aborted" in str(e.value)
+    s.sync()                                                     # nothing is left waiting on the device
+    with pytest.raises(MMGError) as e2:
+        grp.run_chains([s], 1)
+    assert e2.value.code == 4 and "aborted" in str(e2.value)
+    grp.close(); s.close(); prob.close()
