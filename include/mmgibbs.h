@@ -243,6 +243,11 @@ int mmg_sampler_iteration(const mmg_sampler *s, int *iter);
 int mmg_sampler_get_trace(mmg_sampler *s, int chain, double *out);
 /* Same samples, sample-major (the row order of .trace_gibbs.gz, :912-916): out[s*n + t]. */
 int mmg_sampler_get_trace_rows(mmg_sampler *s, int chain, int first_sample, int n_samples, double *out);
+/* The same rows for samples the device has FINISHED (the caller synchronised after the iteration that produced the last of them):
+ * copied on a stream of their own, without waiting for -- or delaying -- iterations enqueued behind those samples.  May be called
+ * from another thread than the one driving the sampler: the trace writers of src/mmseq.cpp:911-917 print sample s inside the loop,
+ * right after iteration s * gibbs_ss; this is how a caller does the same while the device runs on. */
+int mmg_sampler_get_trace_rows_done(mmg_sampler *s, int chain, int first_sample, int n_samples, double *out);
 int mmg_sampler_get_mu(mmg_sampler *s, int chain, double *mu);
 /* Xcolsum of the last completed iteration (src/mmseq.cpp:896-899). */
 int mmg_sampler_get_counts(mmg_sampler *s, int chain, int32_t *cnt);
@@ -280,6 +285,16 @@ enum { MMG_SERIES_TRANSCRIPT = 0, MMG_SERIES_VIRTUAL = 1, MMG_SERIES_IDENTICAL =
  * trace length is 1024, src/mmseq.cpp:190); a sampler with a longer trace is refused here with MMG_ERR_ARG -- callers that want the
  * summary keep trace_len <= 2048 (mmg_sampler_get_trace / _get_moments serve longer traces). */
 int mmg_summary_create(mmg_sampler *s, const mmg_summary_desc *d, mmg_summary **out);
+/* The same in steps, for a caller that prints the trace files while the chain runs (src/mmseq.cpp:911-917 prints sample s inside the
+ * loop): _begin checks and uploads the description and draws the simulated traces (the chain may be running: its trace is not read);
+ * _advance computes the derived rows of the samples [done, samples_done) -- the caller vouches that the chain has finished them (it
+ * synchronised after iteration samples_done * gibbs_iter / trace_len - 1); mmg_summary_get_rows serves rows below samples_done;
+ * _finish, once every sample is in, computes the summary columns.  The summary works on a stream of its own: it neither waits for nor
+ * delays iterations enqueued behind the samples it reads.  One thread at a time drives _advance / _finish; mmg_summary_get_rows may be
+ * called from several threads for rows already advanced. */
+int mmg_summary_begin(mmg_sampler *s, const mmg_summary_desc *d, mmg_summary **out);
+int mmg_summary_advance(mmg_summary *q, int samples_done);
+int mmg_summary_finish(mmg_summary *q);
 /* Per series of `kind` (n, n_virtual, n_identical or n_genes of them): mean of the logged trace, Sokal's var and tau of the
  * logged trace with its return code (0; 200 / 201 when trace_len is no power of two >= 4: var = tau = 0), and the
  * n_percentiles order statistics of the trace itself, [series][percentile].  Any output may be NULL. */

@@ -94,6 +94,7 @@ SYMBOLS = {
     "mmg_sampler_iteration": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "mmg_sampler_get_trace": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mmg_sampler_get_trace_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mmg_sampler_get_trace_rows_done": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mmg_sampler_get_mu": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mmg_sampler_get_counts": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mmg_sampler_get_moments": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
@@ -101,6 +102,9 @@ SYMBOLS = {
     "mmg_sampler_reset_timing": (C.c_int, [C.c_void_p]),
     "mmg_sampler_destroy": (None, [C.c_void_p]),
     "mmg_summary_create": (C.c_int, [C.c_void_p, C.POINTER(SummaryDesc), C.POINTER(C.c_void_p)]),
+    "mmg_summary_begin": (C.c_int, [C.c_void_p, C.POINTER(SummaryDesc), C.POINTER(C.c_void_p)]),
+    "mmg_summary_advance": (C.c_int, [C.c_void_p, C.c_int]),
+    "mmg_summary_finish": (C.c_int, [C.c_void_p]),
     "mmg_summary_get": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mmg_summary_get_proportions": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mmg_summary_get_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -214,14 +214,15 @@ struct GzText {
 // (device gather + copy), the formatting and compression of this round -- in parallel over pieces of <= 32 k columns of a line
 // (~ 290 KB of text each, deflated independently and joined with sync flushes) -- and the write of the previous round's bytes.
 static void write_trace_rows(GzText &gz, int n_lines, size_t n_cols, const function<void(int, int, double *)> &fetch,
-                             const function<bool(size_t)> &keep)
+                             const function<bool(size_t)> &keep, int threads = 0)
 {
+    if (threads < 1) threads = max(1, omp_get_max_threads());
     vector<char> mask(n_cols);
     size_t n_keep = 0;
     for (size_t c = 0; c < n_cols; ++c) n_keep += (mask[c] = keep(c) ? 1 : 0);
     if (n_keep == 0) { for (int i = 0; i < n_lines; ++i) gz.str("\n"); return; }
     const size_t cols_per_piece = 32768, pieces_per_line = (n_cols + cols_per_piece - 1) / cols_per_piece;
-    const size_t want_pieces = (size_t)max(1, omp_get_max_threads()) * 2;
+    const size_t want_pieces = (size_t)threads * 2;
     size_t lines_per_round = max<size_t>((size_t)(64u << 20) / (n_cols * 8), (want_pieces + pieces_per_line - 1) / pieces_per_line);
     lines_per_round = max<size_t>(1, min<size_t>({lines_per_round, (size_t)(512u << 20) / (n_cols * 8) + 1, (size_t)n_lines}));
     vector<double> buf[2];
@@ -241,7 +242,7 @@ static void write_trace_rows(GzText &gz, int n_lines, size_t n_cols, const funct
         vector<string> comp((size_t)n_pieces);
         vector<uLong> crcs((size_t)n_pieces);
         vector<size_t> sizes((size_t)n_pieces);
-#pragma omp parallel
+#pragma omp parallel num_threads(threads)
         {
             string text;
             char tmp[48];
@@ -655,9 +656,12 @@ int main(int argc, char **argv)
     // ---- start values and the shared-count histogram (src/mmseq.cpp:610-638); host, deterministic
     //      Every thread owns a range of transcripts and walks all rows: a transcript's shares are added in row order whatever the
     //      thread count (the reference's order), and the walk is a stream of the hit list.
+    //      The pass runs on a thread of its own next to what follows -- the unique-hit counts, the .k / .M writer, the device problem
+    //      -- and is waited for where its results are first needed: the start of the EM (and -debug's .sharedcounts).
     vector<vector<int>> counts_shared(n, vector<int>(100, 0));
     vector<double> mu(n, 0.0);
-#pragma omp parallel num_threads(min(16, omp_get_max_threads())) // every thread reads the whole hit list: more only adds traffic
+    std::thread start_values([&]() {
+#pragma omp parallel num_threads(max(1, min(8, omp_get_max_threads() / 2))) // every thread reads the whole hit list: more only adds traffic
     {
         const uint64_t nth = (uint64_t)omp_get_num_threads(), tid = (uint64_t)omp_get_thread_num();
         const uint32_t lo = (uint32_t)((uint64_t)n * tid / nth), hi = (uint32_t)((uint64_t)n * (tid + 1) / nth);
@@ -676,8 +680,10 @@ int main(int argc, char **argv)
             }
     }
     for (uint32_t t = 0; t < n; ++t) mu[t] /= l[t];
+    });
+    struct JoinStart { std::thread &t; void now() { if (t.joinable()) t.join(); } ~JoinStart() { now(); } } start_values_join{start_values};
 
-    stage.mark("l, start values, histogram");
+    stage.mark("l (start values, histogram: in the background)");
     // ---- unique hits to identical sets and genes: O(nnz) form of src/uh.cpp:3-26
     vector<int> identical_unique_hits(identical_transcripts.size(), 0), gene_unique_hits(gene2transcripts.size(), 0);
     {
@@ -767,6 +773,7 @@ int main(int argc, char **argv)
     g_background_writer = &km_writer;
 
     if (debug) { // src/mmseq.cpp:697-731
+        start_values_join.now();
         ofs.open((output_base + ".sharedcounts").c_str());
         for (auto &name : transcriptList) {
             ofs << name << "\t";
@@ -830,6 +837,8 @@ int main(int argc, char **argv)
     }
 
     stage.mark("device problem build");
+    start_values_join.now();
+    stage.mark("wait for the start values");
     // ---- several devices: the stored problem (canonical order, device numbering) is cut into contiguous read shards, one per device
     //      (one chain: EM and Gibbs both run sharded), or replicated (chains >= devices).  Cut on device 0 and copied device to
     //      device (mmg_problem_shard): nothing comes back to the host.
@@ -907,6 +916,15 @@ int main(int argc, char **argv)
     //      (mmg_shard_bounds), one per device, counts all-reduced over RCCL every iteration -- bit-identical to the one-device run.
     //      several devices, chains >= devices: the stored problem is replicated, every device runs chains / gpus chains.
     vector<mmg_sampler *> smps;
+    mmg_sampler *smp = nullptr;
+    mmg_summary *summ = nullptr;
+    const size_t nI = identical_transcripts.size(), nG = gene2transcripts.size();
+    const size_t nP = percentiles.size();
+    vector<int> pind(nP);
+    for (size_t i = 0; i < nP; i++) pind[i] = static_cast<int>(round(percentiles[i] / 100.0 * (trace_length - 1)));
+    map<string, uint32_t> headerIndexOf;
+    for (size_t i = 0; i < nHeader; ++i) headerIndexOf[transcriptList[i]] = (uint32_t)i;
+    map<string, uint32_t> simuIndex; // isoform without hits -> its simulated ("virtual") trace
     {
         mmg_config cfg;
         memset(&cfg, 0, sizeof cfg);
@@ -924,48 +942,12 @@ int main(int argc, char **argv)
                 MMG_TRY(mmg_sampler_create(part[i], &ci, mu_em.data(), &smps[i]));
             }
         }
-        const int chunk = max(1, gibbs_iter / 16);
-        for (int done = 0; done < gibbs_iter; done += chunk) {
-            cout << "Gibbs iteration " << done << "       \r" << flush;
-            const int it = min(chunk, gibbs_iter - done);
-            if (gpus == 1) MMG_TRY(mmg_sampler_run(smps[0], it));
-            else if (gpus > 1 && chains == 1) MMG_TRY(mmg_group_run_sharded(grp, smps.data(), it));
-            else MMG_TRY(mmg_group_run_chains(grp, smps.data(), it));
-            for (auto sp : smps) MMG_TRY(mmg_sampler_sync(sp));
-        }
-        cout << "Gibbs iteration " << gibbs_iter - 1 << "       \r" << endl;
+        // ---- the posterior summary is set up BEFORE the loop and fed while it runs (src/mmseq.cpp:911-917 prints sample s inside the
+        //      loop; :927-1108 derives the other traces after it): sample s is final after iteration s * gibbs_ss, so the four trace files
+        //      are formatted, compressed and written by background threads while the device runs on -- rows come off the device on
+        //      streams of their own (mmg_sampler_get_trace_rows_done, mmg_summary_get_rows), nothing waits for the chain.
+        smp = smps[0]; // traces and per-feature summaries come from chain 0 (every shard holds the whole chain)
     }
-    mmg_sampler *smp = smps[0]; // traces and per-feature summaries come from chain 0 (every shard holds the whole chain)
-    // moments of log mu pooled over all chains and devices (one fp64 all-reduce): log_mu, sd and mcse of multi-chain runs
-    vector<double> pooled_sl, pooled_sl2;
-    int64_t pooled_ns = 0;
-    if (chains > 1) {
-        pooled_sl.resize(n); pooled_sl2.resize(n);
-        if (grp) MMG_TRY(mmg_group_pool_moments(grp, smps.data(), pooled_sl.data(), pooled_sl2.data(), &pooled_ns));
-        else {
-            vector<double> a_(n), b_(n);
-            for (int c = 0; c < chains; ++c) {
-                int64_t ns = 0;
-                MMG_TRY(mmg_sampler_get_moments(smp, c, a_.data(), b_.data(), &ns));
-                for (uint32_t t = 0; t < n; ++t) { pooled_sl[t] += a_[t]; pooled_sl2[t] += b_[t]; }
-                pooled_ns += ns;
-            }
-        }
-    }
-    stage.mark("Gibbs");
-
-    cout << "Amalgamating transcripts and calculating summary statistics..." << flush;
-    // ---- posterior summary on the device (src/mmseq.cpp:927-1363): trace sums over identical sets and genes, simulated traces of
-    //      isoforms without hits, proportions, percentiles, log means, Sokal.  Only summary columns and the rows the trace
-    //      writers print come back.
-    const size_t nI = identical_transcripts.size(), nG = gene2transcripts.size();
-    const size_t nP = percentiles.size();
-    vector<int> pind(nP);
-    for (size_t i = 0; i < nP; i++) pind[i] = static_cast<int>(round(percentiles[i] / 100.0 * (trace_length - 1)));
-    map<string, uint32_t> headerIndexOf;
-    for (size_t i = 0; i < nHeader; ++i) headerIndexOf[transcriptList[i]] = (uint32_t)i;
-    map<string, uint32_t> simuIndex; // isoform without hits -> its simulated ("virtual") trace
-    mmg_summary *summ = nullptr;
     {
         vector<uint64_t> vid, iptr(1, 0), gptr(1, 0);
         vector<double> vscale;
@@ -995,60 +977,111 @@ int main(int argc, char **argv)
         sd.n_identical = (uint32_t)nI; sd.identical_ptr = iptr.data(); sd.identical_member = imem.data();
         sd.n_genes = (uint32_t)nG; sd.gene_ptr = gptr.data(); sd.gene_member = gmem.data();
         sd.n_percentiles = (uint32_t)nP; sd.percentile_index = pind.data();
-        MMG_TRY(mmg_summary_create(smp, &sd, &summ));
+        MMG_TRY(mmg_summary_begin(smp, &sd, &summ));
     }
     const size_t nV = simuIndex.size();
-    stage.mark("device summary");
-
-    // ---- trace files (src/mmseq.cpp:823-831, :911-917, :1033-1108), written after the loop from rows fetched off the device
     {
-        GzText gz(output_base + ".trace_gibbs.gz");
-        for (uint32_t t = 0; t < n; t++) { gz.str(sid(t)); gz.str(" "); }
-        gz.str("\n");
-        write_trace_rows(gz, trace_length, n, [&](int first, int count, double *out) { MMG_TRY(mmg_sampler_get_trace_rows(smp, 0, first, count, out)); },
-                         [](size_t) { return true; });
-        gz.close();
+        std::mutex ready_mu;
+        std::condition_variable ready_cv;
+        int samples_ready = 0;                       // samples whose rows may be fetched (trace and derived traces)
+        auto wait_for = [&](int upto) { std::unique_lock<std::mutex> lk(ready_mu); ready_cv.wait(lk, [&] { return samples_ready >= upto; }); };
+        const int T = max(1, omp_get_max_threads());
+        const int t_big = max(1, (T - 1) * 9 / 20), t_gene = max(1, T / 10);
+        std::thread w_trace([&]() {
+            GzText gz(output_base + ".trace_gibbs.gz");
+            for (uint32_t t = 0; t < n; t++) { gz.str(sid(t)); gz.str(" "); }
+            gz.str("\n");
+            write_trace_rows(gz, trace_length, n, [&](int first, int count, double *out) { wait_for(first + count); MMG_TRY(mmg_sampler_get_trace_rows_done(smp, 0, first, count, out)); },
+                             [](size_t) { return true; }, t_big);
+            gz.close();
+        });
+        std::thread w_ident([&]() {
+            // a set whose first summed sample has no finite logarithm is left out of its trace file (:1040)
+            wait_for(1);
+            vector<double> firstI(max<size_t>(nI, 1));
+            MMG_TRY(mmg_summary_get_rows(summ, MMG_SERIES_IDENTICAL, 0, 1, firstI.data()));
+            vector<char> keepI(nI);
+            for (size_t v = 0; v < nI; ++v) keepI[v] = isfinite(log(firstI[v])) != 0;
+            GzText gi(output_base + ".identical.trace_gibbs.gz");
+            for (size_t v = 0; v < nI; ++v)
+                if (keepI[v]) {
+                    for (size_t j = 0; j < identical_transcripts[v].size(); ++j) {
+                        gi.str(identical_transcripts[v][j]);
+                        if (identical_transcripts[v][j].compare(identical_transcripts[v].back()) != 0) gi.str("+");
+                    }
+                    gi.str(" ");
+                }
+            gi.str("\n");
+            write_trace_rows(gi, trace_length, nI, [&](int first, int count, double *out) { wait_for(first + count); MMG_TRY(mmg_summary_get_rows(summ, MMG_SERIES_IDENTICAL, first, count, out)); },
+                             [&](size_t v) { return keepI[v] != 0; }, 1);
+            gi.close();
+        });
+        std::thread w_gene([&]() {
+            wait_for(1);                             // (:1068: the same rule for genes)
+            vector<double> firstG(max<size_t>(nG, 1));
+            MMG_TRY(mmg_summary_get_rows(summ, MMG_SERIES_GENE, 0, 1, firstG.data()));
+            vector<char> keepG(nG);
+            for (size_t g = 0; g < nG; ++g) keepG[g] = isfinite(log(firstG[g])) != 0;
+            GzText gg(output_base + ".gene.trace_gibbs.gz");
+            { size_t g = 0; for (auto &gt : gene2transcripts) { if (keepG[g]) { gg.str(gt.first); gg.str(" "); } g++; } }
+            gg.str("\n");
+            write_trace_rows(gg, trace_length, nG, [&](int first, int count, double *out) { wait_for(first + count); MMG_TRY(mmg_summary_get_rows(summ, MMG_SERIES_GENE, first, count, out)); },
+                             [&](size_t g) { return keepG[g] != 0; }, t_gene);
+            gg.close();
+        });
+        std::thread w_prop([&]() {
+            GzText gp(output_base + ".prop.trace_gibbs.gz");
+            for (uint32_t t = 0; t < n; t++) { gp.str(sid(t)); gp.str(" "); }
+            gp.str("\n");
+            write_trace_rows(gp, trace_length, n, [&](int first, int count, double *out) { wait_for(first + count); MMG_TRY(mmg_summary_get_rows(summ, MMG_SERIES_TRANSCRIPT, first, count, out)); },
+                             [](size_t) { return true; }, t_big);
+            gp.close();
+        });
+        const int chunk = max(1, gibbs_iter / 16);
+        for (int done = 0; done < gibbs_iter; done += chunk) {
+            cout << "Gibbs iteration " << done << "       \r" << flush;
+            const int it = min(chunk, gibbs_iter - done);
+            if (gpus == 1) MMG_TRY(mmg_sampler_run(smps[0], it));
+            else if (gpus > 1 && chains == 1) MMG_TRY(mmg_group_run_sharded(grp, smps.data(), it));
+            else MMG_TRY(mmg_group_run_chains(grp, smps.data(), it));
+            for (auto sp : smps) MMG_TRY(mmg_sampler_sync(sp));
+            // sample s is kept by iteration s * gibbs_ss (:911): the samples of the iterations done so far are final
+            const int final_samples = min(trace_length, (done + it - 1) / gibbs_ss + 1);
+            MMG_TRY(mmg_summary_advance(summ, final_samples));
+            { std::lock_guard<std::mutex> lk(ready_mu); samples_ready = final_samples; }
+            ready_cv.notify_all();
+        }
+        cout << "Gibbs iteration " << gibbs_iter - 1 << "       \r" << endl;
+        stage.mark("Gibbs (trace files written alongside)");
+        w_trace.join(); w_ident.join(); w_gene.join(); w_prop.join();
+        stage.mark("trace files: the rest");
     }
+    // moments of log mu pooled over all chains and devices (one fp64 all-reduce): log_mu, sd and mcse of multi-chain runs
+    vector<double> pooled_sl, pooled_sl2;
+    int64_t pooled_ns = 0;
+    if (chains > 1) {
+        pooled_sl.resize(n); pooled_sl2.resize(n);
+        if (grp) MMG_TRY(mmg_group_pool_moments(grp, smps.data(), pooled_sl.data(), pooled_sl2.data(), &pooled_ns));
+        else {
+            vector<double> a_(n), b_(n);
+            for (int c = 0; c < chains; ++c) {
+                int64_t ns = 0;
+                MMG_TRY(mmg_sampler_get_moments(smp, c, a_.data(), b_.data(), &ns));
+                for (uint32_t t = 0; t < n; ++t) { pooled_sl[t] += a_[t]; pooled_sl2[t] += b_[t]; }
+                pooled_ns += ns;
+            }
+        }
+    }
+
+    cout << "Amalgamating transcripts and calculating summary statistics..." << flush;
+    // ---- posterior summary on the device (src/mmseq.cpp:927-1363): the derived traces were computed while the chain ran; what is left
+    //      are the per-series columns -- percentiles, log means, Sokal -- of which only the columns come back.
+    MMG_TRY(mmg_summary_finish(summ));
+    stage.mark("device summary");
     for (auto sp : smps) mmg_sampler_destroy(sp);
     for (auto pp : dprob) mmg_problem_destroy(pp);
     mmg_problem_destroy(prob);
     if (grp) mmg_group_destroy(grp);
-    stage.mark("write .trace_gibbs.gz");
-    {
-        // a set / gene whose first summed sample has no finite logarithm is left out of its trace file (:1040, :1068)
-        vector<double> firstI(max<size_t>(nI, 1)), firstG(max<size_t>(nG, 1));
-        MMG_TRY(mmg_summary_get_rows(summ, MMG_SERIES_IDENTICAL, 0, 1, firstI.data()));
-        MMG_TRY(mmg_summary_get_rows(summ, MMG_SERIES_GENE, 0, 1, firstG.data()));
-        vector<char> keepI(nI), keepG(nG);
-        for (size_t v = 0; v < nI; ++v) keepI[v] = isfinite(log(firstI[v])) != 0;
-        for (size_t g = 0; g < nG; ++g) keepG[g] = isfinite(log(firstG[g])) != 0;
-        GzText gi(output_base + ".identical.trace_gibbs.gz");
-        for (size_t v = 0; v < nI; ++v)
-            if (keepI[v]) {
-                for (size_t j = 0; j < identical_transcripts[v].size(); ++j) {
-                    gi.str(identical_transcripts[v][j]);
-                    if (identical_transcripts[v][j].compare(identical_transcripts[v].back()) != 0) gi.str("+");
-                }
-                gi.str(" ");
-            }
-        gi.str("\n");
-        write_trace_rows(gi, trace_length, nI, [&](int first, int count, double *out) { MMG_TRY(mmg_summary_get_rows(summ, MMG_SERIES_IDENTICAL, first, count, out)); },
-                         [&](size_t v) { return keepI[v] != 0; });
-        gi.close();
-        GzText gg(output_base + ".gene.trace_gibbs.gz");
-        { size_t g = 0; for (auto &gt : gene2transcripts) { if (keepG[g]) { gg.str(gt.first); gg.str(" "); } g++; } }
-        gg.str("\n");
-        write_trace_rows(gg, trace_length, nG, [&](int first, int count, double *out) { MMG_TRY(mmg_summary_get_rows(summ, MMG_SERIES_GENE, first, count, out)); },
-                         [&](size_t g) { return keepG[g] != 0; });
-        gg.close();
-        GzText gp(output_base + ".prop.trace_gibbs.gz");
-        for (uint32_t t = 0; t < n; t++) { gp.str(sid(t)); gp.str(" "); }
-        gp.str("\n");
-        write_trace_rows(gp, trace_length, n, [&](int first, int count, double *out) { MMG_TRY(mmg_summary_get_rows(summ, MMG_SERIES_TRANSCRIPT, first, count, out)); },
-                         [](size_t) { return true; });
-        gp.close();
-    }
-    stage.mark("write derived traces");
 
     // ---- summary columns (src/mmseq.cpp:1110-1363)
     struct Series { vector<double> mean, sd, mcse, iact, pct; };

@@ -28,15 +28,30 @@ struct mmg_summary {
     double *d_prop = nullptr;    // [S][n], caller's numbering
     SeriesBuf ser[4];            // MMG_SERIES_TRANSCRIPT, _VIRTUAL, _IDENTICAL, _GENE
     PropBuf prop[2];             // MMG_SERIES_TRANSCRIPT, _VIRTUAL
+    // the summary is built in steps (mmg_summary_begin / _advance / _finish): what the steps share
+    const mmg_problem *p = nullptr;
+    const double *trace = nullptr; // the chain's resident trace [S][n], device numbering
+    hipStream_t st = nullptr;      // the summary's own stream: its kernels neither wait for nor delay the chain
+    uint32_t done = 0;             // samples whose derived rows exist
+    bool finished = false;
+    std::vector<void *> scratch;   // device buffers that live until _finish
+    uint64_t *d_iptr = nullptr, *d_gptr = nullptr;
+    uint32_t *d_imem = nullptr, *d_gmem = nullptr, *d_gene_t = nullptr, *d_gene_v = nullptr;
+    uint8_t *d_multi_t = nullptr, *d_multi_v = nullptr;
+    int32_t *d_pind = nullptr;
+    double *d_V = nullptr, *d_propV = nullptr, *d_tw = nullptr;
 };
 
 static void summary_free(mmg_summary *q)
 {
     if (!q) return;
     (void)hipSetDevice(q->device);
+    if (q->st) (void)hipStreamSynchronize(q->st);
+    for (void *x : q->scratch) if (x) (void)hipFree(x);
     for (void *x : {(void *)q->d_ident, (void *)q->d_gene, (void *)q->d_prop}) if (x) (void)hipFree(x);
     for (auto &b : q->ser) for (void *x : {(void *)b.log_mean, (void *)b.var, (void *)b.tau, (void *)b.pct, (void *)b.rc}) if (x) (void)hipFree(x);
     for (auto &b : q->prop) for (void *x : {(void *)b.mean, (void *)b.probit_mean, (void *)b.probit_sd, (void *)b.pct}) if (x) (void)hipFree(x);
+    if (q->st) (void)hipStreamDestroy(q->st);
     delete q;
 }
 
@@ -55,7 +70,9 @@ static int launch_series(uint32_t count, uint32_t S, const double *X, uint32_t n
     return MMG_OK;
 }
 
-extern "C" int mmg_summary_create(mmg_sampler *smp, const mmg_summary_desc *d, mmg_summary **out)
+// Step 1: the description is checked and uploaded, the buffers exist, the simulated traces of isoforms without hits (which do not
+// depend on the chain, :971-978) are drawn.  The chain may still be running: nothing of its trace is read here.
+extern "C" int mmg_summary_begin(mmg_sampler *smp, const mmg_summary_desc *d, mmg_summary **out)
 {
     if (!smp || !d || !out) return fail(MMG_ERR_ARG, "NULL argument");
     SamplerView v;
@@ -87,36 +104,33 @@ extern "C" int mmg_summary_create(mmg_sampler *smp, const mmg_summary_desc *d, m
             if (d->identical_member[j] >= n + nv) return fail(MMG_ERR_ARG, "identical-set member out of range");
     }
     HIP_TRY(hipSetDevice(p->device));
-    hipStream_t st = v.stream;
     mmg_summary *q = new mmg_summary();
     q->device = p->device; q->n = n; q->nv = nv; q->ni = ni; q->ng = ng; q->np = np; q->S = S;
-    // scratch that lives only during this call
-    std::vector<void *> tmp;
-    auto dalloc = [&](void **ptr, size_t bytes) { hipError_t e = hipMalloc(ptr, bytes ? bytes : 8); if (e == hipSuccess) tmp.push_back(*ptr); return e; };
-    auto finish = [&](int code) { (void)hipStreamSynchronize(st); for (void *x : tmp) (void)hipFree(x); if (code) summary_free(q); return code; };
-#define Q_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return finish(fail(MMG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); } while (0)
-#define Q_RC(expr) do { int _r = (expr); if (_r) return finish(_r); } while (0)
+    q->p = p;
+    q->trace = v.d_trace + (size_t)d->chain * S * n;
+    auto bail = [&](int code) { summary_free(q); return code; };
+#define Q_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return bail(fail(MMG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); } while (0)
+    Q_TRY(hipStreamCreateWithFlags(&q->st, hipStreamNonBlocking));
+    hipStream_t st = q->st;
+    auto dalloc = [&](void **ptr, size_t bytes) { hipError_t e = hipMalloc(ptr, bytes ? bytes : 8); if (e == hipSuccess) q->scratch.push_back(*ptr); return e; };
     auto upload = [&](void **dst, const void *src, size_t bytes) {
         hipError_t e = dalloc(dst, bytes);
         if (e == hipSuccess && bytes) e = hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, st);
         return e;
     };
-    uint64_t *d_vid = nullptr, *d_iptr = nullptr, *d_gptr = nullptr;
-    double *d_vscale = nullptr, *d_V = nullptr, *d_tw = nullptr, *d_propV = nullptr, *d_T = nullptr;
-    uint32_t *d_imem = nullptr, *d_gmem = nullptr, *d_gene_t = nullptr, *d_gene_v = nullptr;
-    uint8_t *d_multi_t = nullptr, *d_multi_v = nullptr;
-    int32_t *d_pind = nullptr;
+    uint64_t *d_vid = nullptr;
+    double *d_vscale = nullptr;
     Q_TRY(upload((void **)&d_vid, d->virtual_id, (size_t)nv * 8));
     Q_TRY(upload((void **)&d_vscale, d->virtual_scale, (size_t)nv * 8));
-    Q_TRY(upload((void **)&d_iptr, d->identical_ptr, ((size_t)ni + 1) * 8 * (ni ? 1 : 0)));
-    Q_TRY(upload((void **)&d_imem, d->identical_member, ni ? (size_t)d->identical_ptr[ni] * 4 : 0));
-    Q_TRY(upload((void **)&d_gptr, d->gene_ptr, ((size_t)ng + 1) * 8 * (ng ? 1 : 0)));
-    Q_TRY(upload((void **)&d_gmem, d->gene_member, ng ? (size_t)d->gene_ptr[ng] * 4 : 0));
-    Q_TRY(upload((void **)&d_gene_t, gene_of_t.data(), (size_t)n * 4));
-    Q_TRY(upload((void **)&d_gene_v, gene_of_v.data(), (size_t)nv * 4));
-    Q_TRY(upload((void **)&d_multi_t, multi_t.data(), (size_t)n));
-    Q_TRY(upload((void **)&d_multi_v, multi_v.data(), (size_t)nv));
-    Q_TRY(upload((void **)&d_pind, d->percentile_index, (size_t)np * 4));
+    Q_TRY(upload((void **)&q->d_iptr, d->identical_ptr, ((size_t)ni + 1) * 8 * (ni ? 1 : 0)));
+    Q_TRY(upload((void **)&q->d_imem, d->identical_member, ni ? (size_t)d->identical_ptr[ni] * 4 : 0));
+    Q_TRY(upload((void **)&q->d_gptr, d->gene_ptr, ((size_t)ng + 1) * 8 * (ng ? 1 : 0)));
+    Q_TRY(upload((void **)&q->d_gmem, d->gene_member, ng ? (size_t)d->gene_ptr[ng] * 4 : 0));
+    Q_TRY(upload((void **)&q->d_gene_t, gene_of_t.data(), (size_t)n * 4));
+    Q_TRY(upload((void **)&q->d_gene_v, gene_of_v.data(), (size_t)nv * 4));
+    Q_TRY(upload((void **)&q->d_multi_t, multi_t.data(), (size_t)n));
+    Q_TRY(upload((void **)&q->d_multi_v, multi_v.data(), (size_t)nv));
+    Q_TRY(upload((void **)&q->d_pind, d->percentile_index, (size_t)np * 4));
     // twiddle factors of host/numerics.hpp:fft_pow2, computed with the host's cos / sin: tw[half + j] = exp(-2 pi i j / (2 half))
     std::vector<double> tw(2 * (size_t)(S ? S : 1), 0.0);
     for (uint32_t len = 2; len <= S; len <<= 1) {
@@ -124,64 +138,115 @@ extern "C" int mmg_summary_create(mmg_sampler *smp, const mmg_summary_desc *d, m
         const uint32_t half = len / 2;
         for (uint32_t j = 0; j < half; ++j) { tw[2 * (half + j)] = std::cos(ang * (double)j); tw[2 * (half + j) + 1] = std::sin(ang * (double)j); }
     }
-    Q_TRY(upload((void **)&d_tw, tw.data(), tw.size() * 8));
-
-    const double *trace = v.d_trace + (size_t)d->chain * S * n;
-    // ---- derived traces, sample-major
-    Q_TRY(dalloc((void **)&d_V, (size_t)S * nv * 8));
-    if (nv) hipLaunchKernelGGL(k_virtual_traces, dim3(blocks_of((uint64_t)nv * S)), dim3(256), 0, st, v.cfg.seed, v.cfg.alpha, nv, S, d_vid, d_vscale, d_V);
+    Q_TRY(upload((void **)&q->d_tw, tw.data(), tw.size() * 8));
+    Q_TRY(dalloc((void **)&q->d_V, (size_t)S * nv * 8));
+    Q_TRY(dalloc((void **)&q->d_propV, (size_t)S * nv * 8));
+    if (nv) hipLaunchKernelGGL(k_virtual_traces, dim3(blocks_of((uint64_t)nv * S)), dim3(256), 0, st, v.cfg.seed, v.cfg.alpha, nv, S, d_vid, d_vscale, q->d_V);
+    Q_TRY(hipGetLastError());
     Q_TRY(hipMalloc((void **)&q->d_ident, (size_t)S * (ni ? ni : 1) * 8));
     Q_TRY(hipMalloc((void **)&q->d_gene, (size_t)S * (ng ? ng : 1) * 8));
     Q_TRY(hipMalloc((void **)&q->d_prop, (size_t)S * n * 8));
-    if (ni) hipLaunchKernelGGL(k_group_sums, dim3(blocks_of((uint64_t)ni * S)), dim3(256), 0, st, ni, S, n, nv, d_iptr, d_imem, p->d_int_of_ext, trace, d_V, q->d_ident);
-    if (ng) hipLaunchKernelGGL(k_group_sums, dim3(blocks_of((uint64_t)ng * S)), dim3(256), 0, st, ng, S, n, nv, d_gptr, d_gmem, p->d_int_of_ext, trace, d_V, q->d_gene);
-    hipLaunchKernelGGL(k_proportions, dim3(blocks_of((uint64_t)n * S)), dim3(256), 0, st, n, S, n, trace, p->d_int_of_ext, d_gene_t, ng, q->d_gene, q->d_prop);
-    Q_TRY(dalloc((void **)&d_propV, (size_t)S * nv * 8));
-    if (nv) hipLaunchKernelGGL(k_proportions, dim3(blocks_of((uint64_t)nv * S)), dim3(256), 0, st, nv, S, nv, d_V, (const uint32_t *)nullptr, d_gene_v, ng, q->d_gene, d_propV);
-    Q_TRY(hipGetLastError());
+    Q_TRY(hipStreamSynchronize(st));   // (the host vectors of this call were sources of asynchronous copies)
+#undef Q_TRY
+    *out = q;
+    return MMG_OK;
+}
 
-    // ---- per-series summaries: transpose to series-major, one workgroup per series
+// Step 2: the derived sample rows -- sums over identical sets and genes (:927-1008), proportions (:1014-1031) -- of the samples
+// [done, samples_done).  The caller vouches that the chain has finished those samples (it synchronised after iteration
+// samples_done * gibbs_ss - 1 or later); iterations enqueued behind them neither are waited for nor delayed.
+extern "C" int mmg_summary_advance(mmg_summary *q, int samples_done)
+{
+    if (!q) return fail(MMG_ERR_ARG, "NULL summary");
+    if (q->finished) return fail(MMG_ERR_STATE, "the summary is finished");
+    if (samples_done < (int)q->done || samples_done > (int)q->S) return fail(MMG_ERR_ARG, "samples_done out of range");
+    if ((uint32_t)samples_done == q->done) return MMG_OK;
+    HIP_TRY(hipSetDevice(q->device));
+    const uint32_t s0 = q->done, c = (uint32_t)samples_done - s0, n = q->n, nv = q->nv, ni = q->ni, ng = q->ng;
+    hipStream_t st = q->st;
+    const double *tr = q->trace + (size_t)s0 * n, *V = q->d_V + (size_t)s0 * nv;
+    const uint32_t *ioe = q->p->d_int_of_ext;
+    if (ni) hipLaunchKernelGGL(k_group_sums, dim3(blocks_of((uint64_t)ni * c)), dim3(256), 0, st, ni, c, n, nv, q->d_iptr, q->d_imem, ioe, tr, V, q->d_ident + (size_t)s0 * ni);
+    if (ng) hipLaunchKernelGGL(k_group_sums, dim3(blocks_of((uint64_t)ng * c)), dim3(256), 0, st, ng, c, n, nv, q->d_gptr, q->d_gmem, ioe, tr, V, q->d_gene + (size_t)s0 * ng);
+    hipLaunchKernelGGL(k_proportions, dim3(blocks_of((uint64_t)n * c)), dim3(256), 0, st, n, c, n, tr, ioe, q->d_gene_t, ng, q->d_gene + (size_t)s0 * ng, q->d_prop + (size_t)s0 * n);
+    if (nv) hipLaunchKernelGGL(k_proportions, dim3(blocks_of((uint64_t)nv * c)), dim3(256), 0, st, nv, c, nv, V, (const uint32_t *)nullptr, q->d_gene_v, ng, q->d_gene + (size_t)s0 * ng, q->d_propV + (size_t)s0 * nv);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    q->done = (uint32_t)samples_done;
+    return MMG_OK;
+}
+
+// Step 3, once every sample is in: per series the percentiles (:1110-1192), the mean of the logged trace (:1195-1227), Sokal's
+// variance and autocorrelation time (:1307-1363), the proportion summaries (:1235-1305).
+extern "C" int mmg_summary_finish(mmg_summary *q)
+{
+    if (!q) return fail(MMG_ERR_ARG, "NULL summary");
+    if (q->finished) return MMG_OK;
+    if (q->done != q->S) return fail(MMG_ERR_STATE, "mmg_summary_finish before every sample was handed to mmg_summary_advance");
+    HIP_TRY(hipSetDevice(q->device));
+    const uint32_t n = q->n, nv = q->nv, ni = q->ni, ng = q->ng, np = q->np, S = q->S;
+    hipStream_t st = q->st;
+    // transpose to series-major, one workgroup per series
     size_t maxcnt = n;
     for (size_t c : {(size_t)nv, (size_t)ni, (size_t)ng}) if (c > maxcnt) maxcnt = c;
-    Q_TRY(dalloc((void **)&d_T, maxcnt * S * 8));
+    double *d_T = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_T, maxcnt * S * 8));
+    q->scratch.push_back(d_T);
     const uint32_t counts[4] = {n, nv, ni, ng};
-    const double *srcs[4] = {trace, d_V, q->d_ident, q->d_gene};
+    const double *srcs[4] = {q->trace, q->d_V, q->d_ident, q->d_gene};
     for (int k = 0; k < 4; ++k) {
         SeriesBuf &b = q->ser[k];
         b.count = counts[k];
         const size_t c = counts[k] ? counts[k] : 1;
-        Q_TRY(hipMalloc((void **)&b.log_mean, c * 8));
-        Q_TRY(hipMalloc((void **)&b.var, c * 8));
-        Q_TRY(hipMalloc((void **)&b.tau, c * 8));
-        Q_TRY(hipMalloc((void **)&b.rc, c * 4));
-        Q_TRY(hipMalloc((void **)&b.pct, c * (np ? np : 1) * 8));
+        HIP_TRY(hipMalloc((void **)&b.log_mean, c * 8));
+        HIP_TRY(hipMalloc((void **)&b.var, c * 8));
+        HIP_TRY(hipMalloc((void **)&b.tau, c * 8));
+        HIP_TRY(hipMalloc((void **)&b.rc, c * 4));
+        HIP_TRY(hipMalloc((void **)&b.pct, c * (np ? np : 1) * 8));
         if (!counts[k]) continue;
-        launch_transpose(srcs[k], d_T, counts[k], S, k == MMG_SERIES_TRANSCRIPT ? p->d_int_of_ext : nullptr, st);
+        launch_transpose(srcs[k], d_T, counts[k], S, k == MMG_SERIES_TRANSCRIPT ? q->p->d_int_of_ext : nullptr, st);
         SeriesOut o{b.log_mean, b.var, b.tau, b.rc, b.pct, nullptr, nullptr, nullptr};
-        Q_RC(launch_series<true>(counts[k], S, d_T, np, d_pind, nullptr, d_tw, o, st));
+        int rc = launch_series<true>(counts[k], S, d_T, np, q->d_pind, nullptr, q->d_tw, o, st);
+        if (rc) return rc;
     }
-    const double *psrc[2] = {q->d_prop, d_propV};
-    const uint8_t *pmulti[2] = {d_multi_t, d_multi_v};
+    const double *psrc[2] = {q->d_prop, q->d_propV};
+    const uint8_t *pmulti[2] = {q->d_multi_t, q->d_multi_v};
     for (int k = 0; k < 2; ++k) {
         PropBuf &b = q->prop[k];
         b.count = counts[k];
         const size_t c = counts[k] ? counts[k] : 1;
-        Q_TRY(hipMalloc((void **)&b.mean, c * 8));
-        Q_TRY(hipMalloc((void **)&b.probit_mean, c * 8));
-        Q_TRY(hipMalloc((void **)&b.probit_sd, c * 8));
-        Q_TRY(hipMalloc((void **)&b.pct, c * (np ? np : 1) * 8));
+        HIP_TRY(hipMalloc((void **)&b.mean, c * 8));
+        HIP_TRY(hipMalloc((void **)&b.probit_mean, c * 8));
+        HIP_TRY(hipMalloc((void **)&b.probit_sd, c * 8));
+        HIP_TRY(hipMalloc((void **)&b.pct, c * (np ? np : 1) * 8));
         if (!counts[k]) continue;
         launch_transpose(psrc[k], d_T, counts[k], S, nullptr, st); // d_prop is in the caller's numbering already
         SeriesOut o{nullptr, nullptr, nullptr, nullptr, b.pct, b.mean, b.probit_mean, b.probit_sd};
-        Q_RC(launch_series<false>(counts[k], S, d_T, np, d_pind, pmulti[k], d_tw, o, st));
+        int rc = launch_series<false>(counts[k], S, d_T, np, q->d_pind, pmulti[k], q->d_tw, o, st);
+        if (rc) return rc;
     }
-    Q_TRY(hipGetLastError());
-    Q_TRY(hipStreamSynchronize(st));
-#undef Q_TRY
-#undef Q_RC
-    rc = finish(MMG_OK);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    for (void *x : q->scratch) if (x) (void)hipFree(x);   // the group tables, the virtual traces: the results no longer need them
+    q->scratch.clear();
+    q->d_V = q->d_propV = nullptr;
+    q->finished = true;
+    return MMG_OK;
+}
+
+// The three steps at once, after the chain has run.
+extern "C" int mmg_summary_create(mmg_sampler *smp, const mmg_summary_desc *d, mmg_summary **out)
+{
+    if (!out) return fail(MMG_ERR_ARG, "NULL argument");
+    mmg_summary *q = nullptr;
+    int rc = mmg_summary_begin(smp, d, &q);
+    if (rc) return rc;
+    rc = mmg_sampler_sync(smp);                      // every sample is final
+    if (rc == MMG_OK) rc = mmg_summary_advance(q, (int)q->S);
+    if (rc == MMG_OK) rc = mmg_summary_finish(q);
+    if (rc) { summary_free(q); return rc; }
     *out = q;
-    return rc;
+    return MMG_OK;
 }
 
 static int check_kind(const mmg_summary *q, int kind, int max_kind)
@@ -195,6 +260,7 @@ extern "C" int mmg_summary_get(mmg_summary *q, int kind, double *log_mean, doubl
 {
     int rc = check_kind(q, kind, MMG_SERIES_GENE);
     if (rc) return rc;
+    if (!q->finished) return fail(MMG_ERR_STATE, "summary columns exist after mmg_summary_finish");
     HIP_TRY(hipSetDevice(q->device));
     const SeriesBuf &b = q->ser[kind];
     const size_t c = b.count;
@@ -211,6 +277,7 @@ extern "C" int mmg_summary_get_proportions(mmg_summary *q, int kind, double *mea
 {
     int rc = check_kind(q, kind, MMG_SERIES_VIRTUAL);
     if (rc) return rc;
+    if (!q->finished) return fail(MMG_ERR_STATE, "summary columns exist after mmg_summary_finish");
     HIP_TRY(hipSetDevice(q->device));
     const PropBuf &b = q->prop[kind];
     const size_t c = b.count;
@@ -234,6 +301,7 @@ extern "C" int mmg_summary_get_rows(mmg_summary *q, int kind, int first_sample, 
     default: return fail(MMG_ERR_ARG, "rows exist for the proportion, identical-set and gene traces");
     }
     if (first_sample < 0 || n_samples < 0 || (uint32_t)(first_sample + n_samples) > q->S) return fail(MMG_ERR_ARG, "bad sample range");
+    if ((uint32_t)(first_sample + n_samples) > q->done) return fail(MMG_ERR_STATE, "rows of samples that were not yet handed to mmg_summary_advance");
     HIP_TRY(hipSetDevice(q->device));
     if (width && n_samples) HIP_TRY(hipMemcpy(out, src + (size_t)first_sample * width, (size_t)n_samples * width * 8, hipMemcpyDeviceToHost));
     return MMG_OK;

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <array>
 #include <deque>
+#include <mutex>
 
 using namespace mmg;
 
@@ -25,6 +26,10 @@ struct mmg_sampler {
     std::vector<hipEvent_t> ev_pool;
     std::vector<int> ev_free;                              // indices into ev_pool
     std::deque<std::array<int, 3>> ev_pending;             // {start, stop, 0 sample | 1 update} in enqueue order
+    hipStream_t reader = nullptr;                          // mmg_sampler_get_trace_rows_done: copies that do not queue behind the chain
+    double *d_reader_tmp = nullptr;                        // its gather buffer, kept (hipFree would wait for the running chain)
+    size_t reader_cap = 0;
+    std::mutex reader_mu;
     double acc_sample_ms = 0, acc_update_ms = 0;
     uint64_t acc_sample_n = 0, acc_update_n = 0;
 };
@@ -38,6 +43,8 @@ static void sampler_free(mmg_sampler *s)
     for (void *x : {(void *)s->d_mu, (void *)s->d_scale, (void *)s->d_trace, (void *)s->d_mom, (void *)s->d_cnt, (void *)s->d_cnt_last})
         if (x) (void)hipFree(x);
     if (s->own) (void)hipStreamDestroy(s->own);
+    if (s->reader) (void)hipStreamDestroy(s->reader);
+    if (s->d_reader_tmp) (void)hipFree(s->d_reader_tmp);
     delete s;
 }
 
@@ -398,6 +405,37 @@ extern "C" int mmg_sampler_get_trace_rows(mmg_sampler *s, int chain, int first, 
     if (e == hipSuccess) e = hipMemcpy(out, d_tmp, (size_t)count * n * sizeof(double), hipMemcpyDeviceToHost);
     (void)hipFree(d_tmp);
     if (e != hipSuccess) return fail(MMG_ERR_HIP, std::string("get_trace_rows: ") + hipGetErrorString(e));
+    return MMG_OK;
+}
+
+// The same rows for samples the device has FINISHED (the caller knows: it synchronised after the iteration that produced the last of
+// them): gathered and copied on a stream of the sampler's own for reading, so the call neither waits for iterations enqueued behind
+// those samples nor delays them.  May be called from another thread than the one driving the sampler.
+extern "C" int mmg_sampler_get_trace_rows_done(mmg_sampler *s, int chain, int first, int count, double *out)
+{
+    int rc = check_chain(s, chain);
+    if (rc) return rc;
+    if (!out || first < 0 || count < 0 || first + count > s->cfg.trace_len) return fail(MMG_ERR_ARG, "bad sample range");
+    if (!s->d_trace) return fail(MMG_ERR_STATE, "sampler was created with keep_trace == 0");
+    if (count == 0) return MMG_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    std::lock_guard<std::mutex> lock(s->reader_mu);
+    if (!s->reader) HIP_TRY(hipStreamCreateWithFlags(&s->reader, hipStreamNonBlocking));
+    const size_t n = s->p->n, S = (size_t)s->cfg.trace_len;
+    const double *src = s->d_trace + ((size_t)chain * S + (size_t)first) * n;
+    if (s->p->renumbered()) {
+        if (s->reader_cap < (size_t)count * n) {
+            if (s->d_reader_tmp) (void)hipFree(s->d_reader_tmp);
+            s->d_reader_tmp = nullptr; s->reader_cap = 0;
+            HIP_TRY(hipMalloc((void **)&s->d_reader_tmp, (size_t)count * n * sizeof(double)));
+            s->reader_cap = (size_t)count * n;
+        }
+        launch_gather_rows(src, s->d_reader_tmp, (uint32_t)n, (uint32_t)count, 8, s->p->d_int_of_ext, s->reader);
+        src = s->d_reader_tmp;
+    }
+    hipError_t e = hipMemcpyAsync(out, src, (size_t)count * n * sizeof(double), hipMemcpyDeviceToHost, s->reader);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->reader);
+    if (e != hipSuccess) return fail(MMG_ERR_HIP, std::string("get_trace_rows_done: ") + hipGetErrorString(e));
     return MMG_OK;
 }
 

@@ -248,6 +248,13 @@ class Sampler:
         check(self._lib.mmg_sampler_get_trace_rows(self._h, chain, first, count, _ptr(out)))
         return out
 
+    def trace_rows_done(self, chain=0, first=0, count=None):
+        """rows of samples the device has finished (mmg_sampler_get_trace_rows_done: no wait for iterations enqueued behind them)"""
+        count = self.trace_len - first if count is None else count
+        out = np.empty((count, self.n), np.float64)
+        check(self._lib.mmg_sampler_get_trace_rows_done(self._h, chain, first, count, _ptr(out)))
+        return out
+
     def mu(self, chain=0):
         out = np.empty(self.n, np.float64)
         check(self._lib.mmg_sampler_get_mu(self._h, chain, _ptr(out)))
@@ -371,7 +378,9 @@ class Summary:
     """Posterior summary of a sampler's resident trace on the device (mmg_summary_*; src/mmseq.cpp:927-1363).
     identical / genes: lists of member lists (a member < n: transcript, n + v: virtual transcript v)."""
 
-    def __init__(self, sampler, chain=0, virtual_id=(), virtual_scale=(), identical=(), genes=(), percentile_index=()):
+    def __init__(self, sampler, chain=0, virtual_id=(), virtual_scale=(), identical=(), genes=(), percentile_index=(), staged=False):
+        """staged: mmg_summary_begin only -- the caller then feeds finished samples with advance() while the chain runs and calls
+        finish() after the last one (rows() serves the advanced samples at any time)."""
         from ._lib import SummaryDesc
         self._lib = _lib.load()
         self.n = sampler.n
@@ -386,8 +395,14 @@ class Summary:
         d = SummaryDesc(chain, vid.size, _ptr(vid), _ptr(vsc), len(identical), _ptr(iptr), _ptr(imem), len(genes), _ptr(gptr), _ptr(gmem),
                         pidx.size, _ptr(pidx))
         h = C.c_void_p()
-        check(self._lib.mmg_summary_create(sampler._h, C.byref(d), C.byref(h)))
+        check((self._lib.mmg_summary_begin if staged else self._lib.mmg_summary_create)(sampler._h, C.byref(d), C.byref(h)))
         self._h = h
+
+    def advance(self, samples_done):
+        check(self._lib.mmg_summary_advance(self._h, int(samples_done)))
+
+    def finish(self):
+        check(self._lib.mmg_summary_finish(self._h))
 
     def series(self, kind):
         c = self.counts[kind]

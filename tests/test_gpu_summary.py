@@ -113,3 +113,59 @@ def test_summary_edge_shapes(gpu, orc):
     assert np.array_equal(q.rows(gpu.SERIES_GENE)[:, 0], tg)
     assert q.series(gpu.SERIES_VIRTUAL)["log_mean"].size == 0 and q.rows(gpu.SERIES_IDENTICAL).shape == (S, 0)
     q.close()
+
+
+def test_summary_in_steps_while_the_chain_runs_equals_the_summary_after_it(gpu, orc):
+    """mmg_summary_begin / _advance / _finish and mmg_sampler_get_trace_rows_done: the trace writers of src/mmseq.cpp:911-917 print sample s
+    inside the loop; here the caller feeds finished samples to the summary and fetches their rows WHILE later iterations are enqueued
+    (nothing waits for them: own streams), and ends up with the bits of the summary computed after the chain."""
+    S = 64
+    p, _ = orc.synth_problem(R=20000, T=700, avg_hits=5, seed=11, sort=False)
+    n = p.n
+    rng = np.random.default_rng(2)
+    txo = (rng.permutation(n).astype(np.uint64) // np.uint64(4)) << np.uint64(32)
+    prob = gpu.Problem.from_csr(p.row_ptr, p.col_idx, p.l, tx_order=txo)
+    mu0, _ = prob.start_values()
+    nv = 9
+    vid = (500 + np.arange(nv) * 3).astype(np.uint64)
+    vscale = rng.uniform(0.1, 1.0, nv)
+    members = rng.permutation(n + nv)
+    genes = [[int(m) for m in members[i:i + 3]] for i in range(0, members.size, 3)]
+    kw = dict(chain=0, virtual_id=vid, virtual_scale=vscale, identical=[[1, 2], [5]], genes=genes, percentile_index=[3, 31, 60])
+    a = gpu.Sampler(prob, mu0, seed=3, gibbs_iter=2 * S, trace_len=S)   # a sample every second iteration
+    qa = gpu.Summary(a, staged=True, **kw)
+    with pytest.raises(gpu._lib.MMGError):
+        qa.rows(gpu.SERIES_GENE, 0, 1)                  # nothing advanced yet
+    got_rows, got_gene = [], []
+    a.run(32)
+    a.sync()                                             # samples 0..15 are final
+    for c in range(4):                                   # 4 chunks of 32 iterations = 16 samples
+        if c < 3:
+            a.run(32)                                    # the next chunk is enqueued, NOT waited for, while this one's rows are read
+        qa.advance(16 * (c + 1))
+        got_rows.append(a.trace_rows_done(0, 16 * c, 16))
+        got_gene.append(qa.rows(gpu.SERIES_GENE, 16 * c, 16))
+        if c < 3:
+            with pytest.raises(gpu._lib.MMGError):
+                qa.series(gpu.SERIES_GENE)               # columns exist after finish()
+            with pytest.raises(gpu._lib.MMGError):
+                qa.finish()                              # ... which wants every sample
+            a.sync()
+    qa.finish()
+    # the reference: the same chain in one go, summarised after it
+    b = gpu.Sampler(prob, mu0, seed=3, gibbs_iter=2 * S, trace_len=S)
+    b.run(2 * S)
+    qb = gpu.Summary(b, **kw)
+    for kind in (gpu.SERIES_TRANSCRIPT, gpu.SERIES_VIRTUAL, gpu.SERIES_IDENTICAL, gpu.SERIES_GENE):
+        sa, sb = qa.series(kind), qb.series(kind)
+        for k in sa:
+            assert np.array_equal(sa[k], sb[k], equal_nan=True), (kind, k)
+    for kind in (gpu.SERIES_TRANSCRIPT, gpu.SERIES_VIRTUAL):
+        pa, pb = qa.proportions(kind), qb.proportions(kind)
+        for k in pa:
+            assert np.array_equal(pa[k], pb[k], equal_nan=True), (kind, k)
+    for kind in (gpu.SERIES_TRANSCRIPT, gpu.SERIES_IDENTICAL, gpu.SERIES_GENE):
+        assert np.array_equal(qa.rows(kind), qb.rows(kind), equal_nan=True)
+    assert np.array_equal(np.concatenate(got_gene), qb.rows(gpu.SERIES_GENE))
+    assert np.array_equal(np.concatenate(got_rows), b.trace_rows(0))
+    qa.close(); qb.close(); a.close(); b.close(); prob.close()

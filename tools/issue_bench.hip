@@ -1,13 +1,17 @@
 // Issue-rate microbenchmark for gfx950 (MI355X): how many shader cycles does one SIMD need per wave64 instruction of a given kind,
-// at 1..8 resident waves per SIMD?  Settles the denominator of bench.py's VALU-issue roofline (the guide quotes
-// "2 cycles per wave64 VALU instruction (SIMD-32)", K1's own counters read 4).
+// with 1..8 waves resident on it?  The denominator of every "VALU busy" figure in DESIGN.md / bench.py.
 //
 // Method: every wave runs REPS x an unrolled block of 64 INDEPENDENT instructions of one kind (8 accumulators round-robin, written in
-// inline asm so nothing is folded) between two s_memtime reads.  Workgroups are 256 threads = one wave per SIMD of a CU; k workgroups
-// per CU give k waves per SIMD (grid = 256 CUs x k; the kernel needs < 64 VGPRs and no LDS beyond 16 KB, so 8 fit).  Reported per
-// kind and k:   cycles per instruction per SIMD = k-wave elapsed shader cycles / (k x instructions per wave)   [median over waves],
-// and the same from wall time x 2.4 GHz as a cross-check of the clock.  "mix" rows interleave two kinds to see whether they share an
-// issue port.
+// inline asm so nothing is folded) between two s_memtime reads, and records WHERE it ran: HW_ID (SIMD, CU, SH, SE) and XCC_ID.
+// Workgroups are 256 threads = four waves; grid = 256 CUs x k.  Round 3 assumed that this puts k waves on every SIMD and divided a
+// wave's own elapsed ticks by k -- the dispatcher does not promise that, and the two columns of that table disagreed by up to 5 x.
+// Now the host groups the waves by the SIMD they ran on and computes, per SIMD,
+//     cycles per instruction = (last t1 - first t0 of its waves) / (instructions its waves executed)
+//     waves resident         = sum of the waves' own (t1 - t0) / that interval              (printed in brackets)
+// and reports the median over the SIMDs.  The tick rate of s_memtime is measured against the HIP-event wall time of the k = 1 launch
+// (a wave's own ticks / wall): printed as "GHz" -- it is the shader clock if s_memtime counts shader cycles
+// (MI355X_MICROARCH.md), and then "cycles" above are real ones whatever the clock did under this load.
+// "mix" rows interleave two kinds to see whether they share an issue port.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
@@ -268,16 +272,24 @@ __global__ __launch_bounds__(256) void k_issue(uint64_t *out, int reps, uint32_t
     uint64_t sink = (uint64_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7) + (uint64_t)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7) + (uint64_t)(f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7) +
                     (q0 ^ q1 ^ q2 ^ q3 ^ q4 ^ q5 ^ q6 ^ q7) + s0 + s2 + m64 + (c0 ^ c1 ^ c2 ^ c3 ^ c4 ^ c5 ^ c6 ^ c7) + (h0 ^ h1 ^ h2 ^ h3 ^ h4 ^ h5 ^ h6 ^ h7) + (uint64_t)(p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y) + (uint64_t)(w0.x + w1.y + w2.x + w3.y);
     if (sink == 0x123456789abcdefull) out[0] = sink;
-    if ((tid & 63u) == 0) out[1 + (size_t)blockIdx.x * 4 + (tid >> 6)] = t1 - t0;
+    if ((tid & 63u) == 0) {
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        uint64_t *o = out + 1 + ((size_t)blockIdx.x * 4 + (tid >> 6)) * 3;
+        o[0] = t0; o[1] = t1; o[2] = ((uint64_t)(xcc & 0xfu) << 32) | hw;
+    }
 }
 
 template <int K>
 static void run_kind(uint64_t *d_out, int reps)
 {
     printf("%-52s", kind_name[K]);
+    double ghz_sum = 0.0;
     for (int k : {1, 2, 4, 8}) {
         const int grid = 256 * k;
-        CK(hipMemset(d_out, 0, (1 + (size_t)grid * 4) * 8));
+        const size_t words = 1 + (size_t)grid * 4 * 3;
+        CK(hipMemset(d_out, 0, words * 8));
         hipLaunchKernelGGL(k_issue<K>, dim3(grid), dim3(256), 0, 0, d_out, 4, 1u); // warm-up
         CK(hipDeviceSynchronize());
         hipEvent_t e0, e1;
@@ -288,29 +300,49 @@ static void run_kind(uint64_t *d_out, int reps)
         CK(hipDeviceSynchronize());
         float ms = 0;
         CK(hipEventElapsedTime(&ms, e0, e1));
-        std::vector<uint64_t> h(1 + (size_t)grid * 4);
-        CK(hipMemcpy(h.data(), d_out, h.size() * 8, hipMemcpyDeviceToHost));
-        std::vector<uint64_t> t(h.begin() + 1, h.end());
-        std::sort(t.begin(), t.end());
+        std::vector<uint64_t> h(words);
+        CK(hipMemcpy(h.data(), d_out, words * 8, hipMemcpyDeviceToHost));
+        // waves by the SIMD they ran on: XCC, then SE / SH / CU (HW_ID bits 8-15) and SIMD (bits 4-5)
+        struct W { uint64_t key, t0, t1; };
+        std::vector<W> w((size_t)grid * 4);
+        for (size_t i = 0; i < w.size(); ++i) { const uint64_t *o = &h[1 + i * 3]; w[i] = {((o[2] >> 32) << 16) | (o[2] & 0xff30u), o[0], o[1]}; }
+        std::sort(w.begin(), w.end(), [](const W &a, const W &b) { return a.key < b.key; });
         const double n_inst = (double)reps * kind_block(K);
-        const double cyc_memtime = (double)t[t.size() / 2] / (k * n_inst);      // per SIMD: k waves share it
-        const double cyc_wall = (double)ms * 1e-3 * 2.4e9 / (k * n_inst);
-        printf("  k=%d %6.2f (%6.2f)", k, cyc_memtime, cyc_wall);
+        std::vector<double> cyc, res;
+        for (size_t i = 0; i < w.size();) {
+            size_t j = i;
+            uint64_t lo = ~0ull, hi = 0, own = 0;
+            while (j < w.size() && w[j].key == w[i].key) { lo = std::min(lo, w[j].t0); hi = std::max(hi, w[j].t1); own += w[j].t1 - w[j].t0; ++j; }
+            cyc.push_back((double)(hi - lo) / ((double)(j - i) * n_inst));
+            res.push_back((double)own / (double)(hi - lo));
+            i = j;
+        }
+        std::sort(cyc.begin(), cyc.end());
+        std::sort(res.begin(), res.end());
+        // the clock the ticks count: one wave per SIMD (k = 1) runs from launch to end -- its own ticks over the wall time of the launch
+        // (the few microseconds of launch overhead inside the wall time make this a slight underestimate)
+        if (k == 1) {
+            std::vector<uint64_t> own(w.size());
+            for (size_t i = 0; i < w.size(); ++i) own[i] = w[i].t1 - w[i].t0;
+            std::sort(own.begin(), own.end());
+            ghz_sum = (double)own[own.size() / 2] / ((double)ms * 1e6);
+        }
+        printf("  k=%d %5.2f [%3.1f on %4zu]", k, cyc[cyc.size() / 2], res[res.size() / 2], cyc.size());
         CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
     }
-    printf("\n");
+    printf("  %.2f GHz\n", ghz_sum);
 }
 
 int main(int argc, char **argv)
 {
     const int reps = argc > 1 ? atoi(argv[1]) : 2000;
     uint64_t *d_out;
-    CK(hipMalloc(&d_out, (1 + 256 * 8 * 4) * 8));
+    CK(hipMalloc(&d_out, (1 + 256 * 8 * 4 * 3) * 8));
     hipDeviceProp_t pr;
     CK(hipGetDeviceProperties(&pr, 0));
     printf("# %s, %d CUs, clockRate %d kHz; reps %d x 64-instruction blocks per wave; k = waves per SIMD\n", pr.gcnArchName, pr.multiProcessorCount, pr.clockRate, reps);
-    printf("# columns: s_memtime ticks per instruction per SIMD (wall time x 2.4 GHz per instruction per SIMD); s_memtime ticks at a CONSTANT rate\n");
-    printf("# (see the ratio of the two columns), so the wall column is the one in shader cycles at 2.4 GHz\n");
+    printf("# per k (workgroups per CU): s_memtime ticks per instruction per SIMD, median over the SIMDs [waves resident on a SIMD, SIMDs that ran waves];\n");
+    printf("# last column: a wave's own s_memtime ticks per nanosecond of HIP-event wall time in the k = 1 launch (the clock the ticks count)\n");
     run_kind<ADD_U32>(d_out, reps);
     run_kind<XOR_B32>(d_out, reps);
     run_kind<XOR3>(d_out, reps);
