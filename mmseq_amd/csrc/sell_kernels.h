@@ -269,7 +269,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
         const uint32_t l5 = lane & 31u;
         uint32_t x0, x1;
         // one key for the whole wave unless a multiple of 2^33 row ids lies between the first row of A and the last of B
-        if ((((a.row_id_base + A.r0) ^ (a.row_id_base + B.r0 + 63u)) >> 33) == 0 && A.r0 <= B.r0) {
+        const bool one_key = (((a.row_id_base + A.r0) ^ (a.row_id_base + B.r0 + 63u)) >> 33) == 0 && A.r0 <= B.r0;
+        if (one_key && (((a.row_id_base + A.r0) | (a.row_id_base + B.r0)) & 1u) == 0) {
+            // Both tiles start on an even row id (all but the first tile of a run): rows l and l + 1 (l even) of a tile share a block.
+            // The EVEN lane of a lane pair computes the pair's block for tile A, the ODD lane the one for tile B, and each takes the
+            // word it lacks from its neighbour with a quad-permute DPP move -- no LDS instruction (ds_bpermute: 7 LDS cycles each,
+            // four of them per pair of tiles; tools/issue_bench.hip).
+            const uint32_t key = stream2_key(a.seed, a.chain, TAG_ROW, (uint32_t)(qa >> 32));
+            x0 = ((lane & 1u) ? (uint32_t)qb : (uint32_t)qa) + (lane >> 1);
+            x1 = a.iter;
+            philox2x32_10(x0, x1, key);
+            const uint32_t n0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)x0, 0xB1, 0xF, 0xF, true); // quad_perm [1, 0, 3, 2]: the neighbour's words
+            const uint32_t n1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)x1, 0xB1, 0xF, 0xF, true);
+            xrowA = (lane & 1u) ? n1 : x0;   // row l of A: word 0 of the even lane's block, word 1 for the odd lane
+            xrowB = (lane & 1u) ? x1 : n0;   // row l of B: the odd lane's block
+            return;
+        }
+        if (one_key) {
             // the usual case: one key for the whole wave, kept in scalar registers
             const uint32_t key = stream2_key(a.seed, a.chain, TAG_ROW, (uint32_t)(qa >> 32));
             x0 = (lane < 32u ? (uint32_t)qa : (uint32_t)qb) + l5;

@@ -106,6 +106,18 @@ __global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict
         const uint64_t q = (lane < 32u ? qa : qb) + l5;
         const uint32_t pa = ((uint32_t)(a.row_id_base + A.r0) & 1u) + lane, pb = ((uint32_t)(a.row_id_base + B.r0) & 1u) + lane;
         const int sa = (int)((pa >> 1) << 2), sb = (int)((32u + (pb >> 1)) << 2);
+        if (one_key && (((a.row_id_base + A.r0) | (a.row_id_base + B.r0)) & 1u) == 0) { // both tiles start on an even row id: hand-out by DPP (k_sample_sell)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                uint32_t x0 = ((lane & 1u) ? (uint32_t)qb : (uint32_t)qa) + (lane >> 1), x1 = a.iter;
+                philox2x32_10(x0, x1, stream2_key(a.seed, a.chain + (uint32_t)c, TAG_ROW, (uint32_t)(qa >> 32)));
+                const uint32_t n0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)x0, 0xB1, 0xF, 0xF, true);
+                const uint32_t n1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)x1, 0xB1, 0xF, 0xF, true);
+                xrowA[c] = (lane & 1u) ? n1 : x0;
+                xrowB[c] = (lane & 1u) ? x1 : n0;
+            }
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             uint32_t x0 = (uint32_t)q, x1 = a.iter;
