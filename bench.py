@@ -19,7 +19,7 @@ roofline (K1 = k_sample_sell, the dominant kernel; the same block for the chain-
   pattern_read_peak_gbs   what a pure read with K1's access pattern reaches on this part (tools/stream_bench.hip: 6.5-6.7 TB/s)
   algorithmic_x_peak      SURVEY 8(d)'s figure: bytes of the u32 CSR / time / 8 TB/s.  The kernel streams a 1.1 byte-per-hit encoding of
                that CSR, so this exceeds 1 -- it says how much faster than a CSR-streaming kernel at the HBM roofline this is
-  valu         counted VALU instructions x 4.3 clocks (tools/issue_bench.hip: what a wave64 VALU instruction of K1's mix occupies its
+  valu         counted VALU instructions x 4.0 clocks (tools/issue_bench.hip: what a wave64 VALU instruction of K1's mix occupies its
                SIMD for) / (1024 SIMDs x effective clock x time); effective_clock_ghz = GRBM_GUI_ACTIVE / 8 XCDs / time
   lds          SQ_LDS_IDX_ACTIVE / 256 CUs / kernel cycles
 
@@ -40,9 +40,11 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 PATTERN_READ_PEAK_GBS = 6600.0   # tools/stream_bench.hip on MI355X: single-wave workgroups reading contiguous ranges of 1.5 KB blocks
-VALU_CLOCKS_PER_INST = 4.3   # tools/issue_bench.hip (profiles/r03_issue_bench.txt): VOP3 / fp64 / compare / SDWA / 32-bit multiply
-                             # instructions occupy their SIMD for 4.2-4.5 clocks per wave64 instruction, and in a mixed stream the
-                             # cheap VOP1 / VOP2 class (2.3-2.9 clocks alone) costs the same; v_mad_u64_u32 5.1
+VALU_CLOCKS_PER_INST = 4.0   # tools/issue_bench.hip (profiles/r04_issue_bench.txt; waves grouped by the SIMD they ran on, s_memtime = shader
+                             # cycles): fp64 / VOP3 / SDWA / compares / conversions / 32-bit multiplies occupy their SIMD for 4.1-4.2 cycles per
+                             # wave64 instruction, plain 32-bit VOP1 / VOP2 2.1-2.4 alone and about 3.6 in a mix with the other class.  Three
+                             # quarters of K1's VALU instructions are of the first class: 4.0 on average, which is also what the hardware's own
+                             # SQ_ACTIVE_INST_VALU charges (one quad-cycle per instruction)
 # everything that decides what the kernels do and how they are launched: sources of the device code, the host code that lays the
 # problem out and picks grids and ranges, and the build flags
 KERNEL_SOURCES = ["mmg_math.h", "mmg_types.h", "gibbs_kernels.h", "sell_kernels.h", "sell_multi_kernels.h", "em_kernels.h", "k1.hip", "em.hip",

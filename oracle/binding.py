@@ -288,7 +288,8 @@ SELL_WIN = 255  # transcripts per LDS window (mmg_types.h)
 
 
 def row_keys(row_ptr, col_idx, k=None):
-    """(key, tie) per row: key = !near << 63 | band << 18 | kclass << 16 | (kclass == 1 ? k : 0) << 9 | min(len, 0x1ff) (0 for an empty row), band = the band
+    """(key, tie) per row: key = !near << 63 | band << 18 | kclass << 16 | (kclass == 1 ? k : k_bucket(k)) << 9 | min(len, 0x1ff) (0 for an empty
+    row); kclass 0 (k <= 1), 1 (k <= K_SMALL), 2 (above, k categorical draws), 3 (conditional-binomial chain); band = the band
     of the smallest hit for a near row, the home band (one below the band of hit[(len - 1) // 2]) for a far row;
     tie = csum << 48 | hash >> 16, hash = fold of (len, k, hits in stored order), csum = sum of (hit - 64 * band) over the hits inside
     [64 * band, 64 * band + SELL_WIN).  Spec: mmseq_amd/csrc/mmg_types.h."""

@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import torch
 from mmseq_amd import Problem, Sampler
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 1
