@@ -277,7 +277,10 @@ hipError_t layout_expand_rows(uint64_t *m_io, uint64_t *nnz_io, uint64_t **d_rp,
     X_TRY(layout_scan_lens(m, reps, first, s));
     uint64_t m_new = 0;
     X_TRY(hipMemcpy(&m_new, first + m, 8, hipMemcpyDeviceToHost));
-    if (m_new >= 0xffffffffull) return done(hipErrorInvalidValue); // reported by the caller: too many stored rows for one device
+    // A heavily collapsed file would be un-collapsed by this step: beyond LAYOUT_EXPAND_MAX_RATIO x the rows (or the row limit of one
+    // device) the rows keep their multiplicities and the multiplicity kernel draws for them (k categoricals per row, the same draws).
+    // The rule depends on the set of rows only, like everything else of the stored order.
+    if (m_new > LAYOUT_EXPAND_MAX_RATIO * m || m_new >= 0xffffffffull) return done(hipSuccess);
     X_TRY(hipMalloc((void **)&len_new, m_new * 4));
     X_TRY(hipMalloc((void **)&k_new, m_new * 4));
     X_TRY(hipMalloc((void **)&src, m_new * 4));

@@ -35,6 +35,8 @@ MMG_TYPES_HD inline uint32_t k_bucket(uint32_t k)
 //           collapsed hits file carries (src/mmseq.cpp:409-418) -- then run on the register path and in fused chain pairs like any
 //           other read, instead of through the multiplicity kernel (50M-read file shape: 0.39 -> 0.34 ms per sweep, 8 chains 2.5k ->
 //           4.0k chain-iterations/s); an all-ones k array is dropped.  Rows with k > K_SMALL (conditional-binomial chain) and k = 0 stay.
+//           The step is skipped when it would store more than LAYOUT_EXPAND_MAX_RATIO rows per uploaded row (a heavily collapsed file
+//           would be un-collapsed: memory and work would scale with the reads again) or 2^32 rows: such rows keep their k.
 //   lead    = smallest transcript of the row >> LAYOUT_BAND_SHIFT       (bands of 64 consecutive transcripts)
 //   near    = every hit of the row lies in [lead * 64, lead * 64 + LAYOUT_NEAR_SPAN) and the row has <= 255 hits
 //   band    = lead for a near row; for a far row its HOME band: max(median hit >> LAYOUT_BAND_SHIFT, 1) - 1 (lower median,
@@ -52,6 +54,7 @@ MMG_TYPES_HD inline uint32_t k_bucket(uint32_t k)
 // A tile of the sliced-ELL stream never crosses a (near, band) boundary.  Near tiles: all hits fall into ONE 255-wide LDS window
 // starting at band * 64, rows of (nearly) equal lengths.  Far tiles: the window part of every row is encoded exactly like a near
 // tile, the other hits are transcript ids in a per-lane far list behind it.
+constexpr uint64_t LAYOUT_EXPAND_MAX_RATIO = 8; // step 0 happens only while it stores at most this many rows per row of the upload
 constexpr uint32_t LAYOUT_BAND_SHIFT = 6;
 constexpr uint32_t LAYOUT_NEAR_SPAN = 240;
 constexpr uint32_t SELL_WIN = 255;          // transcripts per window; slot 255 holds 0.0

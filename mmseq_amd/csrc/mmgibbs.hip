@@ -473,9 +473,7 @@ static int problem_build(mmg_problem *p, uint64_t *d_rp64)
     if (p->m && p->layout == (int)MMG_LAYOUT_CANONICAL && p->d_k) {
         // a row with 2 <= k <= K_SMALL is stored as k rows with k = 1: identical reads then run on the register path like any
         // other read, instead of through the multiplicity kernel (mmg_types.h)
-        hipError_t ex = layout_expand_rows(&p->m, &p->nnz, &d_rp64, &p->d_col, &p->d_k, 16, 0);
-        if (ex == hipErrorInvalidValue) return bail(fail(MMG_ERR_ARG, "the canonical layout stores rows with 2 <= k <= 64 as k rows: more than 2^32 stored rows on one device"));
-        B_TRY(ex);
+        B_TRY(layout_expand_rows(&p->m, &p->nnz, &d_rp64, &p->d_col, &p->d_k, 16, 0));
     }
     if (p->m) {
         B_TRY(hipMalloc((void **)&d_key, p->m * sizeof(uint64_t)));

@@ -281,6 +281,7 @@ def sokal_ref(x):
 LAYOUT_BAND_SHIFT = 6
 LAYOUT_NEAR_SPAN = 240
 K_SMALL = 64
+LAYOUT_EXPAND_MAX_RATIO = 8
 K_DRAWS_PER_HIT = 16
 
 
@@ -374,6 +375,8 @@ def canonical_layout(row_ptr, col_idx, k=None):
         # step 0 (ABI 4): a row with 2 <= k <= K_SMALL is stored as k rows with k = 1; an array of ones is no array
         kk0 = np.asarray(k).astype(np.int64)
         reps = np.where((kk0 >= 2) & (kk0 <= K_SMALL), kk0, 1)
+        if int(reps.sum()) > LAYOUT_EXPAND_MAX_RATIO * kk0.size or int(reps.sum()) >= 0xffffffff:
+            reps = np.ones_like(reps)          # a heavily collapsed file is not un-collapsed (mmg_types.h: LAYOUT_EXPAND_MAX_RATIO): the rows keep their k
         if (reps > 1).any():
             src = np.repeat(np.arange(kk0.size, dtype=np.int64), reps)
             row_ptr, col_sorted, k = permute_rows(row_ptr, col_sorted, np.where(reps > 1, 1, kk0).astype(np.uint32), src)

@@ -371,3 +371,30 @@ def test_synth_hits_writes_the_generator_rows_and_the_cli_runs_on_them(tmp_path,
     ids, rows = _trace_file(out + ".trace_gibbs.gz")
     assert ids == e["ingest"]["index_sid"]
     assert rows == [[H.fmt6(v) for v in e["trace"][:, s]] for s in range(1024)]
+
+
+@pytest.mark.gpu
+def test_two_devices_give_the_output_of_one(tmp_path, gpu):
+    """`mmseq -gpus 2` (one chain: the stored rows cut into two read shards by measured cost, EM and Gibbs sharded over RCCL; and with
+    -em_one_device the EM on the first device alone) writes the files `mmseq -gpus 1` writes, byte for byte -- integer all-reduces and
+    keyed random streams: src/mmseq.cpp:864, :893-899 across devices.  Needs two HIP devices (the boxes of this pool have one: skipped
+    there; the same arithmetic runs on one device in tests/test_gpu_parity.py and tests/test_gpu_config4.py)."""
+    if gpu.device_count() < 2:
+        pytest.skip("needs two HIP devices")
+    h = dataset()
+    p = tmp_path / "in.hits"
+    p.write_bytes(H.write_hits_binary(h))
+    outs = {}
+    for tag, flags in (("one", []), ("two", ["-gpus", "2"]), ("two_em1", ["-gpus", "2", "-em_one_device"])):
+        o = str(tmp_path / tag)
+        r = run(["-gibbs_iter", "1024", "-seed", "5"] + flags + [str(p), o], timeout=600)
+        assert r.returncode == 0, r.stderr.decode()
+        outs[tag] = o
+    for ext in (".mmseq", ".identical.mmseq", ".gene.mmseq", ".k", ".M"):
+        a = open(outs["one"] + ext, "rb").read()
+        assert a == open(outs["two"] + ext, "rb").read(), ext
+        assert a == open(outs["two_em1"] + ext, "rb").read(), ext
+    for ext in (".trace_gibbs.gz", ".gene.trace_gibbs.gz", ".identical.trace_gibbs.gz", ".prop.trace_gibbs.gz"):
+        a = gzip.open(outs["one"] + ext, "rb").read()
+        assert a == gzip.open(outs["two"] + ext, "rb").read(), ext
+        assert a == gzip.open(outs["two_em1"] + ext, "rb").read(), ext

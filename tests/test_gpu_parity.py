@@ -459,6 +459,31 @@ def test_sharded_chain_on_one_device_equals_the_unsharded_chain(gpu, orc, parts)
     whole.close(); prob.close()
 
 
+def test_a_heavily_collapsed_file_is_not_uncollapsed(gpu, orc):
+    """Rows with 2 <= k <= 64 are stored k times (step 0 of the canonical layout) -- unless that would store more than 8 rows per uploaded
+    row: a file whose hit sets are shared by dozens of reads each keeps its multiplicities (memory and work stay with the hit sets, not
+    the reads) and the multiplicity kernel draws the same k categoricals per row.  Stored order = the oracle's restatement, chain = the
+    oracle's, on both sides of the limit."""
+    rng = np.random.default_rng(21)
+    p, _ = orc.synth_problem(R=30000, T=4000, avg_hits=6, seed=17, sort=False, far_fraction=0.05)
+    mu0 = rng.gamma(0.6, 1.0, size=p.n)
+    for lo, hi, expanded in ((30, 64, False), (1, 12, True)):
+        k = rng.integers(lo, hi + 1, size=p.m).astype(np.uint32)
+        prob = gpu.Problem.from_csr(p.row_ptr, p.col_idx, p.l, k=k)
+        rp, ci, kk = prob.download(with_k=True)
+        c_rp, c_ci, c_k, _ = orc.canonical_layout(p.row_ptr, p.col_idx, k)
+        assert np.array_equal(rp, c_rp) and np.array_equal(ci, c_ci)
+        assert (prob.info.m == int(k.sum())) == expanded and (prob.info.m == p.m) == (not expanded)
+        assert np.array_equal(kk, c_k if c_k is not None else np.ones(rp.size - 1, np.uint32))
+        assert prob.info.total_k == int(k.sum())
+        s = gpu.Sampler(prob, mu0, seed=4, gibbs_iter=5, trace_len=5)
+        s.run(5)
+        ref = orc.gibbs_keyed(orc.Problem(rp, ci, p.l, k=(None if c_k is None else kk)), mu0, seed=4, n_iter=5, trace_len=5)
+        assert np.array_equal(s.trace(0), ref["trace"]) and np.array_equal(s.counts(0), ref["cnt"])
+        assert int(s.counts(0).astype(np.int64).sum()) == int(k.sum())
+        s.close(); prob.close()
+
+
 @pytest.mark.parametrize("kernel", [2, 0])
 def test_replicated_count_vectors_give_the_same_bits(gpu, orc, kernel):
     """K1's workgroups flush their LDS counts into one of CNT_REPLICAS global vectors (workgroup index mod 8: neighbouring ranges meet at
