@@ -341,10 +341,19 @@ def main():
                          % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    # one rank per GPU; MMSEQ_BENCH_BACKEND=gloo lets several ranks share the devices present (a functional check of the N > 1 paths on a
+    # one-GPU box: the collectives then go through the host, the numbers mean nothing)
+    backend = os.environ.get("MMSEQ_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d has no GPU of its own (%d visible)" % (local_rank, torch.cuda.device_count()))
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     # ---- workload (synthetic, generated straight into device CSR and laid out by the library; not timed)
     shard_rows = None
@@ -356,7 +365,10 @@ def main():
         total_reads = args.rows * world
         full = Problem.synthetic(total_reads, args.transcripts, args.avg_hits, seed=args.seed, mapped_reads=total_reads, device=local_rank)
         mu0, _ = full.start_values()
-        b = full.shard_bounds(world)
+        # the cut by MEASURED cost (mmg_problem_shard_bounds_timed), taken on rank 0's device and broadcast: the ranks must agree on it
+        bt = torch.from_numpy(full.shard_bounds_timed(mu0, world).astype(np.int64) if rank == 0 else np.zeros(world + 1, np.int64)).cuda()
+        dist.broadcast(bt, src=0)
+        b = bt.cpu().numpy().astype(np.uint64)
         shard_rows = [int(b[i + 1] - b[i]) for i in range(world)]
         prob = full.shard(int(b[rank]), int(b[rank + 1]), device=local_rank)
         full.close()
@@ -469,7 +481,7 @@ def main():
                        "avg_hits_per_read": args.avg_hits, "chains_per_gpu": C, "mode": args.mode,
                        "parallelism": ("%d independent chains (1 all-reduce of posterior moments)" % chains_total)
                        if args.mode == "chains" else ("read-sharded single chain over %d GPUs (int32 count all-reduce per iteration), "
-                                                      "one canonical problem cut by modelled cost" % world),
+                                                      "one canonical problem cut by measured cost" % world),
                        "trace": "every iteration kept (fp64 mu trace resident in HBM)", "generator_seed": args.seed,
                        "layout": "generator order in, the library's canonical order stored (device radix sort)",
                        "settle_iters": args.settle_iters, "cold_ms_per_step": cold_ms},
