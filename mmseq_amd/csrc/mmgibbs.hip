@@ -547,7 +547,9 @@ extern "C" int mmg_problem_create(const mmg_problem_desc *d, int device, mmg_pro
             std::vector<uint64_t> edges;
             hipError_t e = order_cooccurrence_edges(p->idx64, p->m, p->nnz, p->d_row_ptr, p->d_col, edges, 0); // (no tx_order: device ids are the caller's)
             if (e != hipSuccess) { problem_free(p); return fail(MMG_ERR_HIP, std::string("transcript order from the hit graph: ") + hipGetErrorString(e)); }
-            if (!edges.empty()) {
+            // (a graph in which the average transcript shares rows with more than 1024 others has no band to find: hits drawn all over
+            // the transcriptome -- the level structures of 10^8 edges would only cost host time before the result is discarded)
+            if (!edges.empty() && edges.size() <= (uint64_t)d->n * 1024) {
                 std::vector<uint32_t> pos;
                 order_from_edges(d->n, edges, pos);
                 std::vector<uint64_t>().swap(edges);

@@ -7,10 +7,10 @@
 //   device   a content-hash sample of the rows (a pure function of the SET of rows: the order does not depend on how the caller
 //            delivered them) emits, per row, the edges between its smallest transcript and its other transcripts, both directions;
 //            radix sort + unique leave the adjacency lists of the co-occurrence graph, sorted (rocPRIM)
-//   host     a breadth-first level structure per connected component from a pseudo-peripheral vertex (George & Liu), every level
-//            ordered by how many neighbours a vertex has in the levels before it (most first), then degree, then index: the
-//            Cuthill-McKee idea with the within-level order a banded graph needs -- rows of transcripts that lie within +-64 of each
-//            other in SOME order come back within an LDS window of each other
+//   host     a breadth-first level structure per connected component from a pseudo-peripheral vertex (George & Liu), hubs left out,
+//            every level ordered by (first parent, number of parents, degree, index): the Cuthill-McKee idea with the within-level
+//            order a banded graph needs -- rows of transcripts that lie within +-64 of each other in SOME order come back within an
+//            LDS window of each other, and the transcripts of a gene family next to each other
 // The result is used exactly like a caller's tx_order; nothing crossing the ABI changes numbering.
 #include <algorithm>
 #include <cstdint>
@@ -114,6 +114,12 @@ hipError_t order_cooccurrence_edges(bool idx64, uint64_t m, uint64_t nnz, const 
 }
 
 // Position of every transcript in the derived order: pos[t] for t < n (a permutation of 0..n-1).  edges: sorted unique u << 32 | v.
+//   hubs       a transcript that shares rows with far more others than is usual (more than max(256, 8 x the median degree of the linked
+//              transcripts): a repeat element, a ubiquitous paralogue) would tie every gene family into one component whose level
+//              structure fans out from it; it is left out of the traversal and placed behind everything (its rows get a far hit)
+//   a level    is ordered by (position of the FIRST parent in the level before it, number of parents: most first, degree, index): the
+//              children of one parent stay together -- gene families, trees -- and in a band every vertex has its own first parent
+//              (the vertex 64 before it), which puts the level in the order of the band
 void order_from_edges(uint32_t n, const std::vector<uint64_t> &edges, std::vector<uint32_t> &pos)
 {
     std::vector<uint64_t> ptr(n + 1, 0);
@@ -121,8 +127,18 @@ void order_from_edges(uint32_t n, const std::vector<uint64_t> &edges, std::vecto
     for (uint32_t v = 0; v < n; ++v) ptr[v + 1] += ptr[v];
     auto deg = [&](uint32_t v) { return (uint32_t)(ptr[v + 1] - ptr[v]); };
     auto nb = [&](uint64_t i) { return (uint32_t)edges[i]; };          // edges are sorted by u: the adjacency list of u is a slice
+    uint32_t hub_deg = 256;
+    {
+        std::vector<uint32_t> dd;
+        for (uint32_t v = 0; v < n; ++v) if (deg(v)) dd.push_back(deg(v));
+        if (!dd.empty()) {
+            std::nth_element(dd.begin(), dd.begin() + dd.size() / 2, dd.end());
+            hub_deg = std::max<uint32_t>(256u, 8u * dd[dd.size() / 2]);
+        }
+    }
     std::vector<uint32_t> stamp(n, 0), level, next, order;
-    std::vector<uint8_t> placed(n, 0);
+    std::vector<uint8_t> placed(n, 0);                                  // 1 placed, 2 hub (not traversed)
+    for (uint32_t v = 0; v < n; ++v) if (deg(v) > hub_deg) placed[v] = 2;
     order.reserve(n);
     uint32_t epoch = 0;
     // levels of a BFS from `root` inside the unplaced part of its component; returns the number of levels and the min-degree vertex of the last
@@ -145,7 +161,7 @@ void order_from_edges(uint32_t n, const std::vector<uint64_t> &edges, std::vecto
     std::vector<uint32_t> by_degree(n);
     for (uint32_t v = 0; v < n; ++v) by_degree[v] = v;
     std::stable_sort(by_degree.begin(), by_degree.end(), [&](uint32_t a, uint32_t b) { return deg(a) < deg(b); });
-    std::vector<uint32_t> seen_nb(n, 0);                                // neighbours of v already placed
+    std::vector<uint32_t> parents(n, 0), first_parent(n, 0);            // parents of v in the level before it, and the first of them (its index in that level)
     for (uint32_t cand : by_degree) {
         if (placed[cand] || deg(cand) == 0) continue;
         // pseudo-peripheral start: walk to a farthest vertex while the eccentricity grows
@@ -156,20 +172,22 @@ void order_from_edges(uint32_t n, const std::vector<uint64_t> &edges, std::vecto
             if (e2 <= ecc) break;
             root = far; ecc = e2; far = far2;
         }
-        // level structure from the root, every level ordered by (placed neighbours: most first, degree, index)
         level.assign(1, root);
         placed[root] = 1;
         while (!level.empty()) {
             for (uint32_t u : level) order.push_back(u);
             next.clear();
-            for (uint32_t u : level)
+            for (uint32_t iu = 0; iu < (uint32_t)level.size(); ++iu) {
+                const uint32_t u = level[iu];
                 for (uint64_t i = ptr[u]; i < ptr[u + 1]; ++i) {
                     const uint32_t v = nb(i);
                     if (placed[v]) continue;
-                    if (seen_nb[v]++ == 0) next.push_back(v);
+                    if (parents[v]++ == 0) { first_parent[v] = iu; next.push_back(v); }
                 }
+            }
             std::sort(next.begin(), next.end(), [&](uint32_t a, uint32_t b) {
-                if (seen_nb[a] != seen_nb[b]) return seen_nb[a] > seen_nb[b];
+                if (first_parent[a] != first_parent[b]) return first_parent[a] < first_parent[b];
+                if (parents[a] != parents[b]) return parents[a] > parents[b];
                 if (deg(a) != deg(b)) return deg(a) < deg(b);
                 return a < b;
             });
@@ -177,7 +195,7 @@ void order_from_edges(uint32_t n, const std::vector<uint64_t> &edges, std::vecto
             level.swap(next);
         }
     }
-    for (uint32_t v = 0; v < n; ++v) if (!placed[v]) order.push_back(v);  // transcripts that share no row with another: anywhere
+    for (uint32_t v = 0; v < n; ++v) if (placed[v] != 1) order.push_back(v);  // hubs, and transcripts that share no row with another: anywhere
     pos.assign(n, 0);
     for (uint32_t i = 0; i < n; ++i) pos[order[i]] = i;
 }

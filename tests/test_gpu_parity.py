@@ -459,6 +459,56 @@ def test_sharded_chain_on_one_device_equals_the_unsharded_chain(gpu, orc, parts)
     whole.close(); prob.close()
 
 
+def test_derived_order_on_graphs_without_a_band(gpu, orc):
+    """The order derived from the hit graph (spec version 6) is kept only when the model prices the rebuilt problem a fifth lower, and is
+    not even attempted on a graph without locality: hits drawn uniformly over the transcripts stay on the CSR-tile kernel in the
+    caller's numbering; disconnected gene families in random numbering (the shape of a real transcriptome: small components, plus
+    transcripts no read hits and one hub that shares rows with everything) are laid out component by component -- and every chain
+    is the oracle's replay of the downloaded rows."""
+    rng = np.random.default_rng(2)
+    u, _ = orc.synth_problem(R=120000, T=30000, avg_hits=8, seed=3, uniform=True, sort=False)
+    pu = gpu.Problem.from_csr(u.row_ptr, u.col_idx, u.l)
+    assert pu.info.sample_kernel == 0 and pu.info.tx_renumbered == 0
+    pu.close()
+    # 3000 gene families of 2..9 transcripts, numbered at random; reads hit 1..6 transcripts of one family; a hub in 1 % of the reads
+    T = 16000
+    ids = rng.permutation(T - 500)                      # the last 500 ids: transcripts without any read
+    fams, i = [], 0
+    while i < ids.size:
+        sz = int(rng.integers(2, 10))
+        fams.append(ids[i:i + sz]); i += sz
+    hub = int(ids[0])
+    rows = []
+    for _ in range(150000):
+        f = fams[int(rng.integers(len(fams)))]
+        r = rng.choice(f, size=int(rng.integers(1, min(6, f.size) + 1)), replace=False).tolist()
+        if rng.random() < 0.01 and hub not in r:
+            r.append(hub)
+        rows.append(sorted(r))
+    rp = np.cumsum([0] + [len(r) for r in rows]).astype(np.uint64)
+    ci = np.concatenate([np.asarray(r, np.uint32) for r in rows])
+    l = rng.uniform(0.2, 3.0, T)
+    with gpu.options(derive_order=0):
+        p0 = gpu.Problem.from_csr(rp, ci, l)
+        k0 = p0.info.sample_kernel
+        p0.close()
+    p1 = gpu.Problem.from_csr(rp, ci, l)
+    inf = p1.info
+    assert k0 == 0 and inf.sample_kernel == 2 and inf.tx_renumbered == 2 and inf.fast_tiles + inf.far_tiles >= 0.95 * inf.n_tiles
+    perm = p1.tx_perm()
+    for f in fams[:200]:                                # a family's transcripts end up within an LDS window of each other
+        if hub in f:
+            continue
+        assert int(perm[f].max()) - int(perm[f].min()) < 240, (f, perm[f])
+    d_rp, d_ci = p1.download()
+    mu0, _ = p1.start_values()
+    s = gpu.Sampler(p1, mu0, seed=9, gibbs_iter=6, trace_len=6)
+    s.run(6)
+    ref = orc.gibbs_keyed(orc.Problem(d_rp, d_ci, l), mu0, seed=9, n_iter=6, trace_len=6)
+    assert np.array_equal(s.trace(0), ref["trace"]) and np.array_equal(s.counts(0), ref["cnt"])
+    s.close(); p1.close()
+
+
 def test_a_heavily_collapsed_file_is_not_uncollapsed(gpu, orc):
     """Rows with 2 <= k <= 64 are stored k times (step 0 of the canonical layout) -- unless that would store more than 8 rows per uploaded
     row: a file whose hit sets are shared by dozens of reads each keeps its multiplicities (memory and work stay with the hit sets, not
