@@ -175,10 +175,10 @@ def test_analytic_posteriors_on_the_device(gpu):
     summ = gpu.Summary(s, chain=0)
     assert 0.7 < summ.series(gpu.SERIES_TRANSCRIPT)["tau"][0] < 1.4           # iid => iact ~ 1
     summ.close(); s.close(); prob.close()
-    # (2) one row {A, B} with k = 60 (stored as 60 rows), alpha = 3
+    # (2) one row {A, B} with k = 60, alpha = 3
     S2 = 16384
     prob = _tiny(gpu, [[0, 1]], [60], [1.0, 1.0])
-    assert prob.info.m == 60
+    assert prob.info.m == 1                   # (60 stored rows per uploaded row is beyond the expansion limit of 8: the row keeps k = 60 and draws 60 categoricals)
     s = gpu.Sampler(prob, np.ones(2), seed=6, alpha=3.0, gibbs_iter=S2, trace_len=S2)
     s.run(S2)
     tr = s.trace(0)

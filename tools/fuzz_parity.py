@@ -36,6 +36,8 @@ def one_case(seed, gpu, orc, verbose=True):
     if rng.integers(0, 3) == 0: opts["em_grid"] = int(rng.integers(1, 9))
     if rng.integers(0, 3) == 0: opts["em_kernel"] = 0
     if rng.integers(0, 4) == 0: opts["fuse_chains"] = int(rng.choice([1, 4]))
+    if rng.integers(0, 2) == 0: opts["cnt_replicas"] = int(rng.choice([1, 8]))     # one count vector per chain / eight (K2 sums them)
+    if rng.integers(0, 3) == 0: opts["derive_order"] = int(rng.choice([0, 1]))     # never / always try an order from the hit graph
     keep_rows = bool(rng.integers(0, 3) == 0)
     tx_order = None
     if rng.integers(0, 3) == 0:                          # device renumbering: random gene sizes over a random scatter
