@@ -653,37 +653,32 @@ int main(int argc, char **argv)
         if (l[t] <= 0) { cerr << "Error: transcript '" << sid(t) << "' has a length of zero.\n"; exit(1); }
     }
 
-    // ---- start values and the shared-count histogram (src/mmseq.cpp:610-638); host, deterministic
-    //      Every thread owns a range of transcripts and walks all rows: a transcript's shares are added in row order whatever the
-    //      thread count (the reference's order), and the walk is a stream of the hit list.
-    //      The pass runs on a thread of its own next to what follows -- the unique-hit counts, the .k / .M writer, the device problem
-    //      -- and is waited for where its results are first needed: the start of the EM (and -debug's .sharedcounts).
-    vector<vector<int>> counts_shared(n, vector<int>(100, 0));
+    // ---- start values and unique hits (src/mmseq.cpp:610-638) come from the device once the problem is there
+    //      (mmg_problem_start_values: the shares k_i / |row i| summed EXACTLY in fixed point -- the reference adds them in floating point
+    //      in the order it read the file, so its start value depends on that order in the last bits; this one is a function of the hit
+    //      sets).  The 100-bin histogram of shared counts is only ever written by -debug (.sharedcounts): a host pass, then.
+    vector<vector<int>> counts_shared;
     vector<double> mu(n, 0.0);
-    std::thread start_values([&]() {
+    vector<int32_t> unique_hits(n, 0);
+    if (debug) {
+        counts_shared.assign(n, vector<int>(100, 0));
 #pragma omp parallel num_threads(max(1, min(8, omp_get_max_threads() / 2))) // every thread reads the whole hit list: more only adds traffic
-    {
-        const uint64_t nth = (uint64_t)omp_get_num_threads(), tid = (uint64_t)omp_get_thread_num();
-        const uint32_t lo = (uint32_t)((uint64_t)n * tid / nth), hi = (uint32_t)((uint64_t)n * (tid + 1) / nth);
-        if (lo < hi)
-            for (uint64_t i = 0; i < m; ++i) {
-                const uint64_t b = row_ptr[i], e = row_ptr[i + 1];
-                const int L = (int)(e - b);
-                const double share = (double)k[i] / L;
-                for (uint64_t j = b; j < e; ++j) {
-                    const uint32_t c = col_idx[j];
-                    if (c - lo < hi - lo) {
-                        mu[c] += share;
-                        counts_shared[c][min(L, 100) - 1] += (int)k[i];
+        {
+            const uint64_t nth = (uint64_t)omp_get_num_threads(), tid = (uint64_t)omp_get_thread_num();
+            const uint32_t lo = (uint32_t)((uint64_t)n * tid / nth), hi = (uint32_t)((uint64_t)n * (tid + 1) / nth);
+            if (lo < hi)
+                for (uint64_t i = 0; i < m; ++i) {
+                    const uint64_t b = row_ptr[i], e = row_ptr[i + 1];
+                    const int L = (int)(e - b);
+                    for (uint64_t j = b; j < e; ++j) {
+                        const uint32_t c = col_idx[j];
+                        if (c - lo < hi - lo) counts_shared[c][min(L, 100) - 1] += (int)k[i];
                     }
                 }
-            }
+        }
     }
-    for (uint32_t t = 0; t < n; ++t) mu[t] /= l[t];
-    });
-    struct JoinStart { std::thread &t; void now() { if (t.joinable()) t.join(); } ~JoinStart() { now(); } } start_values_join{start_values};
 
-    stage.mark("l (start values, histogram: in the background)");
+    stage.mark("l");
     // ---- unique hits to identical sets and genes: O(nnz) form of src/uh.cpp:3-26
     vector<int> identical_unique_hits(identical_transcripts.size(), 0), gene_unique_hits(gene2transcripts.size(), 0);
     {
@@ -788,7 +783,6 @@ int main(int argc, char **argv)
     g_background_writer = &km_writer;
 
     if (debug) { // src/mmseq.cpp:697-731
-        start_values_join.now();
         ofs.open((output_base + ".sharedcounts").c_str());
         for (auto &name : transcriptList) {
             ofs << name << "\t";
@@ -852,8 +846,8 @@ int main(int argc, char **argv)
     }
 
     stage.mark("device problem build");
-    start_values_join.now();
-    stage.mark("wait for the start values");
+    MMG_TRY(mmg_problem_start_values(prob, mu.data(), unique_hits.data()));
+    stage.mark("start values, unique hits (device)");
     // ---- several devices: the stored problem (canonical order, device numbering) is cut into contiguous read shards, one per device
     //      (one chain: EM and Gibbs both run sharded), or replicated (chains >= devices).  Cut on device 0 and copied device to
     //      device (mmg_problem_shard): nothing comes back to the host.
@@ -995,14 +989,17 @@ int main(int argc, char **argv)
         MMG_TRY(mmg_summary_begin(smp, &sd, &summ));
     }
     const size_t nV = simuIndex.size();
+    // (the writers outlive the loop: they are joined after the tables are written -- the tail of their work runs next to the summary
+    // columns and the tables instead of in front of them)
+    std::mutex ready_mu;
+    std::condition_variable ready_cv;
+    int samples_ready = 0;                           // samples whose rows may be fetched (trace and derived traces)
+    auto wait_for = [&](int upto) { std::unique_lock<std::mutex> lk(ready_mu); ready_cv.wait(lk, [&] { return samples_ready >= upto; }); };
+    const int writer_threads = max(1, omp_get_max_threads());
+    const int t_big = max(1, (writer_threads - 1) * 9 / 20), t_gene = max(1, writer_threads / 10);
+    std::thread w_trace, w_ident, w_gene, w_prop;
     {
-        std::mutex ready_mu;
-        std::condition_variable ready_cv;
-        int samples_ready = 0;                       // samples whose rows may be fetched (trace and derived traces)
-        auto wait_for = [&](int upto) { std::unique_lock<std::mutex> lk(ready_mu); ready_cv.wait(lk, [&] { return samples_ready >= upto; }); };
-        const int T = max(1, omp_get_max_threads());
-        const int t_big = max(1, (T - 1) * 9 / 20), t_gene = max(1, T / 10);
-        std::thread w_trace([&]() {
+        w_trace = std::thread([&]() {
             GzText gz(output_base + ".trace_gibbs.gz");
             for (uint32_t t = 0; t < n; t++) { gz.str(sid(t)); gz.str(" "); }
             gz.str("\n");
@@ -1010,7 +1007,7 @@ int main(int argc, char **argv)
                              [](size_t) { return true; }, t_big);
             gz.close();
         });
-        std::thread w_ident([&]() {
+        w_ident = std::thread([&]() {
             // a set whose first summed sample has no finite logarithm is left out of its trace file (:1040)
             wait_for(1);
             vector<double> firstI(max<size_t>(nI, 1));
@@ -1031,7 +1028,7 @@ int main(int argc, char **argv)
                              [&](size_t v) { return keepI[v] != 0; }, 1);
             gi.close();
         });
-        std::thread w_gene([&]() {
+        w_gene = std::thread([&]() {
             wait_for(1);                             // (:1068: the same rule for genes)
             vector<double> firstG(max<size_t>(nG, 1));
             MMG_TRY(mmg_summary_get_rows(summ, MMG_SERIES_GENE, 0, 1, firstG.data()));
@@ -1044,7 +1041,7 @@ int main(int argc, char **argv)
                              [&](size_t g) { return keepG[g] != 0; }, t_gene);
             gg.close();
         });
-        std::thread w_prop([&]() {
+        w_prop = std::thread([&]() {
             GzText gp(output_base + ".prop.trace_gibbs.gz");
             for (uint32_t t = 0; t < n; t++) { gp.str(sid(t)); gp.str(" "); }
             gp.str("\n");
@@ -1068,8 +1065,6 @@ int main(int argc, char **argv)
         }
         cout << "Gibbs iteration " << gibbs_iter - 1 << "       \r" << endl;
         stage.mark("Gibbs (trace files written alongside)");
-        w_trace.join(); w_ident.join(); w_gene.join(); w_prop.join();
-        stage.mark("trace files: the rest");
     }
     // moments of log mu pooled over all chains and devices (one fp64 all-reduce): log_mu, sd and mcse of multi-chain runs
     vector<double> pooled_sl, pooled_sl2;
@@ -1093,10 +1088,16 @@ int main(int argc, char **argv)
     //      are the per-series columns -- percentiles, log means, Sokal -- of which only the columns come back.
     MMG_TRY(mmg_summary_finish(summ));
     stage.mark("device summary");
-    for (auto sp : smps) mmg_sampler_destroy(sp);
-    for (auto pp : dprob) mmg_problem_destroy(pp);
-    mmg_problem_destroy(prob);
-    if (grp) mmg_group_destroy(grp);
+    // (the trace writer still reads rows of the sampler, the derived-trace writers rows of the summary: both are released once the
+    // writers are done, behind the tables)
+    auto release_device = [&]() {
+        w_trace.join(); w_ident.join(); w_gene.join(); w_prop.join();
+        mmg_summary_destroy(summ);
+        for (auto sp : smps) mmg_sampler_destroy(sp);
+        for (auto pp : dprob) mmg_problem_destroy(pp);
+        mmg_problem_destroy(prob);
+        if (grp) mmg_group_destroy(grp);
+    };
 
     // ---- summary columns (src/mmseq.cpp:1110-1363)
     struct Series { vector<double> mean, sd, mcse, iact, pct; };
@@ -1139,7 +1140,6 @@ int main(int argc, char **argv)
     Props pT, pV;
     fetch_props(MMG_SERIES_TRANSCRIPT, n, pT);
     fetch_props(MMG_SERIES_VIRTUAL, nV, pV);
-    mmg_summary_destroy(summ);
     const vector<double> &meanprop = pT.mean, &meanprobitprop = pT.probit_mean, &sdprobitprop = pT.probit_sd;
     auto pct_row = [&](const vector<double> &pct, size_t i) { return vector<double>(pct.begin() + (ptrdiff_t)(i * nP), pct.begin() + (ptrdiff_t)((i + 1) * nP)); };
 
@@ -1186,7 +1186,7 @@ int main(int argc, char **argv)
         const int32_t t = obs_of(name);
         if (t >= 0) {
             ofs << name << "\t" << meanmu[t] << "\t" << sd[t] << "\t" << mumcse[t] << "\t" << iact[t] << "\t" << sidLen[name] << "\t"
-                << sidSeqLen[name] << "\t" << counts_shared[t][0] << "\t" << meanprop[t] << "\t" << meanprobitprop[t] << "\t"
+                << sidSeqLen[name] << "\t" << unique_hits[t] << "\t" << meanprop[t] << "\t" << meanprobitprop[t] << "\t"
                 << sdprobitprop[t] << "\t" << log(mu_em[t]) << "\t"
                 << "1"
                 << "\t" << gene2transcripts[transcript2gene[name]].size() << "\t";
@@ -1292,6 +1292,8 @@ int main(int argc, char **argv)
              << "  " << output_base << ".dupIDs" << endl;
     }
     stage.mark("write tables");
+    release_device();
+    stage.mark("trace files: the rest");
     if (km_writer.joinable()) km_writer.join();
     stage.mark("wait for the .k .M writer");
     stage.total();

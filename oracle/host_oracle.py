@@ -261,15 +261,14 @@ def expected_run(h, alpha=0.1, beta=0.1, seed=1234, gibbs_iter=1024, max_em_iter
     ci0 = np.array([c for r in dev_rows for c in r], np.uint32)
     rp, ci_dev, k_st, _ = B.canonical_layout(rp0, ci0, k.astype(np.uint32))
     p = B.Problem(rp, obs_of_dev[ci_dev.astype(np.int64)].astype(np.uint32), l, k=k_st)
-    # start values in FIRST-SEEN row order on the host (deterministic), src/mmseq.cpp:617-638
-    mu0 = np.zeros(n)
+    # start values (src/mmseq.cpp:617-638): the shares k_i / |row i| of the STORED rows summed exactly, as the CLI takes them from the
+    # device (mmg_problem_start_values) -- the reference's floating-point sum in file order differs in the last bits and depends on that
+    # order; unique hits (:633) are integers either way
+    mu0 = B.start_values_exact(p)
     uh = np.zeros(n, np.int64)
     for r, kk in zip(rows, k):
-        for c in r:
-            mu0[c] += float(kk) / len(r)
         if len(r) == 1:
             uh[r[0]] += kk
-    mu0 /= l
     mu_em, em_iters, ll = B.em(p, mu0, max_iter=max_em_iter, epsilon=epsilon)
     chain = B.gibbs_keyed(p, mu_em, alpha=alpha, beta=beta, seed=seed, n_iter=gibbs_iter, trace_len=trace_len)
     trace = chain["trace"]                                   # [n, trace_len], real scale, observed (first-seen) order
