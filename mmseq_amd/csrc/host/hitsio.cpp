@@ -4,7 +4,9 @@
 
 #include <zlib.h>
 
+#include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -42,6 +44,9 @@ public:
         }
         if (zinit) inflateEnd(&zs);
         if (fp) std::fclose(fp);
+        if (compressed && std::getenv("MMSEQ_TIMING"))
+            std::fprintf(stderr, "[timing] hits file: inflate thread busy %.1f s, waited for a free slab %.1f s; the reader waited for inflated data %.1f s\n",
+                         t_inflate, t_inflate_wait, t_reader_wait);
     }
     // next byte or -1 at end of data
     int peek()
@@ -112,7 +117,9 @@ private:
         }
         std::unique_lock<std::mutex> lk(mtx);
         if (reading >= 0) { ring[reading].state = 0; reading = -1; cv.notify_all(); }
+        const auto w0 = std::chrono::steady_clock::now();
         cv.wait(lk, [&] { return ring[next_read].state == 1 || zdone; });
+        t_reader_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
         if (ring[next_read].state != 1) return false;
         reading = next_read;
         next_read = (next_read + 1) % NSLAB;
@@ -124,11 +131,14 @@ private:
     void inflate_ahead()
     {
         for (int w = 0;; w = (w + 1) % NSLAB) {
+            const auto w0 = std::chrono::steady_clock::now();
             {
                 std::unique_lock<std::mutex> lk(mtx);
                 cv.wait(lk, [&] { return ring[w].state == 0 || stop; });
                 if (stop) return;
             }
+            const auto w1 = std::chrono::steady_clock::now();
+            t_inflate_wait += std::chrono::duration<double>(w1 - w0).count();
             Slab &sl = ring[w];
             zs.next_out = (Bytef *)sl.data.data();
             zs.avail_out = (uInt)SLAB;
@@ -147,6 +157,7 @@ private:
                 }
             }
             sl.len = SLAB - zs.avail_out;
+            t_inflate += std::chrono::duration<double>(std::chrono::steady_clock::now() - w1).count();
             {
                 std::lock_guard<std::mutex> lk(mtx);
                 if (sl.len) sl.state = 1;
@@ -168,6 +179,7 @@ private:
     std::mutex mtx;
     std::condition_variable cv;
     std::thread worker;
+    double t_inflate = 0.0, t_inflate_wait = 0.0, t_reader_wait = 0.0; // MMSEQ_TIMING: which of the two threads paces the reader
 };
 
 // ---------------------------------------------------------------- output (plain or zlib level 1)
