@@ -12,7 +12,8 @@ import pytest
 from oracle import host_oracle as H
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-MMSEQ = os.path.join(ROOT, "mmseq_amd", "csrc", "mmseq")
+BIN_DIR = os.environ.get("MMSEQ_HOST_BIN_DIR") or os.path.join(ROOT, "mmseq_amd", "csrc")   # (make -C mmseq_amd/csrc asan: a sanitizer build)
+MMSEQ = os.path.join(BIN_DIR, "mmseq")
 
 
 def run(args, **kw):
@@ -345,7 +346,7 @@ def test_synth_hits_writes_the_generator_rows_and_the_cli_runs_on_them(tmp_path,
     """synth_hits (the benchmark workload as a hits FILE, for end-to-end runs at sizes no alignment here provides): both schemas hold
     the oracle generator's rows in generator order (the writer's transcript-index fast path), 3 % of them with a far hit, and the CLI's
     outputs on that file equal the Python pipeline's."""
-    tool = os.path.join(ROOT, "mmseq_amd", "csrc", "synth_hits")
+    tool = os.path.join(BIN_DIR, "synth_hits")
     R, T = 3000, 500
     p, aux = orc.synth_problem(R=R, T=T, avg_hits=5, seed=1234, sort=False, far_fraction=0.03)
     rp = p.row_ptr.astype(np.int64)

@@ -11,7 +11,8 @@ import pytest
 from oracle import host_oracle as H
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TOOLS = os.path.join(ROOT, "mmseq_amd", "csrc", "hitstools")
+BIN_DIR = os.environ.get("MMSEQ_HOST_BIN_DIR") or os.path.join(ROOT, "mmseq_amd", "csrc")   # (make -C mmseq_amd/csrc asan: a sanitizer build)
+TOOLS = os.path.join(BIN_DIR, "hitstools")
 
 
 def _dataset(seed=0, n_t=40, n_reads=300, long_ids=False):
@@ -107,7 +108,7 @@ def test_t2g_hits_gene_level_records(tmp_path):
     h = _dataset(3)
     t2g = {t: g for g, ts in h.genes.items() for t in ts}
     exp = "".join(">%s\n%s" % (rid, "".join(g + "\n" for g in sorted({t2g[t] for t in ts}))) for rid, ts in h.reads).encode()
-    exe = os.path.join(ROOT, "mmseq_amd", "csrc", "t2g_hits")
+    exe = os.path.join(BIN_DIR, "t2g_hits")
     for data in (H.write_hits_text(h), H.write_hits_binary(h)):
         p = tmp_path / "in.hits"
         p.write_bytes(data)
