@@ -281,9 +281,9 @@ typedef struct mmg_summary_desc {
     const int32_t *percentile_index;
 } mmg_summary_desc;
 enum { MMG_SERIES_TRANSCRIPT = 0, MMG_SERIES_VIRTUAL = 1, MMG_SERIES_IDENTICAL = 2, MMG_SERIES_GENE = 3 };
-/* LIMIT: the per-series kernel sorts and Fourier-transforms a series in LDS and exists for trace_len <= 2048 (the reference's
- * trace length is 1024, src/mmseq.cpp:190); a sampler with a longer trace is refused here with MMG_ERR_ARG -- callers that want the
- * summary keep trace_len <= 2048 (mmg_sampler_get_trace / _get_moments serve longer traces). */
+/* Any trace_len: a series is sorted and Fourier-transformed in LDS up to 8192 samples (the reference's trace length is 1024,
+ * src/mmseq.cpp:190) and in a global workspace beyond (the same steps, slower).  Sokal's estimator needs a power of two in
+ * [4, 2^21] (src/sokal.cc:36-39); for other lengths the percentiles and means exist and sokal_rc says why var / tau do not. */
 int mmg_summary_create(mmg_sampler *s, const mmg_summary_desc *d, mmg_summary **out);
 /* The same in steps, for a caller that prints the trace files while the chain runs (src/mmseq.cpp:911-917 prints sample s inside the
  * loop): _begin checks and uploads the description and draws the simulated traces (the chain may be running: its trace is not read);

@@ -57,15 +57,32 @@ static void summary_free(mmg_summary *q)
 
 static inline unsigned blocks_of(uint64_t n) { return (unsigned)((n + 255) / 256); }
 
-// the per-series summary kernel exists for LDS capacities of 1024 and 2048 samples
+// The per-series summary kernel sorts and transforms in LDS up to 8192 samples (128 KB of the 160 KB a workgroup may hold); longer
+// traces take the same steps in a global workspace, SERIES_WS_GROUPS workgroups striding over the series.
+static constexpr uint32_t SERIES_WS_GROUPS = 1024;
+static size_t series_workspace_bytes(uint32_t S)
+{
+    if (S <= 8192) return 0;
+    size_t sp = 1;
+    while (sp < S) sp <<= 1;
+    return (size_t)SERIES_WS_GROUPS * 3 * sp * 8;
+}
 template <bool LOG_MODE>
 static int launch_series(uint32_t count, uint32_t S, const double *X, uint32_t np, const int32_t *pind, const uint8_t *multi, const double *tw,
-                         SeriesOut o, hipStream_t st)
+                         SeriesOut o, uint64_t *ws, hipStream_t st)
 {
     if (count == 0) return MMG_OK;
-    if (S <= 1024) hipLaunchKernelGGL((k_series_summary<1024, LOG_MODE>), dim3(count), dim3(256), 0, st, count, S, X, np, pind, multi, tw, o);
-    else if (S <= 2048) hipLaunchKernelGGL((k_series_summary<2048, LOG_MODE>), dim3(count), dim3(256), 0, st, count, S, X, np, pind, multi, tw, o);
-    else return fail(MMG_ERR_ARG, "the device summary handles traces of at most 2048 samples");
+#define SERIES_IN_LDS(SMAX) hipLaunchKernelGGL((k_series_summary<SMAX, LOG_MODE>), dim3(count), dim3(256), 0, st, count, S, X, np, pind, multi, tw, o, (uint64_t *)nullptr)
+    if (S <= 1024) SERIES_IN_LDS(1024);
+    else if (S <= 2048) SERIES_IN_LDS(2048);
+    else if (S <= 4096) SERIES_IN_LDS(4096);
+    else if (S <= 8192) SERIES_IN_LDS(8192);
+    else {
+        if (!ws) return fail(MMG_ERR_STATE, "no workspace for the summary of a long trace");
+        hipLaunchKernelGGL((k_series_summary<0, LOG_MODE>), dim3(count < SERIES_WS_GROUPS ? count : SERIES_WS_GROUPS), dim3(256), 0, st, count, S, X, np, pind,
+                           multi, tw, o, ws);
+    }
+#undef SERIES_IN_LDS
     HIP_TRY(hipGetLastError());
     return MMG_OK;
 }
@@ -82,7 +99,6 @@ extern "C" int mmg_summary_begin(mmg_sampler *smp, const mmg_summary_desc *d, mm
     if (d->chain < 0 || d->chain >= v.cfg.n_chains) return fail(MMG_ERR_ARG, "chain index out of range");
     const mmg_problem *p = v.p;
     const uint32_t n = p->n, S = (uint32_t)v.cfg.trace_len, nv = d->n_virtual, ni = d->n_identical, ng = d->n_genes, np = d->n_percentiles;
-    if (S > 2048) return fail(MMG_ERR_ARG, "the device summary handles traces of at most 2048 samples");
     if ((nv && (!d->virtual_id || !d->virtual_scale)) || (ni && (!d->identical_ptr || !d->identical_member)) ||
         (ng && (!d->gene_ptr || !d->gene_member)) || (np && !d->percentile_index))
         return fail(MMG_ERR_ARG, "summary description: missing array");
@@ -192,6 +208,11 @@ extern "C" int mmg_summary_finish(mmg_summary *q)
     double *d_T = nullptr;
     HIP_TRY(hipMalloc((void **)&d_T, maxcnt * S * 8));
     q->scratch.push_back(d_T);
+    uint64_t *d_ws = nullptr;
+    if (series_workspace_bytes(S)) {
+        HIP_TRY(hipMalloc((void **)&d_ws, series_workspace_bytes(S)));
+        q->scratch.push_back(d_ws);
+    }
     const uint32_t counts[4] = {n, nv, ni, ng};
     const double *srcs[4] = {q->trace, q->d_V, q->d_ident, q->d_gene};
     for (int k = 0; k < 4; ++k) {
@@ -206,7 +227,7 @@ extern "C" int mmg_summary_finish(mmg_summary *q)
         if (!counts[k]) continue;
         launch_transpose(srcs[k], d_T, counts[k], S, k == MMG_SERIES_TRANSCRIPT ? q->p->d_int_of_ext : nullptr, st);
         SeriesOut o{b.log_mean, b.var, b.tau, b.rc, b.pct, nullptr, nullptr, nullptr};
-        int rc = launch_series<true>(counts[k], S, d_T, np, q->d_pind, nullptr, q->d_tw, o, st);
+        int rc = launch_series<true>(counts[k], S, d_T, np, q->d_pind, nullptr, q->d_tw, o, d_ws, st);
         if (rc) return rc;
     }
     const double *psrc[2] = {q->d_prop, q->d_propV};
@@ -222,7 +243,7 @@ extern "C" int mmg_summary_finish(mmg_summary *q)
         if (!counts[k]) continue;
         launch_transpose(psrc[k], d_T, counts[k], S, nullptr, st); // d_prop is in the caller's numbering already
         SeriesOut o{nullptr, nullptr, nullptr, nullptr, b.pct, b.mean, b.probit_mean, b.probit_sd};
-        int rc = launch_series<false>(counts[k], S, d_T, np, q->d_pind, pmulti[k], q->d_tw, o, st);
+        int rc = launch_series<false>(counts[k], S, d_T, np, q->d_pind, pmulti[k], q->d_tw, o, d_ws, st);
         if (rc) return rc;
     }
     HIP_TRY(hipGetLastError());

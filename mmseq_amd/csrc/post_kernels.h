@@ -115,131 +115,149 @@ struct SeriesOut {
     double *mean, *probit_mean, *probit_sd; // [count]  (proportion mode)
 };
 
-// One workgroup per series of S samples (series-major input X[series * S + s]).
+// One workgroup per series of S samples at a time (series-major input X[series * S + s]); workgroup b takes the series b, b + gridDim.x, ...
 //   LOG_MODE:  percentiles of x (:1110-1192); y = log x; mean of y (:1195-1227); Sokal var / tau of y (:1307-1363)
 //   otherwise: percentiles of x; mean of x; mean and sd of probit(clamp(x)) when multi[series] (:1235-1305)
-// SMAX: LDS capacity in samples (S <= SMAX).  S a power of two in [4, SMAX] for the Sokal part, else rc = 201 / 200.
+// SMAX > 0: the series is sorted and transformed in LDS (S <= SMAX; the sort keys and the real parts share their storage: the sort
+// is over before the transform starts).  SMAX == 0: any S, in the workgroup's slice of ws (3 * SP * 8 bytes per workgroup, SP = S
+// rounded up to a power of two) -- the same steps on global memory, for traces longer than LDS holds.
+// S a power of two in [4, 2^21] for the Sokal part, else rc = 201 / 200 / 100 (src/sokal.cc:36-39).
 template <int SMAX, bool LOG_MODE>
 __global__ __launch_bounds__(256) void k_series_summary(uint32_t count, uint32_t S, const double *__restrict__ X, uint32_t np,
                                                         const int32_t *__restrict__ pind, const uint8_t *__restrict__ multi,
                                                         const double *__restrict__ tw /* [S] (cos, sin) pairs at tw[2 * (half + j)] */,
-                                                        SeriesOut o)
+                                                        SeriesOut o, uint64_t *__restrict__ ws)
 {
-    __shared__ uint64_t s_key[SMAX];
-    __shared__ double s_re[LOG_MODE ? SMAX : 1], s_im[LOG_MODE ? SMAX : 1];
-    const uint32_t ser = blockIdx.x, tid = threadIdx.x;
-    if (ser >= count) return;
-    const double *x = X + (uint64_t)ser * S;
-    for (uint32_t i = tid; i < S; i += 256) s_key[i] = sort_key(x[i]);
-    for (uint32_t i = S + tid; i < (uint32_t)SMAX; i += 256) s_key[i] = ~0ull; // padding sorts last
-    __syncthreads();
-    // bitonic sort of SP = next power of two >= S keys
+    constexpr bool IN_LDS = SMAX > 0;
+    __shared__ uint64_t l_key[IN_LDS ? SMAX : 1];
+    __shared__ double l_im[(IN_LDS && LOG_MODE) ? SMAX : 1];
+    const uint32_t tid = threadIdx.x;
     uint32_t SP = 1;
     while (SP < S) SP <<= 1;
-    for (uint32_t k = 2; k <= SP; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = tid; i < SP; i += 256) {
-                const uint32_t l = i ^ j;
-                if (l > i) {
-                    const uint64_t a = s_key[i], b = s_key[l];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { s_key[i] = b; s_key[l] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    for (uint32_t q = tid; q < np; q += 256) {
-        const int32_t idx = pind[q];
-        o.pct[(uint64_t)ser * np + q] = (idx >= 0 && (uint32_t)idx < S) ? sort_unkey(s_key[idx]) : __builtin_nan("");
+    uint64_t *s_key;
+    double *s_re, *s_im, *s_pw;
+    uint32_t cap;
+    if constexpr (IN_LDS) {
+        s_key = l_key; s_re = reinterpret_cast<double *>(l_key); s_im = l_im; s_pw = nullptr; cap = SMAX;
+    } else {
+        s_key = ws + (uint64_t)blockIdx.x * 3 * SP; s_re = reinterpret_cast<double *>(s_key + SP); s_im = s_re + SP;
+        s_pw = reinterpret_cast<double *>(s_key); cap = SP;
     }
-    if (!LOG_MODE) {
-        // sequential sums in sample order, as the reference (:1237-1262)
-        if (tid == 0) {
-            double sp = 0.0;
-            for (uint32_t i = 0; i < S; ++i) sp += x[i];
-            o.mean[ser] = sp / (double)S;
-        }
-        if (tid == 64) {
-            const bool mm = multi[ser] != 0;
-            double s1 = 0.0, s2 = 0.0;
-            for (uint32_t i = 0; i < S; ++i) {
-                double z = __builtin_huge_val();
-                if (mm) {
-                    double p = x[i];
-                    p = p < 0.000000001 ? 0.000000001 : p;   // std::min(std::max(p, 1e-9), 1 - 1e-9) (:1250); a NaN stays a NaN
-                    p = 0.999999999 < p ? 0.999999999 : p;
-                    z = dprobit(p);
-                }
-                s1 += z;
-                s2 += z * z;
-            }
-            o.probit_mean[ser] = s1 / (double)S;
-            o.probit_sd[ser] = dsqrt((s2 - s1 * s1 / (double)S) / ((double)S - 1.0));
-        }
-        return;
-    }
-    // ---- log mode
-    __syncthreads();
-    int rc = 0;
-    if (S > (2u << 20)) rc = 100;
-    else if (S < 4) rc = 200;
-    else if (S & (S - 1)) rc = 201;
-    // y = log x into the FFT buffers in bit-reversed order (the host permutes after loading; same values)
     uint32_t lg = 0;
     while ((1u << lg) < S) ++lg;
-    for (uint32_t i = tid; i < S; i += 256) {
-        const double y = dlog(x[i]);
-        s_im[i] = y; // natural order, for the mean
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double acc = 0.0;
-        for (uint32_t i = 0; i < S; ++i) acc += s_im[i];
-        o.log_mean[ser] = acc / (double)S;
-    }
-    if (rc != 0) {
-        if (tid == 0) { o.rc[ser] = rc; o.var[ser] = 0.0; o.tau[ser] = 0.0; }
-        return;
-    }
-    for (uint32_t i = tid; i < S; i += 256) s_re[__brev(i) >> (32 - lg)] = s_im[i];
-    __syncthreads();
-    for (uint32_t i = tid; i < S; i += 256) s_im[i] = 0.0;
-    __syncthreads();
-    auto fft = [&]() { // in-place radix-2 DIT on bit-reversed input: the butterflies of host/numerics.hpp:fft_pow2
-        for (uint32_t len = 2; len <= S; len <<= 1) {
-            const uint32_t half = len >> 1;
-            for (uint32_t b = tid; b < (S >> 1); b += 256) {
-                const uint32_t j = b & (half - 1), i = ((b / half) * len) + j, q = i + half;
-                const double wr = tw[2 * (half + j)], wi = tw[2 * (half + j) + 1];
-                const double xr = s_re[q] * wr - s_im[q] * wi, xi = s_re[q] * wi + s_im[q] * wr;
-                const double ar = s_re[i], ai = s_im[i];
-                s_re[q] = ar - xr; s_im[q] = ai - xi;
-                s_re[i] = ar + xr; s_im[i] = ai + xi;
+    for (uint32_t ser = blockIdx.x; ser < count; ser += gridDim.x) {
+        __syncthreads();   // the previous series of this workgroup is done with the buffers
+        const double *x = X + (uint64_t)ser * S;
+        for (uint32_t i = tid; i < S; i += 256) s_key[i] = sort_key(x[i]);
+        for (uint32_t i = S + tid; i < cap; i += 256) s_key[i] = ~0ull; // padding sorts last
+        __syncthreads();
+        // bitonic sort of SP = next power of two >= S keys
+        for (uint32_t k = 2; k <= SP; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = tid; i < SP; i += 256) {
+                    const uint32_t l = i ^ j;
+                    if (l > i) {
+                        const uint64_t a = s_key[i], b = s_key[l];
+                        const bool up = (i & k) == 0;
+                        if ((a > b) == up) { s_key[i] = b; s_key[l] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        for (uint32_t q = tid; q < np; q += 256) {
+            const int32_t idx = pind[q];
+            o.pct[(uint64_t)ser * np + q] = (idx >= 0 && (uint32_t)idx < S) ? sort_unkey(s_key[idx]) : __builtin_nan("");
+        }
+        if constexpr (!LOG_MODE) {
+            // sequential sums in sample order, as the reference (:1237-1262)
+            if (tid == 0) {
+                double sp = 0.0;
+                for (uint32_t i = 0; i < S; ++i) sp += x[i];
+                o.mean[ser] = sp / (double)S;
+            }
+            if (tid == 64) {
+                const bool mm = multi[ser] != 0;
+                double s1 = 0.0, s2 = 0.0;
+                for (uint32_t i = 0; i < S; ++i) {
+                    double z = __builtin_huge_val();
+                    if (mm) {
+                        double p = x[i];
+                        p = p < 0.000000001 ? 0.000000001 : p;   // std::min(std::max(p, 1e-9), 1 - 1e-9) (:1250); a NaN stays a NaN
+                        p = 0.999999999 < p ? 0.999999999 : p;
+                        z = dprobit(p);
+                    }
+                    s1 += z;
+                    s2 += z * z;
+                }
+                o.probit_mean[ser] = s1 / (double)S;
+                o.probit_sd[ser] = dsqrt((s2 - s1 * s1 / (double)S) / ((double)S - 1.0));
+            }
+        } else {
+            // ---- log mode
+            __syncthreads();   // the percentiles are out: the keys' storage becomes the real parts
+            int rc = 0;
+            if (S > (2u << 20)) rc = 100;
+            else if (S < 4) rc = 200;
+            else if (S & (S - 1)) rc = 201;
+            for (uint32_t i = tid; i < S; i += 256) s_im[i] = dlog(x[i]); // natural order, for the mean
+            __syncthreads();
+            if (tid == 0) {
+                double acc = 0.0;
+                for (uint32_t i = 0; i < S; ++i) acc += s_im[i];
+                o.log_mean[ser] = acc / (double)S;
+            }
+            if (rc != 0) {
+                if (tid == 0) { o.rc[ser] = rc; o.var[ser] = 0.0; o.tau[ser] = 0.0; }
+                continue;
+            }
+            // y into the transform buffers in bit-reversed order (the host permutes after loading; same values)
+            for (uint32_t i = tid; i < S; i += 256) s_re[__brev(i) >> (32 - lg)] = s_im[i];
+            __syncthreads();
+            for (uint32_t i = tid; i < S; i += 256) s_im[i] = 0.0;
+            __syncthreads();
+            auto fft = [&]() { // in-place radix-2 DIT on bit-reversed input: the butterflies of host/numerics.hpp:fft_pow2
+                for (uint32_t len = 2; len <= S; len <<= 1) {
+                    const uint32_t half = len >> 1;
+                    for (uint32_t b = tid; b < (S >> 1); b += 256) {
+                        const uint32_t j = b & (half - 1), i = ((b / half) * len) + j, q = i + half;
+                        const double wr = tw[2 * (half + j)], wi = tw[2 * (half + j) + 1];
+                        const double xr = s_re[q] * wr - s_im[q] * wi, xi = s_re[q] * wi + s_im[q] * wr;
+                        const double ar = s_re[i], ai = s_im[i];
+                        s_re[q] = ar - xr; s_im[q] = ai - xi;
+                        s_re[i] = ar + xr; s_im[i] = ai + xi;
+                    }
+                    __syncthreads();
+                }
+            };
+            fft();
+            // power spectrum, mean removed, back into bit-reversed order for the second transform
+            if constexpr (IN_LDS) {
+                double pw[(SMAX + 255) / 256];
+                for (uint32_t i = tid, c = 0; i < S; i += 256, ++c) pw[c] = i == 0 ? 0.0 : s_re[i] * s_re[i] + s_im[i] * s_im[i];
+                __syncthreads();
+                for (uint32_t i = tid, c = 0; i < S; i += 256, ++c) { s_re[__brev(i) >> (32 - lg)] = pw[c]; s_im[i] = 0.0; }
+            } else {
+                for (uint32_t i = tid; i < S; i += 256) s_pw[i] = i == 0 ? 0.0 : s_re[i] * s_re[i] + s_im[i] * s_im[i];
+                __syncthreads();
+                for (uint32_t i = tid; i < S; i += 256) { s_re[__brev(i) >> (32 - lg)] = s_pw[i]; s_im[i] = 0.0; }
             }
             __syncthreads();
+            fft();
+            if (tid == 0) {
+                const double n = (double)S;
+                const double r0 = s_re[0];
+                o.var[ser] = r0 / (n * (n - 1.0));
+                const double c = 1.0 / r0;
+                double sum = -0.333333333333333333333;
+                int m = (int)S + 1;
+                for (uint32_t i = 0; i < S; ++i) {
+                    sum += s_re[i] * c - 0.166666666666666666666;
+                    if (sum < 0) { m = (int)i + 1; break; }
+                }
+                o.tau[ser] = 2 * (sum + ((double)m - 1.0) / 6.0);
+                o.rc[ser] = 0;
+            }
         }
-    };
-    fft();
-    // power spectrum, mean removed, back into bit-reversed order for the second transform
-    double pw[(SMAX + 255) / 256];
-    for (uint32_t i = tid, c = 0; i < S; i += 256, ++c) pw[c] = i == 0 ? 0.0 : s_re[i] * s_re[i] + s_im[i] * s_im[i];
-    __syncthreads();
-    for (uint32_t i = tid, c = 0; i < S; i += 256, ++c) { s_re[__brev(i) >> (32 - lg)] = pw[c]; s_im[i] = 0.0; }
-    __syncthreads();
-    fft();
-    if (tid == 0) {
-        const double n = (double)S;
-        const double r0 = s_re[0];
-        o.var[ser] = r0 / (n * (n - 1.0));
-        const double c = 1.0 / r0;
-        double sum = -0.333333333333333333333;
-        int m = (int)S + 1;
-        for (uint32_t i = 0; i < S; ++i) {
-            sum += s_re[i] * c - 0.166666666666666666666;
-            if (sum < 0) { m = (int)i + 1; break; }
-        }
-        o.tau[ser] = 2 * (sum + ((double)m - 1.0) / 6.0);
-        o.rc[ser] = 0;
     }
 }
 

@@ -170,7 +170,7 @@ def test_analytic_posteriors_on_the_device(gpu):
     assert abs(lg.mean() - (digamma(10.1) - np.log(0.9))) < 5 * np.sqrt(polygamma(1, 10.1) / S)
     assert abs(lg.std(ddof=1) - np.sqrt(polygamma(1, 10.1))) < 0.03          # 0.3226
     s.close()
-    s = gpu.Sampler(prob, np.ones(3), seed=5, gibbs_iter=2048, trace_len=2048)  # (the device summary takes at most 2048 samples)
+    s = gpu.Sampler(prob, np.ones(3), seed=5, gibbs_iter=2048, trace_len=2048)
     s.run(2048)
     summ = gpu.Summary(s, chain=0)
     assert 0.7 < summ.series(gpu.SERIES_TRANSCRIPT)["tau"][0] < 1.4           # iid => iact ~ 1

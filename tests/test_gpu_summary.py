@@ -115,6 +115,50 @@ def test_summary_edge_shapes(gpu, orc):
     q.close()
 
 
+@pytest.mark.parametrize("S", [2048, 4096, 8192, 16384, 12000])
+def test_summary_of_long_traces(gpu, orc, S):
+    """Traces longer than the reference's default 1024 samples: up to 8192 the series is sorted and transformed in LDS, beyond that in a
+    global workspace (the reference's sokal takes up to 2^21 samples, src/sokal.cc:36); 12000 is no power of two: percentiles and
+    means exist, Sokal returns 201."""
+    p, _ = orc.synth_problem(R=3000, T=70, avg_hits=4, seed=12, sort=False)
+    n = p.n
+    prob = gpu.Problem.from_csr(p.row_ptr, p.col_idx, p.l)
+    mu0, _ = prob.start_values()
+    s = gpu.Sampler(prob, mu0, seed=9, gibbs_iter=S, trace_len=S)
+    s.run(S)
+    trace = s.trace(0)
+    genes = [[0, 1, 2], [3], list(range(4, n))]
+    pidx = [0, int(np.floor(0.5 * (S - 1) + 0.5)), S - 1]
+    q = gpu.Summary(s, genes=genes, identical=[[5, 6]], virtual_id=np.array([901], np.uint64), virtual_scale=np.array([0.5]), percentile_index=pidx)
+    V = orc.simu_gamma_trace(9, 901, 0.1, 0.5, S)[None, :]
+    t_gene = np.zeros((3, S))
+    for g, ms in enumerate(genes):
+        for m in ms:
+            t_gene[g] += trace[m]
+    assert np.array_equal(q.rows(gpu.SERIES_GENE).T, t_gene)
+    pow2 = S & (S - 1) == 0
+    for kind, tr in ((gpu.SERIES_TRANSCRIPT, trace), (gpu.SERIES_GENE, t_gene), (gpu.SERIES_VIRTUAL, V)):
+        r = q.series(kind)
+        assert np.array_equal(r["percentiles"], np.sort(tr, axis=1)[:, pidx])
+        with np.errstate(divide="ignore"):
+            lt = np.log(tr)
+        np.testing.assert_allclose(r["log_mean"], lt.mean(axis=1), rtol=1e-12, atol=1e-12)
+        assert (r["rc"] == (0 if pow2 else 201)).all()
+        for i in range(0, tr.shape[0], 7):
+            rc, var, tau, m = orc.sokal(lt[i])
+            assert rc == (0 if pow2 else 201)
+            if pow2:
+                np.testing.assert_allclose([r["var"][i], r["tau"][i]], [var, tau], rtol=1e-9)
+    gene_of = np.empty(n, np.int64)
+    for g, ms in enumerate(genes):
+        gene_of[ms] = g
+    pr = trace / t_gene[gene_of]
+    r = q.proportions(gpu.SERIES_TRANSCRIPT)
+    assert np.array_equal(r["percentiles"], np.sort(pr, axis=1)[:, pidx])
+    np.testing.assert_allclose(r["mean"], pr.mean(axis=1), rtol=1e-12)
+    q.close()
+
+
 def test_summary_in_steps_while_the_chain_runs_equals_the_summary_after_it(gpu, orc):
     """mmg_summary_begin / _advance / _finish and mmg_sampler_get_trace_rows_done: the trace writers of src/mmseq.cpp:911-917 print sample s
     inside the loop; here the caller feeds finished samples to the summary and fetches their rows WHILE later iterations are enqueued
