@@ -12,6 +12,25 @@ LIB_PATH = os.environ.get("MMSEQ_AMD_LIB") or os.path.join(_HERE, "csrc", "libmm
 _lib = None
 
 
+def _point_rccl_at_pytorchs_copy():
+    """One RCCL per process: the library loads RCCL on first use of a device group (dlopen); a Python process that ALSO imports torch
+    (mmseq_amd/dist.py does) must not get /opt/rocm's build from here and PyTorch's bundled one from torch -- two builds in one process
+    crash in the exit handlers.  So when a PyTorch installation carries its own librccl, MMG_RCCL_LIBRARY (read by csrc/group.hip)
+    names that file; whichever of the two loads it first, the other gets the same handle.  torch itself is not imported here."""
+    if os.environ.get("MMG_RCCL_LIBRARY"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    for base in (spec.submodule_search_locations or []) if spec else []:
+        cand = os.path.join(base, "lib", "librccl.so")
+        if os.path.exists(cand):
+            os.environ["MMG_RCCL_LIBRARY"] = cand
+            return
+
+
 class MMGError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("libmmgibbs error %d: %s" % (code, msg))
@@ -91,6 +110,7 @@ SYMBOLS = {
     "mmg_sampler_counts_devptr": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "mmg_sampler_moments_devptr": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "mmg_sampler_sync": (C.c_int, [C.c_void_p]),
+    "mmg_sampler_wait_iterations": (C.c_int, [C.c_void_p, C.c_int]),
     "mmg_sampler_iteration": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "mmg_sampler_get_trace": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mmg_sampler_get_trace_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -153,6 +173,7 @@ def load():
     if _lib is not None:
         return _lib
     _share_hip_runtime_with_torch()
+    _point_rccl_at_pytorchs_copy()
     if not os.path.exists(LIB_PATH):
         raise OSError("libmmgibbs.so not built at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                       "(there is no CPU fallback)" % LIB_PATH)

@@ -10,10 +10,11 @@
 // One communicator per device from ncclCommInitAll, every collective enqueued on the sampler's own stream inside a
 // ncclGroupStart / ncclGroupEnd bracket, so kernels and collectives of a device stay ordered without host synchronisation.
 // RCCL is loaded on first use (dlopen): a process that never forms a group does not need it, and inside a PyTorch process the
-// copy PyTorch already loaded is the one that gets used.
+// copy PyTorch already loaded (or, through MMG_RCCL_LIBRARY, is going to load) is the one that gets used.
 #include "mmg_host.h"
 #include "mmg_launch.h"
 
+#include <cstdlib>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -39,8 +40,13 @@ struct Rccl {
     bool load()
     {
         if (lib) return true;
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        // MMG_RCCL_LIBRARY names the copy to use: a process must not end up with two RCCL builds (a host program that loads its own
+        // later -- PyTorch's bundled one -- next to /opt/rocm's crashed in the exit handlers); mmseq_amd/_lib.py points it at PyTorch's.
+        const char *wanted = getenv("MMG_RCCL_LIBRARY");
+        for (const char *name : {wanted ? wanted : "librccl.so.1", "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            // RTLD_LOCAL: with RCCL's symbols in the global namespace a PyTorch imported LATER bound some of its own to them and the
+            // process died in the exit handlers ("double free"), whichever RCCL build it was (tools/exit_probe.py)
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (lib) break;
         }
         if (!lib) { err = std::string("cannot load librccl: ") + dlerror(); return false; }

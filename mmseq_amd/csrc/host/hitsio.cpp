@@ -99,8 +99,9 @@ public:
 
 private:
     // A compressed file is ONE zlib stream (src/hitsio.cpp:127): it inflates in a thread of its own, a ring of slabs ahead of the
-    // record decoding, which was a third of the reader's time at 50 M reads.
-    static constexpr int NSLAB = 4;
+    // record decoding, which was a third of the reader's time at 50 M reads.  The ring is deep (256 MB): inflating bounds the ingest
+    // of a large file, and with four slabs it stood still for 1.0 s of 14.5 s whenever a later stage (a growing hash table) paused.
+    static constexpr int NSLAB = 256;
     static constexpr size_t SLAB = 1u << 20;
     struct Slab { std::vector<char> data; size_t len = 0; int state = 0; }; // 0 free, 1 filled, 2 being read
     bool fill()
@@ -112,7 +113,6 @@ private:
             return len > 0;
         }
         if (!worker.joinable() && !zdone) {
-            for (auto &sl : ring) sl.data.resize(SLAB);
             worker = std::thread([this] { inflate_ahead(); });
         }
         std::unique_lock<std::mutex> lk(mtx);
@@ -140,6 +140,7 @@ private:
             const auto w1 = std::chrono::steady_clock::now();
             t_inflate_wait += std::chrono::duration<double>(w1 - w0).count();
             Slab &sl = ring[w];
+            if (sl.data.size() != SLAB) sl.data.resize(SLAB);   // (a small file never touches most of the ring)
             zs.next_out = (Bytef *)sl.data.data();
             zs.avail_out = (uInt)SLAB;
             bool end = false;

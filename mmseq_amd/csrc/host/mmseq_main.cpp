@@ -689,20 +689,34 @@ int main(int argc, char **argv)
                 const int32_t t = obs_of(name);
                 if (t >= 0) t2sets[t].push_back((uint32_t)v);
             }
-        vector<uint32_t> cand, tmp;
-        for (uint64_t i = 0; i < m; ++i) {
-            const uint64_t b = row_ptr[i], e = row_ptr[i + 1];
-            if (b == e) { for (auto &x : identical_unique_hits) x += (int)k[i]; continue; } // empty row counts for every group
-            cand = t2sets[col_idx[b]];
-            for (uint64_t j = b + 1; j < e && !cand.empty(); ++j) {
-                tmp.clear();
-                for (uint32_t s : cand)
-                    if (find(t2sets[col_idx[j]].begin(), t2sets[col_idx[j]].end(), s) != t2sets[col_idx[j]].end()) tmp.push_back(s);
-                cand.swap(tmp);
+        // rows in parallel, integer counts per thread summed at the end (the sums do not depend on the split)
+        const int uh_threads = max(1, omp_get_max_threads());
+        int64_t empty_rows_k = 0;
+        {
+            vector<vector<int>> part((size_t)uh_threads, vector<int>(identical_unique_hits.size(), 0));
+#pragma omp parallel num_threads(uh_threads) reduction(+ : empty_rows_k)
+            {
+                vector<int> &mine = part[(size_t)omp_get_thread_num()];
+                vector<uint32_t> cand, tmp;
+#pragma omp for schedule(static)
+                for (int64_t i = 0; i < (int64_t)m; ++i) {
+                    const uint64_t b = row_ptr[i], e = row_ptr[i + 1];
+                    if (b == e) { empty_rows_k += (int64_t)k[i]; continue; } // an empty row counts for every group
+                    if (t2sets[col_idx[b]].empty()) continue;
+                    cand = t2sets[col_idx[b]];
+                    for (uint64_t j = b + 1; j < e && !cand.empty(); ++j) {
+                        tmp.clear();
+                        for (uint32_t s : cand)
+                            if (find(t2sets[col_idx[j]].begin(), t2sets[col_idx[j]].end(), s) != t2sets[col_idx[j]].end()) tmp.push_back(s);
+                        cand.swap(tmp);
+                    }
+                    sort(cand.begin(), cand.end());
+                    cand.erase(unique(cand.begin(), cand.end()), cand.end());
+                    for (uint32_t s : cand) mine[s] += (int)k[i];
+                }
             }
-            sort(cand.begin(), cand.end());
-            cand.erase(unique(cand.begin(), cand.end()), cand.end());
-            for (uint32_t s : cand) identical_unique_hits[s] += (int)k[i];
+            for (auto &pt : part) for (size_t v = 0; v < pt.size(); ++v) identical_unique_hits[v] += pt[v];
+            for (auto &x : identical_unique_hits) x += (int)empty_rows_k;
         }
         cerr << "done." << endl;
         cerr << "Counting unique hits to genes...";
@@ -710,13 +724,23 @@ int main(int argc, char **argv)
         { int g = 0; for (auto &gt : gene2transcripts) gene2index[gt.first] = g++; }
         vector<int> t2g(n);
         for (uint32_t t = 0; t < n; ++t) t2g[t] = gene2index[transcript2gene[sid(t)]];
-        for (uint64_t i = 0; i < m; ++i) {
-            const uint64_t b = row_ptr[i], e = row_ptr[i + 1];
-            if (b == e) { for (auto &x : gene_unique_hits) x += (int)k[i]; continue; }
-            const int g = t2g[col_idx[b]];
-            bool uniq = true;
-            for (uint64_t j = b + 1; j < e; ++j) if (t2g[col_idx[j]] != g) { uniq = false; break; }
-            if (uniq) gene_unique_hits[g] += (int)k[i];
+        {
+            vector<vector<int>> part((size_t)uh_threads, vector<int>(gene_unique_hits.size(), 0));
+#pragma omp parallel num_threads(uh_threads)
+            {
+                vector<int> &mine = part[(size_t)omp_get_thread_num()];
+#pragma omp for schedule(static)
+                for (int64_t i = 0; i < (int64_t)m; ++i) {
+                    const uint64_t b = row_ptr[i], e = row_ptr[i + 1];
+                    if (b == e) continue;
+                    const int g = t2g[col_idx[b]];
+                    bool uniq = true;
+                    for (uint64_t j = b + 1; j < e; ++j) if (t2g[col_idx[j]] != g) { uniq = false; break; }
+                    if (uniq) mine[g] += (int)k[i];
+                }
+            }
+            for (auto &pt : part) for (size_t g = 0; g < pt.size(); ++g) gene_unique_hits[g] += pt[g];
+            for (auto &x : gene_unique_hits) x += (int)empty_rows_k;
         }
         cerr << "done." << endl;
     }
@@ -1049,21 +1073,38 @@ int main(int argc, char **argv)
                              [](size_t) { return true; }, t_big);
             gp.close();
         });
-        const int chunk = max(1, gibbs_iter / 16);
-        for (int done = 0; done < gibbs_iter; done += chunk) {
-            cout << "Gibbs iteration " << done << "       \r" << flush;
-            const int it = min(chunk, gibbs_iter - done);
+        // chunks of 1/64 of the run: the writers start on a chunk's samples when it ends, so what is left of their work after the last
+        // iteration is 1/64 of the files
+        const int chunk = max(1, gibbs_iter / 64);
+        double t_enqueue = 0.0, t_sync = 0.0, t_advance = 0.0;
+        auto enqueue = [&](int it) {
+            const double c0 = omp_get_wtime();
             if (gpus == 1) MMG_TRY(mmg_sampler_run(smps[0], it));
             else if (gpus > 1 && chains == 1) MMG_TRY(mmg_group_run_sharded(grp, smps.data(), it));
             else MMG_TRY(mmg_group_run_chains(grp, smps.data(), it));
-            for (auto sp : smps) MMG_TRY(mmg_sampler_sync(sp));
-            // sample s is kept by iteration s * gibbs_ss (:911): the samples of the iterations done so far are final
+            t_enqueue += omp_get_wtime() - c0;
+        };
+        // one chunk is always enqueued ahead of the one waited for: the device does not idle while this thread hands samples on (or is
+        // held up: the writers use every CPU of the quota)
+        enqueue(min(chunk, gibbs_iter));
+        for (int done = 0; done < gibbs_iter; done += chunk) {
+            cout << "Gibbs iteration " << done << "       \r" << flush;
+            const int it = min(chunk, gibbs_iter - done);
+            if (done + it < gibbs_iter) enqueue(min(chunk, gibbs_iter - done - it));
+            // sample s is kept by iteration s * gibbs_ss (:911): the samples of the iterations up to done + it are final once the
+            // iteration that stored the last of them is
             const int final_samples = min(trace_length, (done + it - 1) / gibbs_ss + 1);
+            const double c1 = omp_get_wtime();
+            for (auto sp : smps) MMG_TRY(mmg_sampler_wait_iterations(sp, done + it < gibbs_iter ? (final_samples - 1) * gibbs_ss + 1 : gibbs_iter));
+            const double c2 = omp_get_wtime();
             MMG_TRY(mmg_summary_advance(summ, final_samples));
             { std::lock_guard<std::mutex> lk(ready_mu); samples_ready = final_samples; }
             ready_cv.notify_all();
+            t_sync += c2 - c1; t_advance += omp_get_wtime() - c2;
         }
+        for (auto sp : smps) MMG_TRY(mmg_sampler_sync(sp));
         cout << "Gibbs iteration " << gibbs_iter - 1 << "       \r" << endl;
+        if (stage.on) fprintf(stderr, "[timing] Gibbs loop: enqueue %.3f s, wait for the device %.3f s, derived rows %.3f s\n", t_enqueue, t_sync, t_advance);
         stage.mark("Gibbs (trace files written alongside)");
     }
     // moments of log mu pooled over all chains and devices (one fp64 all-reduce): log_mu, sd and mcse of multi-chain runs
@@ -1145,7 +1186,17 @@ int main(int argc, char **argv)
 
     const double digalpha = mmnum::digamma(alpha);                 // gsl_sf_psi(alpha)        :1372
     const double sqrtpolygalpha = sqrt(mmnum::trigamma(alpha));    // sqrt(gsl_sf_psi_n(1,.))  :1373
-    auto prior_logmu = [&](const string &name) { return digalpha - log(beta + sidLen[name] * (double)numbermappedreads / 1000000000.0); };
+    // (lookups that never insert: the table writers below run in several threads; a name the header did not describe reads as 0, which
+    // is what the maps' operator[] would have inserted)
+    auto len_of = [&](const string &name) { auto it = sidLen.find(name); return it == sidLen.end() ? 0.0 : it->second; };
+    auto seqlen_of = [&](const string &name) { auto it = sidSeqLen.find(name); return it == sidSeqLen.end() ? 0 : it->second; };
+    auto gene_size_of = [&](const string &name) {
+        auto tg = transcript2gene.find(name);
+        auto it = gene2transcripts.find(tg == transcript2gene.end() ? string() : tg->second);
+        return it == gene2transcripts.end() ? (size_t)0 : it->second.size();
+    };
+    auto simu_of = [&](const string &name) { auto it = simuIndex.find(name); return it == simuIndex.end() ? 0u : it->second; };
+    auto prior_logmu = [&](const string &name) { return digalpha - log(beta + len_of(name) * (double)numbermappedreads / 1000000000.0); };
 
     // ---- gene-level expression-weighted effective length (src/mmseq.cpp:1375-1395)
     vector<double> gene_lengths(nG, 0.0);
@@ -1157,7 +1208,7 @@ int main(int argc, char **argv)
                 for (auto &name : gt.second) {
                     const int32_t t = obs_of(name);
                     const double e = t >= 0 ? exp(meanmu[t]) : exp(prior_logmu(name));
-                    gene_lengths[g] += sidLen[name] * e;
+                    gene_lengths[g] += len_of(name) * e;
                     sum += e;
                 }
                 gene_lengths[g] /= sum;
@@ -1174,6 +1225,41 @@ int main(int argc, char **argv)
         for (size_t i = 0; i < nP; i++) { o << percentiles[i]; o << (i == nP - 1 ? term : ","); }
     };
 
+    // ---- .gene.mmseq (src/mmseq.cpp:1615-1669)
+    auto write_gene_table = [&]() {
+    ofstream ofs((output_base + ".gene.mmseq").c_str());
+    ofs << "# Mapped fragments: " << numbermappedreads << endl;
+    ofs << "feature_id\tlog_mu\tsd\tmcse\tiact\teffective_length\ttrue_length\tunique_hits\tntranscripts\tobserved\t";
+    pct_header(ofs, "percentiles", "\n");
+    {
+        size_t g = 0;
+        for (auto &gt : gene2transcripts) {
+            bool obs = false;
+            for (auto &name : gt.second) if (obs_of(name) >= 0) { obs = true; break; }
+            if (obs) {
+                ofs << gt.first << "\t" << meanmu_gene[g] << "\t" << sd_gene[g] << "\t" << mumcse_gene[g] << "\t" << iact_gene[g] << "\t"
+                    << gene_lengths[g] << "\t"
+                    << "NA"
+                    << "\t" << gene_unique_hits[g] << "\t" << gt.second.size() << "\t"
+                    << "1"
+                    << "\t";
+            } else {
+                ofs << gt.first << "\t" << meanmu_gene[g] << "\t" << sd_gene[g] << "\t" << sd_gene[g] / sqrt(trace_length) << "\t" << 1 << "\t"
+                    << gene_lengths[g] << "\t"
+                    << "NA"
+                    << "\t"
+                    << "0"
+                    << "\t" << gt.second.size() << "\t"
+                    << "0"
+                    << "\t";
+            }
+            join_pct(ofs, pct_row(sG.pct, g), "\n");
+            g++;
+        }
+    }
+    ofs.close();
+    };
+
     stage.mark("summary columns");
     // ---- .mmseq (src/mmseq.cpp:1469-1554)
     ofs.open((output_base + ".mmseq").c_str());
@@ -1182,30 +1268,47 @@ int main(int argc, char **argv)
            "probit_proportion\tlog_mu_em\tobserved\tntranscripts\t";
     pct_header(ofs, "percentiles", "\t");
     pct_header(ofs, "percentiles_proportion", "\n");
-    for (auto &name : transcriptList) {
+    // (the rows are formatted in parallel, a slice of the list per thread into a stream of its own with the default formatting of
+    // the file stream, and written in order; the gene table, which shares nothing with this one, is written by a thread of its own)
+    (void)obs_of(string());   // the name table exists before threads read it
+    auto mmseq_row = [&](ostream &o, const string &name) {
         const int32_t t = obs_of(name);
         if (t >= 0) {
-            ofs << name << "\t" << meanmu[t] << "\t" << sd[t] << "\t" << mumcse[t] << "\t" << iact[t] << "\t" << sidLen[name] << "\t"
-                << sidSeqLen[name] << "\t" << unique_hits[t] << "\t" << meanprop[t] << "\t" << meanprobitprop[t] << "\t"
+            o << name << "\t" << meanmu[t] << "\t" << sd[t] << "\t" << mumcse[t] << "\t" << iact[t] << "\t" << len_of(name) << "\t"
+                << seqlen_of(name) << "\t" << unique_hits[t] << "\t" << meanprop[t] << "\t" << meanprobitprop[t] << "\t"
                 << sdprobitprop[t] << "\t" << log(mu_em[t]) << "\t"
                 << "1"
-                << "\t" << gene2transcripts[transcript2gene[name]].size() << "\t";
-            join_pct(ofs, pct_row(sT.pct, t), "\t");
-            join_pct(ofs, pct_row(pT.pct, t), "\n");
+                << "\t" << gene_size_of(name) << "\t";
+            join_pct(o, pct_row(sT.pct, t), "\t");
+            join_pct(o, pct_row(pT.pct, t), "\n");
         } else {
-            ofs << name << "\t" << prior_logmu(name) << "\t" << sqrtpolygalpha << "\t"
+            o << name << "\t" << prior_logmu(name) << "\t" << sqrtpolygalpha << "\t"
                 << "0"
                 << "\t"
                 << "1"
-                << "\t" << sidLen[name] << "\t" << sidSeqLen[name] << "\t" << 0 << "\t" << pV.mean[simuIndex[name]] << "\t"
-                << pV.probit_mean[simuIndex[name]] << "\t" << pV.probit_sd[simuIndex[name]] << "\t"
+                << "\t" << len_of(name) << "\t" << seqlen_of(name) << "\t" << 0 << "\t" << pV.mean[simu_of(name)] << "\t"
+                << pV.probit_mean[simu_of(name)] << "\t" << pV.probit_sd[simu_of(name)] << "\t"
                 << "NA"
                 << "\t"
                 << "0"
-                << "\t" << gene2transcripts[transcript2gene[name]].size() << "\t";
-            join_pct(ofs, pct_row(sV.pct, simuIndex[name]), "\t");
-            join_pct(ofs, pct_row(pV.pct, simuIndex[name]), "\n");
+                << "\t" << gene_size_of(name) << "\t";
+            join_pct(o, pct_row(sV.pct, simu_of(name)), "\t");
+            join_pct(o, pct_row(pV.pct, simu_of(name)), "\n");
         }
+        };
+    std::thread gene_table([&]() { write_gene_table(); });
+    {
+        const int tt = max(1, min(omp_get_max_threads(), (int)(transcriptList.size() / 4096) + 1));
+        vector<string> parts((size_t)tt);
+#pragma omp parallel num_threads(tt)
+        {
+            const size_t me = (size_t)omp_get_thread_num(), nt = (size_t)omp_get_num_threads();
+            const size_t lo = transcriptList.size() * me / nt, hi = transcriptList.size() * (me + 1) / nt;
+            ostringstream o;
+            for (size_t i = lo; i < hi; ++i) mmseq_row(o, transcriptList[i]);
+            parts[me] = o.str();
+        }
+        for (auto &pt : parts) ofs.write(pt.data(), (streamsize)pt.size());
     }
     ofs.close(); ofs.clear();
 
@@ -1239,38 +1342,7 @@ int main(int argc, char **argv)
     }
     ofs.close(); ofs.clear();
 
-    // ---- .gene.mmseq (src/mmseq.cpp:1615-1669)
-    ofs.open((output_base + ".gene.mmseq").c_str());
-    ofs << "# Mapped fragments: " << numbermappedreads << endl;
-    ofs << "feature_id\tlog_mu\tsd\tmcse\tiact\teffective_length\ttrue_length\tunique_hits\tntranscripts\tobserved\t";
-    pct_header(ofs, "percentiles", "\n");
-    {
-        size_t g = 0;
-        for (auto &gt : gene2transcripts) {
-            bool obs = false;
-            for (auto &name : gt.second) if (obs_of(name) >= 0) { obs = true; break; }
-            if (obs) {
-                ofs << gt.first << "\t" << meanmu_gene[g] << "\t" << sd_gene[g] << "\t" << mumcse_gene[g] << "\t" << iact_gene[g] << "\t"
-                    << gene_lengths[g] << "\t"
-                    << "NA"
-                    << "\t" << gene_unique_hits[g] << "\t" << gt.second.size() << "\t"
-                    << "1"
-                    << "\t";
-            } else {
-                ofs << gt.first << "\t" << meanmu_gene[g] << "\t" << sd_gene[g] << "\t" << sd_gene[g] / sqrt(trace_length) << "\t" << 1 << "\t"
-                    << gene_lengths[g] << "\t"
-                    << "NA"
-                    << "\t"
-                    << "0"
-                    << "\t" << gt.second.size() << "\t"
-                    << "0"
-                    << "\t";
-            }
-            join_pct(ofs, pct_row(sG.pct, g), "\n");
-            g++;
-        }
-    }
-    ofs.close(); ofs.clear();
+    gene_table.join();
 
     cout << "done." << endl;
     cout << "Output files: " << endl

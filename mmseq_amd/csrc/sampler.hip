@@ -30,6 +30,10 @@ struct mmg_sampler {
     double *d_reader_tmp = nullptr;                        // its gather buffer, kept (hipFree would wait for the running chain)
     size_t reader_cap = 0;
     std::mutex reader_mu;
+    // marks: an event behind every iteration that stored a sample, for mmg_sampler_wait_iterations (events without timing, recycled)
+    std::vector<hipEvent_t> mark_pool;
+    std::vector<int> mark_free;
+    std::deque<std::pair<int, int>> marks;                 // {iterations completed when the event fires, index into mark_pool}
     double acc_sample_ms = 0, acc_update_ms = 0;
     uint64_t acc_sample_n = 0, acc_update_n = 0;
 };
@@ -40,6 +44,7 @@ static void sampler_free(mmg_sampler *s)
     (void)hipSetDevice(s->device);
     if (s->own) { (void)hipStreamSynchronize(s->own); }
     for (auto e : s->ev_pool) (void)hipEventDestroy(e);
+    for (auto e : s->mark_pool) (void)hipEventDestroy(e);
     for (void *x : {(void *)s->d_mu, (void *)s->d_scale, (void *)s->d_trace, (void *)s->d_mom, (void *)s->d_cnt, (void *)s->d_cnt_last})
         if (x) (void)hipFree(x);
     if (s->own) (void)hipStreamDestroy(s->own);
@@ -240,6 +245,28 @@ static int sampler_sample(mmg_sampler *s, bool fold)
     return MMG_OK;
 }
 
+// An event behind the iteration just enqueued (one that stored a sample): mmg_sampler_wait_iterations waits on these.  Marks that
+// have fired are recycled here, so the pool is as large as the samples in flight.
+static int mark_iteration(mmg_sampler *s)
+{
+    while (!s->marks.empty()) {
+        if (hipEventQuery(s->mark_pool[s->marks.front().second]) != hipSuccess) { (void)hipGetLastError(); break; }
+        s->mark_free.push_back(s->marks.front().second);
+        s->marks.pop_front();
+    }
+    if (s->mark_free.empty()) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        s->mark_pool.push_back(e);
+        s->mark_free.push_back((int)s->mark_pool.size() - 1);
+    }
+    const int idx = s->mark_free.back();
+    s->mark_free.pop_back();
+    HIP_TRY(hipEventRecord(s->mark_pool[idx], s->cur));
+    s->marks.push_back({s->iter, idx});
+    return MMG_OK;
+}
+
 extern "C" int mmg_sampler_sample(mmg_sampler *s) { return sampler_sample(s, true); }
 
 extern "C" int mmg_sampler_update(mmg_sampler *s)
@@ -277,6 +304,7 @@ extern "C" int mmg_sampler_update(mmg_sampler *s)
     if (sample_idx >= 0) s->n_kept++;
     s->iter++;
     s->sampled = false;
+    if (sample_idx >= 0) { int rc = mark_iteration(s); if (rc) return rc; }
     return MMG_OK;
 }
 
@@ -349,6 +377,26 @@ extern "C" int mmg_sampler_sync(mmg_sampler *s)
     if (!s) return fail(MMG_ERR_ARG, "NULL sampler");
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipStreamSynchronize(s->cur));
+    return MMG_OK;
+}
+
+// Wait until the first n_done iterations have completed on the device; iterations enqueued behind them are not waited for (a caller
+// that streams the trace out enqueues the next stretch BEFORE it waits for this one: the device never idles while the host writes).
+extern "C" int mmg_sampler_wait_iterations(mmg_sampler *s, int n_done)
+{
+    if (!s) return fail(MMG_ERR_ARG, "NULL sampler");
+    if (n_done < 0 || n_done > s->iter) return fail(MMG_ERR_ARG, "wait for iterations that were not enqueued");
+    HIP_TRY(hipSetDevice(s->device));
+    // the first mark at or behind n_done; without one (n_done behind the last stored sample) the whole stream
+    size_t k = 0;
+    while (k < s->marks.size() && s->marks[k].first < n_done) ++k;
+    if (k == s->marks.size()) {
+        if (n_done > 0) HIP_TRY(hipStreamSynchronize(s->cur));
+    } else {
+        HIP_TRY(hipEventSynchronize(s->mark_pool[s->marks[k].second]));
+        ++k;
+    }
+    for (size_t i = 0; i < k; ++i) { s->mark_free.push_back(s->marks.front().second); s->marks.pop_front(); }
     return MMG_OK;
 }
 

@@ -218,6 +218,10 @@ class Sampler:
     def sync(self):
         check(self._lib.mmg_sampler_sync(self._h))
 
+    def wait_iterations(self, n_done):
+        """Block until the first n_done iterations are complete on the device (later ones may still be running)."""
+        check(self._lib.mmg_sampler_wait_iterations(self._h, int(n_done)))
+
     @property
     def iteration(self):
         it = C.c_int(0)

@@ -160,7 +160,7 @@ def test_summary_of_long_traces(gpu, orc, S):
 
 
 def test_summary_in_steps_while_the_chain_runs_equals_the_summary_after_it(gpu, orc):
-    """mmg_summary_begin / _advance / _finish and mmg_sampler_get_trace_rows_done: the trace writers of src/mmseq.cpp:911-917 print sample s
+    """mmg_summary_begin / _advance / _finish, mmg_sampler_wait_iterations and mmg_sampler_get_trace_rows_done: the trace writers of src/mmseq.cpp:911-917 print sample s
     inside the loop; here the caller feeds finished samples to the summary and fetches their rows WHILE later iterations are enqueued
     (nothing waits for them: own streams), and ends up with the bits of the summary computed after the chain."""
     S = 64
@@ -182,10 +182,14 @@ def test_summary_in_steps_while_the_chain_runs_equals_the_summary_after_it(gpu, 
         qa.rows(gpu.SERIES_GENE, 0, 1)                  # nothing advanced yet
     got_rows, got_gene = [], []
     a.run(32)
-    a.sync()                                             # samples 0..15 are final
+    with pytest.raises(gpu._lib.MMGError):
+        a.wait_iterations(33)                            # more than was enqueued
     for c in range(4):                                   # 4 chunks of 32 iterations = 16 samples
         if c < 3:
-            a.run(32)                                    # the next chunk is enqueued, NOT waited for, while this one's rows are read
+            a.run(32)                                    # the next chunk is enqueued BEFORE this one is waited for
+        # mmg_sampler_wait_iterations: sample 16 c + 15 is stored by iteration 32 c + 30, the 32 c + 31st; the last chunk asks for every
+        # iteration (behind the last stored sample: the whole stream)
+        a.wait_iterations(32 * c + 31 if c < 3 else 128)
         qa.advance(16 * (c + 1))
         got_rows.append(a.trace_rows_done(0, 16 * c, 16))
         got_gene.append(qa.rows(gpu.SERIES_GENE, 16 * c, 16))
@@ -194,7 +198,6 @@ def test_summary_in_steps_while_the_chain_runs_equals_the_summary_after_it(gpu, 
                 qa.series(gpu.SERIES_GENE)               # columns exist after finish()
             with pytest.raises(gpu._lib.MMGError):
                 qa.finish()                              # ... which wants every sample
-            a.sync()
     qa.finish()
     # the reference: the same chain in one go, summarised after it
     b = gpu.Sampler(prob, mu0, seed=3, gibbs_iter=2 * S, trace_len=S)
