@@ -36,6 +36,7 @@
 
 #include "../../../include/mmgibbs.h"
 #include "hitsio.hpp"
+#include "huffenc.hpp"
 #include "numerics.hpp"
 
 #ifndef MMSEQ_VERSION
@@ -128,6 +129,8 @@ static inline int fmt_g(char *tmp, double v)
 // Trace files are megabytes of 6-digit numbers: deflate level 6 (the reference's Boost default) manages 12 MB/s per core on
 // them, level 1 73 MB/s for files 11 % larger, Huffman coding alone (such text has next to no repeats for LZ77 to find) 110 MB/s for
 // another 3 %.  Huffman-only unless MMSEQ_GZIP_LEVEL asks for a level (default strategy then); any gzip reader reads all of them.
+// The Huffman-only blocks are written by host/huffenc.hpp (4.4 x zlib's rate for them: with zlib the trace writers needed more CPUs
+// than a 16-CPU quota leaves next to the .M writer, and finished a second after the chain).
 static int gzip_level()
 {
     static const int level = [] { const char *e = getenv("MMSEQ_GZIP_LEVEL"); const int v = e ? atoi(e) : 1; return v >= 0 && v <= 9 ? v : 1; }();
@@ -154,6 +157,10 @@ struct GzText {
     }
     static string deflate_chunk(const string &in, bool last)
     {
+        if (!last && gzip_strategy() == Z_HUFFMAN_ONLY) { // the default: host/huffenc.hpp, the same kind of block several times faster
+            string out;
+            if (huffenc::deflate_literals(in.data(), in.size(), out)) return out;
+        }
         z_stream zs;
         memset(&zs, 0, sizeof zs);
         if (deflateInit2(&zs, gzip_level(), Z_DEFLATED, -15, 8, gzip_strategy()) != Z_OK) {

@@ -73,6 +73,42 @@ struct mmg_em;
 
 namespace mmg {
 
+// Device-to-host copies into the caller's (pageable) memory through two pinned buffers the handle keeps: the runtime would otherwise
+// pin and unpin the destination pages for every copy, and a caller that fetches trace rows while the chain runs -- and while its other
+// threads allocate and write files -- had the chain's kernels stall for 20-40 ms at a time around those (un)pinnings (the 50 M-read
+// CLI run: the chain took 4.5 s instead of 3.9 s).  One copy at a time per stage (the owner's mutex).
+struct PinnedStage {
+    static constexpr size_t CHUNK = 16u << 20;
+    void *buf[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    ~PinnedStage()
+    {
+        for (int i = 0; i < 2; ++i) { if (buf[i]) (void)hipHostFree(buf[i]); if (ev[i]) (void)hipEventDestroy(ev[i]); }
+    }
+    hipError_t copy_out(void *dst, const void *dsrc, size_t bytes, hipStream_t st)
+    {
+        for (int i = 0; i < 2; ++i) {
+            if (!buf[i]) { hipError_t e = hipHostMalloc(&buf[i], CHUNK, hipHostMallocDefault); if (e != hipSuccess) { buf[i] = nullptr; return e; } }
+            if (!ev[i]) { hipError_t e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming); if (e != hipSuccess) { ev[i] = nullptr; return e; } }
+        }
+        const size_t chunks = (bytes + CHUNK - 1) / CHUNK;
+        auto issue = [&](size_t c) {
+            const size_t off = c * CHUNK, len = bytes - off < CHUNK ? bytes - off : CHUNK;
+            hipError_t e = hipMemcpyAsync(buf[c & 1], (const char *)dsrc + off, len, hipMemcpyDeviceToHost, st);
+            return e == hipSuccess ? hipEventRecord(ev[c & 1], st) : e;
+        };
+        if (chunks) { hipError_t e = issue(0); if (e != hipSuccess) return e; }
+        for (size_t c = 0; c < chunks; ++c) {
+            if (c + 1 < chunks) { hipError_t e = issue(c + 1); if (e != hipSuccess) return e; } // (its buffer was emptied an iteration ago)
+            hipError_t e = hipEventSynchronize(ev[c & 1]);
+            if (e != hipSuccess) return e;
+            const size_t off = c * CHUNK, len = bytes - off < CHUNK ? bytes - off : CHUNK;
+            std::memcpy((char *)dst + off, buf[c & 1], len);
+        }
+        return hipSuccess;
+    }
+};
+
 // what the summary code needs to see of a sampler (sampler.hip)
 struct SamplerView {
     const mmg_problem *p;

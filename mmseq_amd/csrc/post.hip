@@ -5,6 +5,7 @@
 #include "mmg_launch.h"
 
 #include <cmath>
+#include <mutex>
 #include <vector>
 
 using namespace mmg;
@@ -40,6 +41,10 @@ struct mmg_summary {
     uint8_t *d_multi_t = nullptr, *d_multi_v = nullptr;
     int32_t *d_pind = nullptr;
     double *d_V = nullptr, *d_propV = nullptr, *d_tw = nullptr;
+    // mmg_summary_get_rows: a stream and pinned buffers of its own (the writers of a caller fetch rows while the chain runs)
+    hipStream_t rows_st = nullptr;
+    std::mutex rows_mu;
+    PinnedStage rows_stage;
 };
 
 static void summary_free(mmg_summary *q)
@@ -52,6 +57,7 @@ static void summary_free(mmg_summary *q)
     for (auto &b : q->ser) for (void *x : {(void *)b.log_mean, (void *)b.var, (void *)b.tau, (void *)b.pct, (void *)b.rc}) if (x) (void)hipFree(x);
     for (auto &b : q->prop) for (void *x : {(void *)b.mean, (void *)b.probit_mean, (void *)b.probit_sd, (void *)b.pct}) if (x) (void)hipFree(x);
     if (q->st) (void)hipStreamDestroy(q->st);
+    if (q->rows_st) (void)hipStreamDestroy(q->rows_st);
     delete q;
 }
 
@@ -324,7 +330,11 @@ extern "C" int mmg_summary_get_rows(mmg_summary *q, int kind, int first_sample, 
     if (first_sample < 0 || n_samples < 0 || (uint32_t)(first_sample + n_samples) > q->S) return fail(MMG_ERR_ARG, "bad sample range");
     if ((uint32_t)(first_sample + n_samples) > q->done) return fail(MMG_ERR_STATE, "rows of samples that were not yet handed to mmg_summary_advance");
     HIP_TRY(hipSetDevice(q->device));
-    if (width && n_samples) HIP_TRY(hipMemcpy(out, src + (size_t)first_sample * width, (size_t)n_samples * width * 8, hipMemcpyDeviceToHost));
+    if (width && n_samples) {
+        std::lock_guard<std::mutex> lock(q->rows_mu);
+        if (!q->rows_st) HIP_TRY(hipStreamCreateWithFlags(&q->rows_st, hipStreamNonBlocking));
+        HIP_TRY(q->rows_stage.copy_out(out, src + (size_t)first_sample * width, (size_t)n_samples * width * 8, q->rows_st));
+    }
     return MMG_OK;
 }
 

@@ -30,6 +30,7 @@ struct mmg_sampler {
     double *d_reader_tmp = nullptr;                        // its gather buffer, kept (hipFree would wait for the running chain)
     size_t reader_cap = 0;
     std::mutex reader_mu;
+    PinnedStage reader_stage;
     // marks: an event behind every iteration that stored a sample, for mmg_sampler_wait_iterations (events without timing, recycled)
     std::vector<hipEvent_t> mark_pool;
     std::vector<int> mark_free;
@@ -481,8 +482,7 @@ extern "C" int mmg_sampler_get_trace_rows_done(mmg_sampler *s, int chain, int fi
         launch_gather_rows(src, s->d_reader_tmp, (uint32_t)n, (uint32_t)count, 8, s->p->d_int_of_ext, s->reader);
         src = s->d_reader_tmp;
     }
-    hipError_t e = hipMemcpyAsync(out, src, (size_t)count * n * sizeof(double), hipMemcpyDeviceToHost, s->reader);
-    if (e == hipSuccess) e = hipStreamSynchronize(s->reader);
+    const hipError_t e = s->reader_stage.copy_out(out, src, (size_t)count * n * sizeof(double), s->reader);
     if (e != hipSuccess) return fail(MMG_ERR_HIP, std::string("get_trace_rows_done: ") + hipGetErrorString(e));
     return MMG_OK;
 }
