@@ -19,11 +19,17 @@ __global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict
 {
     static_assert(NCH == 2 || NCH == 4, "chains are fused in pairs or fours");
     constexpr int WIN = (int)SELL_WIN;
-    constexpr int SH = NCH == 2 ? 4 : 5;                       // log2 of the bytes per window entry
-    __shared__ __attribute__((aligned(16))) double s_mu[(WIN + 1) * NCH]; // entry [WIN] stays 0.0 for every chain: what pad slots read
-    // counts laid out like the weights, [index][chain] at 8 bytes per chain (upper word unused): the offset that gathered a hit's
-    // weights, plus 8 c, addresses chain c's count of it -- no address arithmetic per pick
-    __shared__ int32_t s_cnt[2 * NCH * (WIN + 1)];
+    constexpr int SH = 3;                                      // log2 of the bytes per window entry
+    // One window per chain, CS entries apart: a hit's weights are NCH 8-byte reads at one offset register and NCH immediate offsets.
+    // (Interleaved [index][chain] entries read with one ds_read_b128 per pair of chains moved the same bytes with half the
+    // instructions, but at 51 % bank-conflict cycles where the 8-byte reads of k_sample_sell see 40 %: the fused kernel is bound by
+    // the LDS pipe, so the conflicts decide.  CS = WIN + 2: not a multiple of 64 entries, or the compiler merges the reads of two
+    // chains into one ds_read2st64_b64, which behaves like the 16-byte read.)  Entry [WIN] stays 0.0: what pad slots read.
+    constexpr int CS = WIN + 2;
+    __shared__ __attribute__((aligned(16))) double s_mu[CS * NCH];
+    // counts laid out like the weights, 8 bytes per entry (upper word unused): the offset that gathered a hit's weight, plus chain c's
+    // window offset, addresses chain c's count of it -- no address arithmetic per pick
+    __shared__ int32_t s_cnt[2 * CS * NCH];
     const uint32_t lane = threadIdx.x;
     // grid.y = group of NCH chains: one launch advances all the fused chains of a sampler (the tail of one group overlaps the head of
     // the next instead of a launch boundary)
@@ -41,15 +47,15 @@ __global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict
     const uint32_t nt = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(t_end - t_begin));
     const SellTile *__restrict__ T = tiles + t_begin;
 
-    for (int i = lane; i < 2 * NCH * (WIN + 1); i += 64) s_cnt[i] = 0;
-    if (lane < NCH) s_mu[WIN * NCH + lane] = 0.0;
+    for (int i = lane; i < 2 * CS * NCH; i += 64) s_cnt[i] = 0;
+    if (lane < NCH) s_mu[lane * CS + WIN] = 0.0;
 
     auto flush_window = [&](uint32_t base) {
         for (int i = lane; i < WIN; i += 64) {
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                const int32_t v = s_cnt[2 * (i * NCH + c)];
-                s_cnt[2 * (i * NCH + c)] = 0;
+                const int32_t v = s_cnt[2 * (c * CS + i)];
+                s_cnt[2 * (c * CS + i)] = 0;
                 if (v) global_count_add(gcnt + (size_t)c * a.n, base + (uint32_t)i, v);
             }
         }
@@ -58,7 +64,7 @@ __global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict
         for (int i = lane; i < WIN; i += 64) {
             const uint32_t col = base + (uint32_t)i;
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) s_mu[i * NCH + c] = col < a.n ? gmu[(size_t)c * a.n + col] : 0.0;
+            for (int c = 0; c < NCH; ++c) s_mu[c * CS + i] = col < a.n ? gmu[(size_t)c * a.n + col] : 0.0;
         }
     };
     // byte k of a group word as the LDS byte offset of the window entry (all chains)
@@ -79,9 +85,9 @@ __global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict
     struct W { double c[NCH]; };
     auto wo = [&](uint32_t off) {
         W r;
-        const f64x2 *p = (const f64x2 *)((const char *)s_mu + off);
+        const double *p = (const double *)((const char *)s_mu + off);
 #pragma unroll
-        for (int q = 0; q < NCH / 2; ++q) { const f64x2 v = p[q]; r.c[2 * q] = v.x; r.c[2 * q + 1] = v.y; }
+        for (int c = 0; c < NCH; ++c) r.c[c] = p[c * CS];
         return r;
     };
 
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict
 #undef SM_STEP
             }
             const bool hit = v != 0u; // a stored group word is never 0
-            const double *m = (const double *)((const char *)s_mu + c * 8);
+            const double *m = s_mu + c * CS;
             uint32_t sel; // LDS byte offset of the selected window entry
             {
                 const uint32_t o0 = SM_OFF0(v), o1 = SM_OFF1(v), o2 = SM_OFF2(v), o3 = SM_OFF3(v);
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict
                     if (!found) sel = off_of(L - 1); // rounding left target >= total: the last real hit
                 }
             }
-            atomicAdd((int32_t *)((char *)s_cnt + c * 8 + sel), 1);
+            atomicAdd((int32_t *)((char *)s_cnt + c * (CS * 8) + sel), 1);
         }
     };
 #undef SM_GROUPS
@@ -281,13 +287,13 @@ __global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict
     struct RowViewMulti {
         const uint32_t *cl;
         uint32_t L, wbase, n;
-        const double *s_mu_c; // s_mu + chain
+        const double *s_mu_c; // the chain's window
         const double *gmu_c;  // gmu + chain * n
         __device__ __forceinline__ uint32_t col(uint32_t j) const { return cl[j]; }
         __device__ __forceinline__ double w(uint32_t j) const
         {
             const uint32_t col = cl[j], dd = col - wbase;
-            return dd < (uint32_t)SELL_WIN ? s_mu_c[dd * NCH] : gmu_c[col];
+            return dd < (uint32_t)SELL_WIN ? s_mu_c[dd] : gmu_c[col];
         }
         __device__ __forceinline__ double total() const
         {
@@ -315,10 +321,10 @@ __global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict
                 int32_t *gc = gcnt + (size_t)c * a.n;
                 auto add = [&](uint32_t col, int32_t x) {
                     const uint32_t dd = col - wbase;
-                    if (dd < (uint32_t)WIN) atomicAdd(&s_cnt[2 * (dd * NCH + c)], x);
+                    if (dd < (uint32_t)WIN) atomicAdd(&s_cnt[2 * (c * CS + dd)], x);
                     else global_count_add(gc, col, x);
                 };
-                RowViewMulti v{col_idx + st, L, wbase, a.n, s_mu + c, gmu + (size_t)c * a.n};
+                RowViewMulti v{col_idx + st, L, wbase, a.n, s_mu + c * CS, gmu + (size_t)c * a.n};
                 SampleArgs ac = a;
                 ac.chain = a.chain + (uint32_t)c;
                 allocate_row<false>(v, add, 1u, ac, a.row_id_base + d.r0 + lane);
