@@ -216,3 +216,25 @@ def test_summary_in_steps_while_the_chain_runs_equals_the_summary_after_it(gpu, 
     assert np.array_equal(np.concatenate(got_gene), qb.rows(gpu.SERIES_GENE))
     assert np.array_equal(np.concatenate(got_rows), b.trace_rows(0))
     qa.close(); qb.close(); a.close(); b.close(); prob.close()
+
+
+def test_row_fetches_larger_than_a_staging_buffer(gpu):
+    """mmg_sampler_get_trace_rows_done and mmg_summary_get_rows copy through two 16 MB pinned buffers (mmg_host.h: PinnedStage): rows of
+    200 k transcripts x 24 samples are 38 MB, three chunks with a ragged last one -- the same numbers as the one-piece copies."""
+    n, S = 200_000, 24
+    prob = gpu.Problem.synthetic(400_000, n, 6, seed=4)
+    mu0, _ = prob.start_values()
+    s = gpu.Sampler(prob, mu0, seed=2, gibbs_iter=S, trace_len=S)
+    s.run(S)
+    s.sync()
+    whole = s.trace_rows(0)                                       # one hipMemcpy of the gathered rows
+    assert np.array_equal(s.trace_rows_done(0, 0, S), whole)
+    assert np.array_equal(s.trace_rows_done(0, 5, 17), whole[5:22])
+    assert np.array_equal(s.trace(0).T, whole)
+    genes = [[t, t + 1] for t in range(0, n, 2)]
+    q = gpu.Summary(s, genes=genes, percentile_index=[0])
+    prop = q.rows(gpu.SERIES_TRANSCRIPT)                          # [S, n]: 38 MB through the summary's buffers
+    gsum = q.rows(gpu.SERIES_GENE)
+    assert np.array_equal(gsum, whole[:, 0::2] + whole[:, 1::2])
+    assert np.array_equal(prop, whole / np.repeat(gsum, 2, axis=1))
+    q.close(); s.close(); prob.close()
