@@ -19,9 +19,7 @@ if mode in ("A", "B"):   # the library's own group (A), with an injected failure
     import os
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from mmseq_amd import gibbs as G
-    from oracle import binding as B
-    p, _ = B.synth_problem(R=20000, T=500, avg_hits=5, seed=2)
-    prob = G.Problem.from_csr(p.row_ptr, p.col_idx, p.l)
+    prob = G.Problem.synthetic(20000, 500, 5)
     mu0, _ = prob.start_values()
     s = G.Sampler(prob, mu0, seed=1, gibbs_iter=8, trace_len=8)
     grp = G.Group([0])

@@ -5,11 +5,28 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from mmseq_amd import gibbs as G
-from oracle import binding as B
+
+
+class _Csr:
+    """rows of 1 + Poisson(6) distinct hits within +-64 of a random centre, every tenth row with one hit anywhere"""
+    def __init__(self, R, T, rng):
+        rows = []
+        for i in range(R):
+            c = int(rng.integers(0, T))
+            L = 1 + int(rng.poisson(6))
+            h = np.unique(np.clip(c + rng.integers(-64, 65, size=L), 0, T - 1))
+            if i % 10 == 0:
+                h = np.unique(np.append(h, rng.integers(0, T)))
+            rows.append(h.astype(np.uint32))
+        self.m, self.n = R, T
+        self.row_ptr = np.concatenate([[0], np.cumsum([r.size for r in rows])]).astype(np.uint64)
+        self.col_idx = np.concatenate(rows)
+        self.l = rng.uniform(0.5, 3.0, T)
+
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(1)
-p, _ = B.synth_problem(R=120000, T=9000, avg_hits=7, seed=3, sort=False, far_fraction=0.1)
+p = _Csr(60000, 9000, rng)
 k = rng.choice([1, 1, 1, 2, 6, 80, 400], size=p.m).astype(np.uint32)
 scat = rng.permutation(p.n).astype(np.uint32)
 l_ext = np.empty(p.n); l_ext[scat] = p.l
