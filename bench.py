@@ -128,7 +128,7 @@ def cpu_quota():
         return None
 
 
-def cpu_baseline(args, prob, mu0):
+def cpu_baseline(args, prob, mu0, device=0):
     """Oracle ("port" of src/mmseq.cpp:851-918, reference-structured: per-thread MT19937, count slabs of n x threads ints cleared and
     reduced every iteration, conditional-binomial multinomial) timed on this host's cores on the FULL problem: the device CSR is
     downloaded (stored order: sorted rows, which only helps the CPU's caches) and `--cpu-iters` iterations run at the best thread count;
@@ -156,7 +156,19 @@ def cpu_baseline(args, prob, mu0):
     r = B.gibbs_ref(p, mu0, seed=args.seed, n_iter=iters, trace_len=iters, threads=best_t, want_trace=False)
     it_s = iters / r["seconds"]
     r1 = B.gibbs_ref(ps, mu0, seed=args.seed, n_iter=2, trace_len=2, threads=1, want_trace=False)
-    return {"value": it_s, "unit": "iterations/s", "cores": best_t, "kind": "port",
+    # SURVEY 8(d) also asks for the config-2 shape (5 M reads x 50 k transcripts, 1 + Poisson(7) hits) for >= 64 iterations at all cores
+    # and at one thread (there: 8 iterations, 64 would take half a minute)
+    from mmseq_amd import Problem
+    p2 = Problem.synthetic(5_000_000, 50_000, 8.0, seed=args.seed, mapped_reads=5_000_000, device=device)
+    mu2, _ = p2.start_values()
+    rp2, ci2 = p2.download()
+    q2 = B.Problem(rp2, ci2, p2.l())
+    p2.close()
+    c2 = B.gibbs_ref(q2, mu2, seed=args.seed, n_iter=64, trace_len=64, threads=best_t, want_trace=False)
+    c2_1 = B.gibbs_ref(q2, mu2, seed=args.seed, n_iter=8, trace_len=8, threads=1, want_trace=False)
+    cfg2 = {"iterations_per_sec": 64 / c2["seconds"], "iterations": 64, "cores": best_t,
+            "single_thread_iterations_per_sec": 8 / c2_1["seconds"], "single_thread_iterations": 8}
+    return {"value": it_s, "unit": "iterations/s", "cores": best_t, "kind": "port", "cfg2": cfg2,
             "sample": "%d rows (the full problem, %d hits), %d iterations, %d threads (best of %s; %d CPUs, quota %s)"
                       % (inf.m, inf.nnz, iters, best_t, cands, ncpu, quota),
             "reads_iters_per_sec": it_s * inf.m, "seconds": r["seconds"],
@@ -493,7 +505,7 @@ def main():
             out["config"]["k1_ms_per_rank"] = k1_ranks
         record = {"headline": dict(out), "roofline_k1": full_roof}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, prob, mu0)
+            out["cpu_baseline"] = cpu_baseline(args, prob, mu0, device=local_rank)
             out["speedup_vs_cpu_baseline"] = iters_per_s / out["cpu_baseline"]["value"]
         if world == 1 and not args.no_extra:
             prob.close()
