@@ -240,8 +240,8 @@ int mmg_sampler_sync(mmg_sampler *s);
 /* Wait until the first n_done iterations (n_done <= mmg_sampler_iteration) have completed on the device -- not for what is enqueued
  * behind them.  The reference prints sample s inside its loop (src/mmseq.cpp:911-917); a caller that streams the trace out enqueues
  * the next stretch of iterations, THEN waits for the previous one and fetches its rows (mmg_sampler_get_trace_rows_done), so the device
- * does not idle while the host formats.  An event follows every iteration that stored a sample; other values of n_done wait for the
- * next such iteration (or the whole stream when there is none). */
+ * does not idle while the host formats.  An event follows the iteration that stored sample 16 j - 1 (j = 1, 2, ...) and the last sample;
+ * other values of n_done wait for the next such iteration (or the whole stream when there is none). */
 int mmg_sampler_wait_iterations(mmg_sampler *s, int n_done);
 int mmg_sampler_iteration(const mmg_sampler *s, int *iter);
 /* Trace of one chain, transcript-major exactly like mu_trace at src/mmseq.cpp:914:
