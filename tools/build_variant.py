@@ -8,7 +8,7 @@ name, subs = sys.argv[1], sys.argv[2:]
 dst = os.path.join(ROOT, "build_ab", name)
 shutil.rmtree(dst, ignore_errors=True)
 os.makedirs(os.path.join(dst, "mmseq_amd"))
-shutil.copytree(os.path.join(ROOT, "mmseq_amd", "csrc"), os.path.join(dst, "mmseq_amd", "csrc"), ignore=shutil.ignore_patterns("*.o", "*.so", "mmseq", "hitstools", "t2g_hits", "synth_hits", "test_group"))
+shutil.copytree(os.path.join(ROOT, "mmseq_amd", "csrc"), os.path.join(dst, "mmseq_amd", "csrc"), ignore=shutil.ignore_patterns("*.o", "*.o.*", "*.so", "asan", "huffenc_test", "mmseq", "hitstools", "t2g_hits", "synth_hits", "test_group"))
 shutil.copytree(os.path.join(ROOT, "include"), os.path.join(dst, "include"))
 triples = []
 for sub in subs:
