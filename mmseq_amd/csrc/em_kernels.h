@@ -451,6 +451,7 @@ __global__ __launch_bounds__(64 * W) void k_em_sell(const IdxT *__restrict__ row
     load_window(cur_base);
     __syncthreads();
     issue(dA, bufA);
+    __builtin_amdgcn_sched_barrier(0); // A's block is requested before B's, here as in the loop (sell_multi_kernels.h): the waits are by count
     issue(dB, bufB);
     for (uint64_t g = wave; g < nt; g += 2 * W) {
         const SellTile nA = tile_at(g + 2 * W), nB = tile_at(g + 3 * W);

@@ -592,6 +592,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
     uint32_t cur_base = dA.wbase;
     __syncthreads();
     issue(dA, bufA);
+    __builtin_amdgcn_sched_barrier(0); // A's block is requested before B's, here as in the loop (sell_multi_kernels.h): the waits are by count
     issue(dB, bufB);
     for (uint32_t i = 0; i < nt; i += 2) {
         const SellTile nA = tile_at(i + 2), nB = tile_at(i + 3);

@@ -136,6 +136,150 @@ __global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict
         }
     };
 
+
+    // ---- the walk of a register-path tile of at most 8 groups, written out per group count (chain pairs only) --------------------
+    // The generic walk below is what the compiler makes of one body for every ng: a wave issues a group's gathers, waits for all of
+    // them, adds, tests ng, and walks the two chains' picks one behind the other -- about seven LDS round trips per tile that nothing
+    // of the SAME wave overlaps, with four waves per SIMD to hide them (counters: 34 % of the wave cycles at s_waitcnt, VALU 0.70 and
+    // LDS 0.68 busy).  Here a tile's ng selects straight-line code: the gathers of group i + 1 are in flight while group i is added
+    // (two register sets), no boundary is copied, the sweep of the pick has no entry branches, and the two chains' picks are
+    // interleaved -- chain 1's sweep runs while chain 0's in-group gathers travel.  Same additions, comparisons and draws in the same
+    // order per chain: bit-identical to the generic walk (tests/test_gpu_parity.py, test_gpu_fullsize.py).
+    auto walk_fixed = [&](const SellTile &d, const Buf &bf, uint32_t which, auto ng_tag) {
+        constexpr int NG = decltype(ng_tag)::value;
+        static_assert(NCH == 2 && NG >= 1 && NG <= 8, "chain pairs, cached groups only");
+        const uint32_t gw[8] = {bf.g0, bf.g1, bf.g2, bf.g3, bf.g4, bf.g5, bf.g6, bf.g7};
+        struct G4 { double w[4][2]; };
+        auto gather = [&](uint32_t v) {
+            G4 r;
+            const uint32_t o0 = SM_OFF0(v), o1 = SM_OFF1(v), o2 = SM_OFF2(v), o3 = SM_OFF3(v);
+            const uint32_t o[4] = {o0, o1, o2, o3};
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const double *p = (const double *)((const char *)s_mu + o[h]);
+                r.w[h][0] = p[0];
+                r.w[h][1] = p[CS];
+            }
+            return r;
+        };
+        double P[NG][2];
+        {
+            G4 cur = gather(gw[0]), nxt = cur;
+            if (NG > 1) nxt = gather(gw[1]);
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    double t = i == 0 ? cur.w[0][c] : P[i - 1][c] + cur.w[0][c]; // 0.0 + w == w exactly
+                    t += cur.w[1][c]; t += cur.w[2][c]; t += cur.w[3][c];
+                    P[i][c] = t;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                cur = nxt;
+                if (i + 2 < NG) nxt = gather(gw[i + 2]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        uint32_t x[2], v[2], sel[2], oo[2][4];
+        double target[2], acc[2], wi[2][3];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            x[c] = which ? xrowB[c] : xrowA[c];
+            const double ts = P[NG - 1][c] * 0x1p-32, hs = ts * 0.5;
+            target[c] = draw_target(x[c], ts, hs); // mmg_math.h
+        }
+#define SMF_STEP(i, prev) "v_cmpx_lt_f64_e64 %[tm], %[t], %[p" #i "]\n\t" "v_mov_b32 %[v], %[g" #i "]\n\t" "v_mov_b64 %[acc], " prev "\n\t"
+#define SMF_HEAD "s_mov_b64 %[sv], exec\n\t" "v_mov_b32 %[v], 0\n\t" "v_mov_b64 %[acc], 0\n\t"
+#define SMF_TAIL "s_mov_b64 exec, %[sv]"
+#define SMF_OUT(c) [v] "=&v"(v[c]), [acc] "=&v"(acc[c]), [sv] "=&s"(sv), [tm] "=&s"(tm)
+#define SMF_IN(c, n) [t] "v"(target[c]), [p0] "v"(P[0][c]), [p1] "v"(P[n > 1 ? 1 : 0][c]), [p2] "v"(P[n > 2 ? 2 : 0][c]), [p3] "v"(P[n > 3 ? 3 : 0][c]), \
+                     [p4] "v"(P[n > 4 ? 4 : 0][c]), [p5] "v"(P[n > 5 ? 5 : 0][c]), [p6] "v"(P[n > 6 ? 6 : 0][c]), [p7] "v"(P[n > 7 ? 7 : 0][c]),          \
+                     [g0] "v"(gw[0]), [g1] "v"(gw[n > 1 ? 1 : 0]), [g2] "v"(gw[n > 2 ? 2 : 0]), [g3] "v"(gw[n > 3 ? 3 : 0]), [g4] "v"(gw[n > 4 ? 4 : 0]), \
+                     [g5] "v"(gw[n > 5 ? 5 : 0]), [g6] "v"(gw[n > 6 ? 6 : 0]), [g7] "v"(gw[n > 7 ? 7 : 0])
+#define SMF_S0 SMF_STEP(0, "0")
+#define SMF_S1 SMF_STEP(1, "%[p0]") SMF_S0
+#define SMF_S2 SMF_STEP(2, "%[p1]") SMF_S1
+#define SMF_S3 SMF_STEP(3, "%[p2]") SMF_S2
+#define SMF_S4 SMF_STEP(4, "%[p3]") SMF_S3
+#define SMF_S5 SMF_STEP(5, "%[p4]") SMF_S4
+#define SMF_S6 SMF_STEP(6, "%[p5]") SMF_S5
+#define SMF_S7 SMF_STEP(7, "%[p6]") SMF_S6
+        auto sweep = [&](auto c_tag) { // first boundary above the chain's target: its group word and the prefix before it (k_sample_sell: draw)
+            constexpr int c = decltype(c_tag)::value;
+            uint64_t sv, tm;
+            if constexpr (NG == 1) asm volatile(SMF_HEAD SMF_S0 SMF_TAIL : SMF_OUT(c) : SMF_IN(c, 1));
+            else if constexpr (NG == 2) asm volatile(SMF_HEAD SMF_S1 SMF_TAIL : SMF_OUT(c) : SMF_IN(c, 2));
+            else if constexpr (NG == 3) asm volatile(SMF_HEAD SMF_S2 SMF_TAIL : SMF_OUT(c) : SMF_IN(c, 3));
+            else if constexpr (NG == 4) asm volatile(SMF_HEAD SMF_S3 SMF_TAIL : SMF_OUT(c) : SMF_IN(c, 4));
+            else if constexpr (NG == 5) asm volatile(SMF_HEAD SMF_S4 SMF_TAIL : SMF_OUT(c) : SMF_IN(c, 5));
+            else if constexpr (NG == 6) asm volatile(SMF_HEAD SMF_S5 SMF_TAIL : SMF_OUT(c) : SMF_IN(c, 6));
+            else if constexpr (NG == 7) asm volatile(SMF_HEAD SMF_S6 SMF_TAIL : SMF_OUT(c) : SMF_IN(c, 7));
+            else asm volatile(SMF_HEAD SMF_S7 SMF_TAIL : SMF_OUT(c) : SMF_IN(c, 8));
+            // inside the group: the three gathers go out now and are waited for in resolve()
+            oo[c][0] = SM_OFF0(v[c]); oo[c][1] = SM_OFF1(v[c]); oo[c][2] = SM_OFF2(v[c]); oo[c][3] = SM_OFF3(v[c]);
+            const char *m = (const char *)(s_mu + c * CS);
+#pragma unroll
+            for (int h = 0; h < 3; ++h) wi[c][h] = *(const double *)(m + oo[c][h]);
+        };
+#undef SMF_S0
+#undef SMF_S1
+#undef SMF_S2
+#undef SMF_S3
+#undef SMF_S4
+#undef SMF_S5
+#undef SMF_S6
+#undef SMF_S7
+#undef SMF_IN
+#undef SMF_OUT
+#undef SMF_TAIL
+#undef SMF_HEAD
+#undef SMF_STEP
+        auto resolve = [&](int c) {
+            const double p0 = acc[c] + wi[c][0], p1 = p0 + wi[c][1], p2 = p1 + wi[c][2];
+            uint32_t s = oo[c][3];
+            uint64_t sv, tm;
+            asm volatile("s_mov_b64 %[sv], exec\n\t"
+                         "v_cmpx_lt_f64_e64 %[tm], %[t], %[p2]\n\t" "v_mov_b32 %[sel], %[o2]\n\t"
+                         "v_cmpx_lt_f64_e64 %[tm], %[t], %[p1]\n\t" "v_mov_b32 %[sel], %[o1]\n\t"
+                         "v_cmpx_lt_f64_e64 %[tm], %[t], %[p0]\n\t" "v_mov_b32 %[sel], %[o0]\n\t"
+                         "s_mov_b64 exec, %[sv]"
+                         : [sel] "+&v"(s), [sv] "=&s"(sv), [tm] "=&s"(tm)
+                         : [t] "v"(target[c]), [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [o0] "v"(oo[c][0]), [o1] "v"(oo[c][1]), [o2] "v"(oo[c][2]));
+            sel[c] = s;
+        };
+        sweep(IntTag<0>());
+        __builtin_amdgcn_sched_barrier(0);
+        sweep(IntTag<1>());
+        __builtin_amdgcn_sched_barrier(0);
+        resolve(0);
+        resolve(1);
+        if ((v[0] == 0u) | (v[1] == 0u)) { // rare: no row in this lane, a degenerate total, rounding (a stored group word is never 0)
+            uint32_t L = 0;
+#pragma unroll
+            for (int i = 0; i < NG; ++i) L += sell_group_hits(gw[i]);
+            auto off_of = [&](uint32_t j) -> uint32_t {
+                uint32_t r = gw[0];
+                asm("" : "+v"(r));
+#pragma unroll
+                for (int i = 1; i < NG; ++i) { r = ((j >> 2) == (uint32_t)i) ? gw[i] : r; asm("" : "+v"(r)); }
+                return ((r >> (8u * (j & 3u))) & 0xffu) << SH;
+            };
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if (v[c] != 0u) continue;
+                const double tc = P[NG - 1][c];
+                if (L == 0) sel[c] = (uint32_t)WIN << SH; // the count of the pad slot, which is never flushed
+                else if (!(tc > 0.0) || !(tc < __builtin_huge_val())) {
+                    const uint32_t j = (uint32_t)(u32_unit(x[c]) * (double)L);
+                    sel[c] = off_of(j < L ? j : L - 1);
+                } else sel[c] = off_of(L - 1); // rounding left target >= total: the last real hit
+            }
+        }
+        atomicAdd((int32_t *)((char *)s_cnt + sel[0]), 1);
+        atomicAdd((int32_t *)((char *)s_cnt + (CS * 8) + sel[1]), 1);
+    };
+
     auto walk = [&](const SellTile &d, const Buf &bf, uint32_t which) {
         const uint32_t ng = d.ng();                                    // uniform
         const uint32_t *__restrict__ src = (const uint32_t *)(stream + d.off16 * 16) + lane; // groups beyond the cached ones
@@ -341,8 +485,21 @@ __global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict
             cur_base = d.wbase;
             __syncthreads();
         }
-        if (d.flags() & SELL_FAST) walk(d, bf, which);
-        else slow_tile(d);
+        if (d.flags() & SELL_FAST) {
+            if constexpr (NCH == 2) {
+                switch (d.ng()) { // uniform
+                case 1: walk_fixed(d, bf, which, IntTag<1>()); break;
+                case 2: walk_fixed(d, bf, which, IntTag<2>()); break;
+                case 3: walk_fixed(d, bf, which, IntTag<3>()); break;
+                case 4: walk_fixed(d, bf, which, IntTag<4>()); break;
+                case 5: walk_fixed(d, bf, which, IntTag<5>()); break;
+                case 6: walk_fixed(d, bf, which, IntTag<6>()); break;
+                case 7: walk_fixed(d, bf, which, IntTag<7>()); break;
+                case 8: walk_fixed(d, bf, which, IntTag<8>()); break;
+                default: walk(d, bf, which); break; // rows of more than 32 hits (ng = 0 does not occur on a register-path tile)
+                }
+            } else walk(d, bf, which);
+        } else slow_tile(d);
         issue(refill, bf);
     };
 
@@ -359,10 +516,20 @@ __global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict
     uint32_t cur_base = dA.wbase;
     __syncthreads();
     issue(dA, bufA);
+    // tile A's block is requested BEFORE tile B's, here as in the loop: the waits are by count, and with the two requests swapped (the
+    // scheduler is free to) the count valid on entry is 0 for tile A -- which the loop header then inherits for every iteration: the
+    // walk of every tile A would wait for the block of tile B requested just before it
+    __builtin_amdgcn_sched_barrier(0);
     issue(dB, bufB);
     for (uint32_t i = 0; i < nt; i += 2) {
         const SellTile nA = tile_at(i + 2), nB = tile_at(i + 3);
         pair_rng(dA, dB);
+        if constexpr (NCH == 2) {
+            // the descriptors' scalar loads are waited for HERE, behind the Philox rounds: scalar loads return out of order, so with
+            // one of them outstanding the walk's first wait for its gathers would be a wait for everything (lgkmcnt(0)) -- including
+            // the gathers of the group it has just requested ahead
+            asm volatile("" ::"s"(nA.off16), "s"(nA.r0), "s"(nA.wbase), "s"(nA.meta), "s"(nB.off16), "s"(nB.r0), "s"(nB.wbase), "s"(nB.meta));
+        }
         process(dA, cur_base, nA, bufA, 0);
         process(dB, cur_base, nB, bufB, 1);
         dA = nA;
