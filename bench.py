@@ -474,13 +474,28 @@ def main():
         b_k1 = 4 * (inf.m + 1) + 4 * inf.nnz + 12 * inf.n
         kname = {0: "k_sample", 2: "k_sample_sell"}[inf.sample_kernel]
         # chains > 1: one event pair brackets the whole sample() call -- pair launches plus the launches for the other tile lists;
-        # per-kernel PMC figures belong to the 1-chain run only
-        full_roof = roofline_block(kname + " (K1)", "k1_1chain" if C == 1 and world == 1 else "none", k1_ms * 1e-3, tm["sample_launches"], inf.n_tiles,
+        # per-kernel PMC figures belong to the 1-chain run only.  Chains mode at ANY world size runs the kernel and the problem of the
+        # 1-GPU run on every GPU (k1_ms is rank 0's own launch time): the same counter entry applies.  A read shard is another problem
+        # (fewer tiles per launch): no counter entry, the fraction then comes from the shard's own stream bytes (stream_frac_of_peak).
+        entry = "k1_1chain" if C == 1 and args.mode == "chains" and (args.rows, args.transcripts, args.avg_hits) == (50_000_000, 200_000, 20.0) else "none"
+        full_roof = roofline_block(kname + " (K1)", entry, k1_ms * 1e-3, tm["sample_launches"], inf.n_tiles,
                                    stream_bytes=inf.stream_bytes, algorithmic_bytes=b_k1)
+        if full_roof["frac"] is None:
+            # no counter pass of this exact launch: what the kernel must read (its stream) + the algorithmic mu / count bytes, over its time
+            full_roof["traffic_is"] = "stream bytes + 12 n (no PMC pass of this launch shape)"
+            full_roof["achieved"] = (inf.stream_bytes + 12 * inf.n) / (k1_ms * 1e-3) / 1e9
+            full_roof["frac"] = full_roof["achieved"] / HBM_PEAK_GBS
+        if k1_ranks:
+            full_roof["k1_ms_per_rank_max"] = max(k1_ranks)
+            full_roof["k1_ms_per_rank_mean"] = sum(k1_ranks) / len(k1_ranks)
+            full_roof["shard_balance" if args.mode == "shard" else "rank_balance"] = max(k1_ranks) / (sum(k1_ranks) / len(k1_ranks))
         full_roof["padded_slots_per_hit"] = (inf.padded_slots / inf.nnz) if inf.nnz else None
         full_roof["k_update_avg_launch_ms"] = k2_ms
         # the contract's six first, then one scalar per BASELINE config and side measurement (filled in below), then the detail
         roof = {k: full_roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms")}
+        for k in ("shard_balance", "rank_balance", "k1_ms_per_rank_max", "k1_ms_per_rank_mean", "traffic_is"):
+            if k in full_roof:
+                roof[k] = full_roof[k]
         out = {
             "metric": "gibbs_iterations_per_sec", "value": iters_per_s, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

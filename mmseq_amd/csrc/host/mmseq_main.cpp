@@ -103,14 +103,35 @@ struct CliOption {
 // the background writer of .k / .M (if any) finishes its files before the process leaves on a device error: the reference has
 // written both by then (src/mmseq.cpp:682-695), and exit() must not run under a thread that is still formatting
 static std::thread *g_background_writer = nullptr;
+// Worker threads (the trace writers and their fetchers) never call exit(): exit() runs the atexit handlers and the HIP / RCCL
+// teardown under the main thread's feet, and two workers failing together would both join the background writer.  A worker RECORDS
+// its error (first one wins) and returns; the main thread sees the flag, stops the workers (g_stop_workers: wakes them, joins them)
+// and leaves with the message -- exit() on the main thread only.
+static std::atomic<bool> g_worker_failed{false};
+static std::mutex g_worker_mu;
+static std::string g_worker_msg;
+static std::function<void()> g_stop_workers; // set while worker threads of main() run: makes them return and joins them
+static bool worker_failed(int rc, const char *what)
+{
+    if (rc == 0) return false;
+    std::lock_guard<std::mutex> lk(g_worker_mu);
+    if (!g_worker_failed.load()) g_worker_msg = std::string(mmg_last_error()) + " (" + what + ")";
+    g_worker_failed.store(true);
+    return true;
+}
+[[noreturn]] static void main_thread_exit(const std::string &msg)
+{
+    cerr << "Error: " << msg << endl;
+    if (g_stop_workers) { auto f = g_stop_workers; g_stop_workers = nullptr; f(); }
+    if (g_background_writer && g_background_writer->joinable()) g_background_writer->join();
+    exit(1);
+}
 #define MMG_TRY(expr)                                                                     \
     do {                                                                                  \
-        if ((expr) != 0) {                                                                \
-            cerr << "Error: " << mmg_last_error() << " (" << #expr << ")" << endl;         \
-            if (g_background_writer && g_background_writer->joinable()) g_background_writer->join(); \
-            exit(1);                                                                      \
-        }                                                                                 \
+        if ((expr) != 0) main_thread_exit(std::string(mmg_last_error()) + " (" + #expr + ")"); \
     } while (0)
+// in a worker thread: record and leave the enclosing function / lambda
+#define MMG_TRY_WORKER(expr) do { if (worker_failed((expr), #expr)) return; } while (0)
 
 // gzip text sink: ONE standard gzip member whose deflate stream is produced chunk-wise in parallel.
 // Every chunk is compressed independently as raw deflate and closed with a sync flush (byte-aligned,
@@ -239,7 +260,7 @@ static void write_trace_rows(GzText &gz, int n_lines, size_t n_cols, const funct
     fetch(0, (int)min<size_t>(lines_per_round, (size_t)n_lines), buf[0].data());
     thread writer;
     vector<string> comp_prev; // owned by the writer thread while it runs
-    for (int l0 = 0, r = 0; l0 < n_lines; l0 += (int)lines_per_round, ++r) {
+    for (int l0 = 0, r = 0; l0 < n_lines && !g_worker_failed.load(); l0 += (int)lines_per_round, ++r) {
         const int cnt = (int)min<size_t>(lines_per_round, (size_t)(n_lines - l0));
         const int next0 = l0 + cnt, next_cnt = (int)min<size_t>(lines_per_round, (size_t)max(0, n_lines - next0));
         thread fetcher;
@@ -1025,7 +1046,7 @@ int main(int argc, char **argv)
     std::mutex ready_mu;
     std::condition_variable ready_cv;
     int samples_ready = 0;                           // samples whose rows may be fetched (trace and derived traces)
-    auto wait_for = [&](int upto) { std::unique_lock<std::mutex> lk(ready_mu); ready_cv.wait(lk, [&] { return samples_ready >= upto; }); };
+    auto wait_for = [&](int upto) { std::unique_lock<std::mutex> lk(ready_mu); ready_cv.wait(lk, [&] { return samples_ready >= upto || g_worker_failed.load(); }); };
     const int writer_threads = max(1, omp_get_max_threads());
     const int t_big = max(1, (writer_threads - 1) * 9 / 20), t_gene = max(1, writer_threads / 10);
     std::thread w_trace, w_ident, w_gene, w_prop;
@@ -1034,15 +1055,16 @@ int main(int argc, char **argv)
             GzText gz(output_base + ".trace_gibbs.gz");
             for (uint32_t t = 0; t < n; t++) { gz.str(sid(t)); gz.str(" "); }
             gz.str("\n");
-            write_trace_rows(gz, trace_length, n, [&](int first, int count, double *out) { wait_for(first + count); MMG_TRY(mmg_sampler_get_trace_rows_done(smp, 0, first, count, out)); },
+            write_trace_rows(gz, trace_length, n, [&](int first, int count, double *out) { wait_for(first + count); if (g_worker_failed.load()) return; MMG_TRY_WORKER(mmg_sampler_get_trace_rows_done(smp, 0, first, count, out)); },
                              [](size_t) { return true; }, t_big);
             gz.close();
         });
         w_ident = std::thread([&]() {
             // a set whose first summed sample has no finite logarithm is left out of its trace file (:1040)
             wait_for(1);
+            if (g_worker_failed.load()) return;
             vector<double> firstI(max<size_t>(nI, 1));
-            MMG_TRY(mmg_summary_get_rows(summ, MMG_SERIES_IDENTICAL, 0, 1, firstI.data()));
+            MMG_TRY_WORKER(mmg_summary_get_rows(summ, MMG_SERIES_IDENTICAL, 0, 1, firstI.data()));
             vector<char> keepI(nI);
             for (size_t v = 0; v < nI; ++v) keepI[v] = isfinite(log(firstI[v])) != 0;
             GzText gi(output_base + ".identical.trace_gibbs.gz");
@@ -1055,20 +1077,21 @@ int main(int argc, char **argv)
                     gi.str(" ");
                 }
             gi.str("\n");
-            write_trace_rows(gi, trace_length, nI, [&](int first, int count, double *out) { wait_for(first + count); MMG_TRY(mmg_summary_get_rows(summ, MMG_SERIES_IDENTICAL, first, count, out)); },
+            write_trace_rows(gi, trace_length, nI, [&](int first, int count, double *out) { wait_for(first + count); if (g_worker_failed.load()) return; MMG_TRY_WORKER(mmg_summary_get_rows(summ, MMG_SERIES_IDENTICAL, first, count, out)); },
                              [&](size_t v) { return keepI[v] != 0; }, 1);
             gi.close();
         });
         w_gene = std::thread([&]() {
             wait_for(1);                             // (:1068: the same rule for genes)
+            if (g_worker_failed.load()) return;
             vector<double> firstG(max<size_t>(nG, 1));
-            MMG_TRY(mmg_summary_get_rows(summ, MMG_SERIES_GENE, 0, 1, firstG.data()));
+            MMG_TRY_WORKER(mmg_summary_get_rows(summ, MMG_SERIES_GENE, 0, 1, firstG.data()));
             vector<char> keepG(nG);
             for (size_t g = 0; g < nG; ++g) keepG[g] = isfinite(log(firstG[g])) != 0;
             GzText gg(output_base + ".gene.trace_gibbs.gz");
             { size_t g = 0; for (auto &gt : gene2transcripts) { if (keepG[g]) { gg.str(gt.first); gg.str(" "); } g++; } }
             gg.str("\n");
-            write_trace_rows(gg, trace_length, nG, [&](int first, int count, double *out) { wait_for(first + count); MMG_TRY(mmg_summary_get_rows(summ, MMG_SERIES_GENE, first, count, out)); },
+            write_trace_rows(gg, trace_length, nG, [&](int first, int count, double *out) { wait_for(first + count); if (g_worker_failed.load()) return; MMG_TRY_WORKER(mmg_summary_get_rows(summ, MMG_SERIES_GENE, first, count, out)); },
                              [&](size_t g) { return keepG[g] != 0; }, t_gene);
             gg.close();
         });
@@ -1076,10 +1099,22 @@ int main(int argc, char **argv)
             GzText gp(output_base + ".prop.trace_gibbs.gz");
             for (uint32_t t = 0; t < n; t++) { gp.str(sid(t)); gp.str(" "); }
             gp.str("\n");
-            write_trace_rows(gp, trace_length, n, [&](int first, int count, double *out) { wait_for(first + count); MMG_TRY(mmg_summary_get_rows(summ, MMG_SERIES_TRANSCRIPT, first, count, out)); },
+            write_trace_rows(gp, trace_length, n, [&](int first, int count, double *out) { wait_for(first + count); if (g_worker_failed.load()) return; MMG_TRY_WORKER(mmg_summary_get_rows(summ, MMG_SERIES_TRANSCRIPT, first, count, out)); },
                              [](size_t) { return true; }, t_big);
             gp.close();
         });
+        // how the main thread stops the four writers when it (or one of them) fails: flag, wake, join
+        g_stop_workers = [&]() {
+            { std::lock_guard<std::mutex> lk(ready_mu); g_worker_failed.store(true); }
+            ready_cv.notify_all();
+            for (std::thread *w : {&w_trace, &w_ident, &w_gene, &w_prop}) if (w->joinable()) w->join();
+        };
+        auto check_workers = [&]() {
+            if (!g_worker_failed.load()) return;
+            std::string msg;
+            { std::lock_guard<std::mutex> lk(g_worker_mu); msg = g_worker_msg; }
+            main_thread_exit(msg);
+        };
         // chunks of 1/64 of the run: the writers start on a chunk's samples when it ends, so what is left of their work after the last
         // iteration is 1/64 of the files
         const int chunk = max(1, gibbs_iter / 64);
@@ -1096,6 +1131,7 @@ int main(int argc, char **argv)
         enqueue(min(chunk, gibbs_iter));
         for (int done = 0; done < gibbs_iter; done += chunk) {
             cout << "Gibbs iteration " << done << "       \r" << flush;
+            check_workers();
             const int it = min(chunk, gibbs_iter - done);
             if (done + it < gibbs_iter) enqueue(min(chunk, gibbs_iter - done - it));
             // sample s is kept by iteration s * gibbs_ss (:911): the samples of the iterations up to done + it are final once the

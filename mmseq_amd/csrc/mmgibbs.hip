@@ -544,9 +544,19 @@ extern "C" int mmg_problem_create(const mmg_problem_desc *d, int device, mmg_pro
     if (!d->tx_order && d->layout == MMG_LAYOUT_CANONICAL && p->m > 0 && d->n > 1 && opt(MMG_OPT_DERIVE_ORDER) != 0) {
         const uint64_t floor_cost = SELL_FAST_TILE_COST * (p->use_sell ? p->n_sell_tiles : (p->m + 63) / 64);
         if (modelled_sweep_cost(p) > floor_cost + floor_cost / 4 || opt(MMG_OPT_DERIVE_ORDER) == 1) {
+            // The attempt must never cost the caller the problem it already has: p is valid.  The second build needs p's device memory
+            // and its build's temporaries once more, plus the edge keys and their sort (16 bytes per sampled hit twice over, at most
+            // 4 GB); without that much free, and on any failure below, p stays.
+            size_t free_b = 0, total_b = 0;
+            const size_t need = 3 * (size_t)p->device_bytes + std::min<size_t>((size_t)4 << 30, 32 * (size_t)p->nnz + ((size_t)64 << 20));
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need) {
+                (void)hipGetLastError();
+                *out = p;
+                return MMG_OK;
+            }
             std::vector<uint64_t> edges;
             hipError_t e = order_cooccurrence_edges(p->idx64, p->m, p->nnz, p->d_row_ptr, p->d_col, edges, 0); // (no tx_order: device ids are the caller's)
-            if (e != hipSuccess) { problem_free(p); return fail(MMG_ERR_HIP, std::string("transcript order from the hit graph: ") + hipGetErrorString(e)); }
+            if (e != hipSuccess) { (void)hipGetLastError(); edges.clear(); }
             // (a graph in which the average transcript shares rows with more than 1024 others has no band to find: hits drawn all over
             // the transcriptome -- the level structures of 10^8 edges would only cost host time before the result is discarded)
             if (!edges.empty() && edges.size() <= (uint64_t)d->n * 1024) {
@@ -556,9 +566,9 @@ extern "C" int mmg_problem_create(const mmg_problem_desc *d, int device, mmg_pro
                 std::vector<uint64_t> keys(pos.begin(), pos.end());
                 mmg_problem *q = nullptr;
                 rc = problem_create_checked(d, device, keys.data(), &q);
-                if (rc) { problem_free(p); return rc; }
-                if (modelled_sweep_cost(q) < modelled_sweep_cost(p) - modelled_sweep_cost(p) / 5) { problem_free(p); p = q; p->order_derived = true; }
-                else problem_free(q);
+                if (rc) { (void)hipGetLastError(); q = nullptr; rc = MMG_OK; } // (problem_create_checked frees what it built)
+                if (q && modelled_sweep_cost(q) < modelled_sweep_cost(p) - modelled_sweep_cost(p) / 5) { problem_free(p); p = q; p->order_derived = true; }
+                else if (q) problem_free(q);
             }
         }
     }

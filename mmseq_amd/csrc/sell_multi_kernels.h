@@ -12,7 +12,7 @@
 namespace mmg {
 
 template <typename IdxT, int NCH>
-__global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 2 ? 4 : 2, NCH == 2 ? 4 : 2))) void k_sample_sell_multi(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
                                                           const SellTile *__restrict__ tiles, const uint64_t *__restrict__ chunk_tile,
                                                           const double *__restrict__ gmu /* [NCH][n] */, const uint8_t *__restrict__ stream,
                                                           int32_t *gcnt /* [NCH][n] */, SampleArgs a)
@@ -145,26 +145,29 @@ __global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict
     // (two register sets), no boundary is copied, the sweep of the pick has no entry branches, and the two chains' picks are
     // interleaved -- chain 1's sweep runs while chain 0's in-group gathers travel.  Same additions, comparisons and draws in the same
     // order per chain: bit-identical to the generic walk (tests/test_gpu_parity.py, test_gpu_fullsize.py).
-    auto walk_fixed = [&](const SellTile &d, const Buf &bf, uint32_t which, auto ng_tag) {
+    // the weights of a group's four hits for the two chains: 4 unpacks, 8 gathers
+    struct G4 { double w[4][2]; };
+    auto gather = [&](uint32_t v) {
+        G4 r;
+        const uint32_t o0 = SM_OFF0(v), o1 = SM_OFF1(v), o2 = SM_OFF2(v), o3 = SM_OFF3(v);
+        const uint32_t o[4] = {o0, o1, o2, o3};
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const double *p = (const double *)((const char *)s_mu + o[h]);
+            r.w[h][0] = p[0];
+            r.w[h][1] = p[CS];
+        }
+        return r;
+    };
+    // head: the weights of the tile's FIRST group, requested by the caller as early as the window allows (behind the Philox rounds of the
+    // pair for tile A, before the picks of tile A for tile B); between(): called between the sums and the picks
+    auto walk_fixed = [&](const SellTile &d, const Buf &bf, uint32_t which, auto ng_tag, const G4 &head, auto &&between) {
         constexpr int NG = decltype(ng_tag)::value;
         static_assert(NCH == 2 && NG >= 1 && NG <= 8, "chain pairs, cached groups only");
         const uint32_t gw[8] = {bf.g0, bf.g1, bf.g2, bf.g3, bf.g4, bf.g5, bf.g6, bf.g7};
-        struct G4 { double w[4][2]; };
-        auto gather = [&](uint32_t v) {
-            G4 r;
-            const uint32_t o0 = SM_OFF0(v), o1 = SM_OFF1(v), o2 = SM_OFF2(v), o3 = SM_OFF3(v);
-            const uint32_t o[4] = {o0, o1, o2, o3};
-#pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                const double *p = (const double *)((const char *)s_mu + o[h]);
-                r.w[h][0] = p[0];
-                r.w[h][1] = p[CS];
-            }
-            return r;
-        };
         double P[NG][2];
         {
-            G4 cur = gather(gw[0]), nxt = cur;
+            G4 cur = head, nxt = cur;
             if (NG > 1) nxt = gather(gw[1]);
 #pragma unroll
             for (int i = 0; i < NG; ++i) {
@@ -180,6 +183,8 @@ __global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict
                 if (i + 2 < NG) nxt = gather(gw[i + 2]);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        between();
         __builtin_amdgcn_sched_barrier(0);
         uint32_t x[2], v[2], sel[2], oo[2][4];
         double target[2], acc[2], wi[2][3];
@@ -485,21 +490,8 @@ __global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict
             cur_base = d.wbase;
             __syncthreads();
         }
-        if (d.flags() & SELL_FAST) {
-            if constexpr (NCH == 2) {
-                switch (d.ng()) { // uniform
-                case 1: walk_fixed(d, bf, which, IntTag<1>()); break;
-                case 2: walk_fixed(d, bf, which, IntTag<2>()); break;
-                case 3: walk_fixed(d, bf, which, IntTag<3>()); break;
-                case 4: walk_fixed(d, bf, which, IntTag<4>()); break;
-                case 5: walk_fixed(d, bf, which, IntTag<5>()); break;
-                case 6: walk_fixed(d, bf, which, IntTag<6>()); break;
-                case 7: walk_fixed(d, bf, which, IntTag<7>()); break;
-                case 8: walk_fixed(d, bf, which, IntTag<8>()); break;
-                default: walk(d, bf, which); break; // rows of more than 32 hits (ng = 0 does not occur on a register-path tile)
-                }
-            } else walk(d, bf, which);
-        } else slow_tile(d);
+        if (d.flags() & SELL_FAST) walk(d, bf, which);
+        else slow_tile(d);
         issue(refill, bf);
     };
 
@@ -523,15 +515,75 @@ __global__ __launch_bounds__(64) void k_sample_sell_multi(const IdxT *__restrict
     issue(dB, bufB);
     for (uint32_t i = 0; i < nt; i += 2) {
         const SellTile nA = tile_at(i + 2), nB = tile_at(i + 3);
-        pair_rng(dA, dB);
         if constexpr (NCH == 2) {
+            // ONE path for every pair of tiles (and one place per buffer where the next block is requested: the registers of a buffer
+            // then stay where they are from iteration to iteration).  A tile's kind: 0 = none (past the end of the range), 1..8 = a
+            // register-path tile of that many groups (straight-line walk), 9 = anything else (generic walk: same bits).
+            auto kind = [&](const SellTile &d) -> uint32_t { // uniform
+                if (d.flags() & SELL_EMPTY) return 0u;
+                return ((d.flags() & SELL_FAST) && d.ng() - 1u < 8u) ? d.ng() : 9u;
+            };
+            auto window_for = [&](const SellTile &d) -> bool {
+                if (d.wbase == cur_base) return false;
+                __syncthreads();
+                flush_window(cur_base);
+                load_window(d.wbase);
+                cur_base = d.wbase;
+                __syncthreads();
+                return true;
+            };
+            const uint32_t kA = kind(dA), kB = kind(dB);
+            if (kA) window_for(dA);
+            const G4 hA = gather(bufA.g0); // tile A's first gathers travel while the pair's Philox blocks are computed
+            pair_rng(dA, dB);
             // the descriptors' scalar loads are waited for HERE, behind the Philox rounds: scalar loads return out of order, so with
             // one of them outstanding the walk's first wait for its gathers would be a wait for everything (lgkmcnt(0)) -- including
             // the gathers of the group it has just requested ahead
             asm volatile("" ::"s"(nA.off16), "s"(nA.r0), "s"(nA.wbase), "s"(nA.meta), "s"(nB.off16), "s"(nB.r0), "s"(nB.wbase), "s"(nB.meta));
+            // tile B's first gathers go out before tile A's picks -- except behind a tile of 7 or 8 groups (one in seven at 20 hits per
+            // read), whose 28 / 32 boundary registers leave no room for the 16 of the gathers at 4 waves per SIMD
+            G4 hB;
+            auto early = [&]() { hB = gather(bufB.g0); };
+            auto nothing = []() {};
+            switch (kA) {
+            case 0: early(); break;
+            case 1: walk_fixed(dA, bufA, 0, IntTag<1>(), hA, early); break;
+            case 2: walk_fixed(dA, bufA, 0, IntTag<2>(), hA, early); break;
+            case 3: walk_fixed(dA, bufA, 0, IntTag<3>(), hA, early); break;
+            case 4: walk_fixed(dA, bufA, 0, IntTag<4>(), hA, early); break;
+            case 5: walk_fixed(dA, bufA, 0, IntTag<5>(), hA, early); break;
+            case 6: walk_fixed(dA, bufA, 0, IntTag<6>(), hA, early); break;
+            case 7: walk_fixed(dA, bufA, 0, IntTag<7>(), hA, nothing); early(); break;
+            case 8: walk_fixed(dA, bufA, 0, IntTag<8>(), hA, nothing); early(); break;
+            default:
+                if (dA.flags() & SELL_FAST) walk(dA, bufA, 0);
+                else slow_tile(dA);
+                early();
+                break;
+            }
+            issue(nA, bufA);
+            if (kB && window_for(dB)) hB = gather(bufB.g0); // (the early gathers read the window before)
+            switch (kB) {
+            case 0: break;
+            case 1: walk_fixed(dB, bufB, 1, IntTag<1>(), hB, nothing); break;
+            case 2: walk_fixed(dB, bufB, 1, IntTag<2>(), hB, nothing); break;
+            case 3: walk_fixed(dB, bufB, 1, IntTag<3>(), hB, nothing); break;
+            case 4: walk_fixed(dB, bufB, 1, IntTag<4>(), hB, nothing); break;
+            case 5: walk_fixed(dB, bufB, 1, IntTag<5>(), hB, nothing); break;
+            case 6: walk_fixed(dB, bufB, 1, IntTag<6>(), hB, nothing); break;
+            case 7: walk_fixed(dB, bufB, 1, IntTag<7>(), hB, nothing); break;
+            case 8: walk_fixed(dB, bufB, 1, IntTag<8>(), hB, nothing); break;
+            default:
+                if (dB.flags() & SELL_FAST) walk(dB, bufB, 1);
+                else slow_tile(dB);
+                break;
+            }
+            issue(nB, bufB);
+        } else {
+            pair_rng(dA, dB);
+            process(dA, cur_base, nA, bufA, 0);
+            process(dB, cur_base, nB, bufB, 1);
         }
-        process(dA, cur_base, nA, bufA, 0);
-        process(dB, cur_base, nB, bufB, 1);
         dA = nA;
         dB = nB;
     }
