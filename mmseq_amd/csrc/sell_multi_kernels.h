@@ -49,6 +49,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 2 ? 4
 
     for (int i = lane; i < 2 * CS * NCH; i += 64) s_cnt[i] = 0;
     if (lane < NCH) s_mu[lane * CS + WIN] = 0.0;
+    if (NCH == 2 && (uint32_t)(uintptr_t)s_mu != 0u) __builtin_trap(); // (the asm gathers of walk_fixed address the windows from LDS offset 0)
 
     auto flush_window = [&](uint32_t base) {
         for (int i = lane; i < WIN; i += 64) {
@@ -113,14 +114,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 2 ? 4
         const uint32_t pa = ((uint32_t)(a.row_id_base + A.r0) & 1u) + lane, pb = ((uint32_t)(a.row_id_base + B.r0) & 1u) + lane;
         const int sa = (int)((pa >> 1) << 2), sb = (int)((32u + (pb >> 1)) << 2);
         if (one_key && (((a.row_id_base + A.r0) | (a.row_id_base + B.r0)) & 1u) == 0) { // both tiles start on an even row id: hand-out by DPP (k_sample_sell)
+            // the chains' blocks round by round, side by side: a block is one dependent chain (multiply -> xor -> multiply ...), and a
+            // wave that issues it alone waits out every result (and a hazard slot behind every v_mad_u64_u32)
+            uint32_t x0[NCH], x1[NCH], key[NCH];
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                uint32_t x0 = ((lane & 1u) ? (uint32_t)qb : (uint32_t)qa) + (lane >> 1), x1 = a.iter;
-                philox2x32_10(x0, x1, stream2_key(a.seed, a.chain + (uint32_t)c, TAG_ROW, (uint32_t)(qa >> 32)));
-                const uint32_t n0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)x0, 0xB1, 0xF, 0xF, true);
-                const uint32_t n1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)x1, 0xB1, 0xF, 0xF, true);
-                xrowA[c] = (lane & 1u) ? n1 : x0;
-                xrowB[c] = (lane & 1u) ? x1 : n0;
+                x0[c] = ((lane & 1u) ? (uint32_t)qb : (uint32_t)qa) + (lane >> 1);
+                x1[c] = a.iter;
+                key[c] = stream2_key(a.seed, a.chain + (uint32_t)c, TAG_ROW, (uint32_t)(qa >> 32));
+            }
+#pragma unroll
+            for (int r = 0; r < 10; ++r) {
+                uint64_t pr[NCH];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(pr[c]) : "v"(x0[c]), "s"(0xD256D193u) : "vcc");
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    x0[c] = __builtin_amdgcn_bitop3_b32((uint32_t)(pr[c] >> 32), x1[c], key[c], 0x96);
+                    x1[c] = (uint32_t)pr[c];
+                    key[c] += 0x9E3779B9u;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const uint32_t n0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)x0[c], 0xB1, 0xF, 0xF, true);
+                const uint32_t n1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)x1[c], 0xB1, 0xF, 0xF, true);
+                xrowA[c] = (lane & 1u) ? n1 : x0[c];
+                xrowB[c] = (lane & 1u) ? x1[c] : n0;
             }
             return;
         }
@@ -146,16 +167,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 2 ? 4
     // interleaved -- chain 1's sweep runs while chain 0's in-group gathers travel.  Same additions, comparisons and draws in the same
     // order per chain: bit-identical to the generic walk (tests/test_gpu_parity.py, test_gpu_fullsize.py).
     // the weights of a group's four hits for the two chains: 4 unpacks, 8 gathers
+    // The gathers of the straight-line walk are issued by inline asm and waited for by HAND (lds_wait: one s_waitcnt per group of
+    // additions).  Left to the compiler every addition gets its own s_waitcnt in front -- it counts the gathers back in one by one --
+    // and a wave issues one instruction per slot: 38 of a tile's ~350.  The rules that make the hand count valid: LDS operations
+    // complete in order, so "at most N outstanding" means everything but the N youngest is there; between a gather and its wait this
+    // code issues nothing but gathers; whatever else is outstanding (count atomics, descriptor loads) only makes a wait longer.
+    // s_mu sits at LDS address 0 (checked at the kernel's head): the immediate offset is the chain's window.
     struct G4 { double w[4][2]; };
+    auto lds_mu = [&](uint32_t off, auto chain_tag) -> double {
+        constexpr int c = decltype(chain_tag)::value;
+        double w;
+        if constexpr (c == 0) asm volatile("ds_read_b64 %0, %1" : "=v"(w) : "v"(off));
+        else asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(w) : "v"(off), "n"(CS * 8));
+        return w;
+    };
+#define SM_LDS_WAIT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
     auto gather = [&](uint32_t v) {
         G4 r;
         const uint32_t o0 = SM_OFF0(v), o1 = SM_OFF1(v), o2 = SM_OFF2(v), o3 = SM_OFF3(v);
         const uint32_t o[4] = {o0, o1, o2, o3};
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-            const double *p = (const double *)((const char *)s_mu + o[h]);
-            r.w[h][0] = p[0];
-            r.w[h][1] = p[CS];
+            r.w[h][0] = lds_mu(o[h], IntTag<0>());
+            r.w[h][1] = lds_mu(o[h], IntTag<1>());
         }
         return r;
     };
@@ -172,11 +206,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 2 ? 4
 #pragma unroll
             for (int i = 0; i < NG; ++i) {
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    double t = i == 0 ? cur.w[0][c] : P[i - 1][c] + cur.w[0][c]; // 0.0 + w == w exactly
-                    t += cur.w[1][c]; t += cur.w[2][c]; t += cur.w[3][c];
-                    P[i][c] = t;
+                // ONE wait for the group's eight gathers (the eight of the next group may still travel) instead of one in front of
+                // every addition: a wave issues one instruction per slot, s_waitcnt included, and they were a fifth of a tile's
+                if (i + 1 < NG) SM_LDS_WAIT(8);
+                else SM_LDS_WAIT(0);
+                __builtin_amdgcn_sched_barrier(0);
+                {   // the two chains' sums side by side: each is a dependent chain of additions
+                    double t0 = i == 0 ? cur.w[0][0] : P[i - 1][0] + cur.w[0][0]; // 0.0 + w == w exactly
+                    double t1 = i == 0 ? cur.w[0][1] : P[i - 1][1] + cur.w[0][1];
+                    t0 += cur.w[1][0]; t1 += cur.w[1][1];
+                    t0 += cur.w[2][0]; t1 += cur.w[2][1];
+                    t0 += cur.w[3][0]; t1 += cur.w[3][1];
+                    P[i][0] = t0; P[i][1] = t1;
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 cur = nxt;
@@ -223,9 +264,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 2 ? 4
             else asm volatile(SMF_HEAD SMF_S7 SMF_TAIL : SMF_OUT(c) : SMF_IN(c, 8));
             // inside the group: the three gathers go out now and are waited for in resolve()
             oo[c][0] = SM_OFF0(v[c]); oo[c][1] = SM_OFF1(v[c]); oo[c][2] = SM_OFF2(v[c]); oo[c][3] = SM_OFF3(v[c]);
-            const char *m = (const char *)(s_mu + c * CS);
 #pragma unroll
-            for (int h = 0; h < 3; ++h) wi[c][h] = *(const double *)(m + oo[c][h]);
+            for (int h = 0; h < 3; ++h) wi[c][h] = lds_mu(oo[c][h], IntTag<c>());
         };
 #undef SMF_S0
 #undef SMF_S1
@@ -241,6 +281,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 2 ? 4
 #undef SMF_HEAD
 #undef SMF_STEP
         auto resolve = [&](int c) {
+            if (c == 0) SM_LDS_WAIT(3); // chain 1's three gathers may still travel
+            else SM_LDS_WAIT(0);
+            __builtin_amdgcn_sched_barrier(0);
             const double p0 = acc[c] + wi[c][0], p1 = p0 + wi[c][1], p2 = p1 + wi[c][2];
             uint32_t s = oo[c][3];
             uint64_t sv, tm;
@@ -589,6 +632,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 2 ? 4
     }
     __syncthreads();
     flush_window(cur_base);
+#undef SM_LDS_WAIT
 #undef SM_OFF0
 #undef SM_OFF1
 #undef SM_OFF2
