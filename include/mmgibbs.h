@@ -367,7 +367,8 @@ enum {
     MMG_OPT_CNT_REPLICAS = 6,      /* 1: one global count vector per chain, 8: replicated (default: by ranges per band) */
     MMG_OPT_GROUP_FAIL = 7,        /* v >= 0: member v % size of a group fails in its second iteration of the next run call (error path) */
     MMG_OPT_DERIVE_ORDER = 8,      /* 0: never derive a transcript order from the hit graph, 1: try it on every canonical problem without tx_order */
-    MMG_OPT_COUNT_ = 9
+    MMG_OPT_WIRE_CHECK = 9,        /* 0: no verification of a group's first exchanges, 1: verify in groups of one device too, 2: 1 + damage a word behind the exchange (the failure path) */
+    MMG_OPT_COUNT_ = 10
 };
 int mmg_selftest_option(int option, int value);
 /* The sharded EM of mmg_group_em_create with every shard on ONE device and the exchange done by plain kernels: `sweeps` sweeps from

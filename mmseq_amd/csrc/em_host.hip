@@ -206,7 +206,7 @@ int mmg::em_create_sharded(const mmg_problem *const *shards, int n_shards, const
         if (rc) return bail(rc);
     }
     mmg_em *lead = es[0];
-    if (n_shards > 1) {
+    if (n_shards > 1 || opt(MMG_OPT_WIRE_CHECK) >= 1) { // (the wire check of a group of one device takes the exchange path too: tests)
         // the scale words need the hits per transcript of the WHOLE problem: a sum of the shards' counts, held per member
         for (mmg_em *e : es) {
             if (hipSetDevice(e->device) != hipSuccess || hipMalloc((void **)&e->d_colcnt, e->p->n * sizeof(uint64_t)) != hipSuccess) { e->d_colcnt = nullptr; return bail(fail(MMG_ERR_HIP, "hipMalloc (column counts)")); }

@@ -70,6 +70,14 @@ struct mmg_group {
     std::vector<ncclComm_t> comms;
     double last_enqueue_us = 0.0; // host time per device-iteration of the last run_* call (slowest driver thread)
     bool aborted = false;         // a member failed inside a run call: the communicators were aborted, the group only remains to be destroyed
+    // The wire is verified ONCE per kind of exchange, the first time it carries data (verify_*): what every device holds after the
+    // all-reduce must be the sum (maximum) of what the devices held before it, computed on the host from downloads.  No N > 1 run
+    // of this code existed when it was written (one-GPU boxes only): the first node that has peers must not produce a wrong table
+    // silently if its transport -- xGMI peer access, the RCCL build -- misbehaves.  Cost: two downloads of the exchanged vector per
+    // device, once.  MMG_OPT_WIRE_CHECK = 1 runs the check in groups of one device too (tests), 2 corrupts a word behind the exchange
+    // (the failure path), 0 switches it off.
+    bool counts_verified = false;
+    bool em_verified[3] = {false, false, false};
 };
 
 // After a failure on one device its peers may already have enqueued the collective of that iteration: their streams would wait on the
@@ -194,6 +202,53 @@ static int all_reduce(const mmg_group *g, const std::vector<SamplerView> &v, voi
     return rc;
 }
 
+// The first iteration of a sharded chain with its count exchange verified: K1 on every device, the devices' own column sums
+// downloaded and added up on the host, the all-reduce, every device's result compared with that sum (and the sum's total with the
+// reads of all shards: src/mmseq.cpp:896-899 -- every read is counted once), then K2.  Any difference fails loudly and aborts the
+// group; nothing of the iteration has reached a trace by then.
+static int verified_first_iteration(mmg_group *g, mmg_sampler *const *samplers, const std::vector<SamplerView> &v, const std::vector<void *> &cnt, size_t count)
+{
+    const size_t G = v.size();
+    auto bail = [&](int code, const std::string &why) { abort_group(g); return fail(code, why); };
+    std::vector<int64_t> want(count, 0);
+    std::vector<int32_t> buf(count);
+    for (size_t i = 0; i < G; ++i) {
+        int rc = mmg_sampler_sample(samplers[i]);
+        if (rc != MMG_OK) { const std::string why = mmg_last_error(); return bail(rc, why); }
+    }
+    for (size_t i = 0; i < G; ++i) {
+        hipError_t e = hipSetDevice(g->devices[i]);
+        if (e == hipSuccess) e = hipStreamSynchronize(v[i].stream);
+        if (e == hipSuccess) e = hipMemcpy(buf.data(), cnt[i], count * sizeof(int32_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return bail(MMG_ERR_HIP, std::string("wire check (counts before the exchange): ") + hipGetErrorString(e));
+        for (size_t j = 0; j < count; ++j) want[j] += buf[j];
+    }
+    int64_t total = 0, reads = 0;
+    for (size_t j = 0; j < count; ++j) total += want[j];
+    for (size_t i = 0; i < G; ++i) reads += (int64_t)v[i].p->total_k * v[i].cfg.n_chains;
+    if (total != reads)
+        return bail(MMG_ERR_STATE, "wire check: the shards' first sweep allocated " + std::to_string(total) + " reads, the shards hold " + std::to_string(reads));
+    int rc = all_reduce(g, v, cnt.data(), cnt.data(), count, ncclInt32);
+    if (rc != MMG_OK) { const std::string why = mmg_last_error(); return bail(rc, why); }
+    for (size_t i = 0; i < G; ++i) {
+        hipError_t e = hipSetDevice(g->devices[i]);
+        if (e == hipSuccess) e = hipStreamSynchronize(v[i].stream);
+        if (e == hipSuccess && opt(MMG_OPT_WIRE_CHECK) == 2 && i + 1 == G) { const int32_t bad = -1; e = hipMemcpy((int32_t *)cnt[i] + count / 2, &bad, 4, hipMemcpyHostToDevice); }
+        if (e == hipSuccess) e = hipMemcpy(buf.data(), cnt[i], count * sizeof(int32_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return bail(MMG_ERR_HIP, std::string("wire check (counts behind the exchange): ") + hipGetErrorString(e));
+        for (size_t j = 0; j < count; ++j)
+            if ((int64_t)buf[j] != want[j])
+                return bail(MMG_ERR_STATE, "wire check: after the count all-reduce device " + std::to_string(g->devices[i]) + " holds " + std::to_string(buf[j]) +
+                            " at element " + std::to_string(j) + " where the devices' own counts add up to " + std::to_string(want[j]) +
+                            ": the exchange between the devices (RCCL) does not deliver the sum; nothing was written");
+    }
+    for (size_t i = 0; i < G; ++i) {
+        rc = mmg_sampler_update(samplers[i]);
+        if (rc != MMG_OK) { const std::string why = mmg_last_error(); return bail(rc, why); }
+    }
+    return MMG_OK;
+}
+
 extern "C" int mmg_group_run_sharded(mmg_group *g, mmg_sampler *const *samplers, int n_iter)
 {
     std::vector<SamplerView> v;
@@ -207,6 +262,12 @@ extern "C" int mmg_group_run_sharded(mmg_group *g, mmg_sampler *const *samplers,
     std::vector<void *> cnt(G);
     uint64_t count = 0;
     for (size_t i = 0; i < G; ++i) if ((rc = mmg_sampler_counts_devptr(samplers[i], &cnt[i], &count)) != MMG_OK) return rc;
+    if (n_iter > 0 && !g->counts_verified && opt(MMG_OPT_WIRE_CHECK) != 0 && (G > 1 || opt(MMG_OPT_WIRE_CHECK) >= 1)) {
+        // the group's first sharded iteration, step by step on this thread, with the exchange checked against the host's own sum
+        if ((rc = verified_first_iteration(g, samplers, v, cnt, (size_t)count)) != MMG_OK) return rc;
+        g->counts_verified = true;
+        --n_iter;
+    }
     return drive_devices(g, G, n_iter, [&](size_t i) -> int {
         int r = mmg_sampler_sample(samplers[i]);                                                          // src/mmseq.cpp:857-891 on the device's rows
         if (r != MMG_OK) return r;
@@ -291,6 +352,32 @@ std::function<int(int)> make_rccl_reduce(const std::vector<mmg_em *> &es, void *
 {
     mmg_group *g = ((EmGroupCtx *)ctx)->g;
     return [es, g](int what) -> int {
+        // the first exchange of every kind is verified against the host's own reduction of the members' buffers (mmg_group: wire check)
+        const bool verify = what >= 0 && what < 3 && !g->em_verified[what] && opt(MMG_OPT_WIRE_CHECK) != 0 && (es.size() > 1 || opt(MMG_OPT_WIRE_CHECK) >= 1);
+        std::vector<uint64_t> want;
+        auto fetch = [&](size_t i, std::vector<uint64_t> &out) -> hipError_t { // member i's buffer as 64-bit words (int32 sign-extended)
+            void *p = nullptr;
+            size_t cnt = 0;
+            em_exchange_buffers(es[i], what, &p, &cnt);
+            hipError_t e = hipSetDevice(g->devices[i]);
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+            out.resize(cnt);
+            if (what == 0) {
+                std::vector<int32_t> t(cnt);
+                if (e == hipSuccess) e = hipMemcpy(t.data(), p, cnt * 4, hipMemcpyDeviceToHost);
+                for (size_t j = 0; j < cnt; ++j) out[j] = (uint64_t)(int64_t)t[j];
+            } else if (e == hipSuccess) e = hipMemcpy(out.data(), p, cnt * 8, hipMemcpyDeviceToHost);
+            return e;
+        };
+        if (verify) {
+            std::vector<uint64_t> b;
+            for (size_t i = 0; i < es.size(); ++i) {
+                const hipError_t e = fetch(i, b);
+                if (e != hipSuccess) { abort_group(g); return fail(MMG_ERR_HIP, std::string("wire check (EM buffers before the exchange): ") + hipGetErrorString(e)); }
+                if (i == 0) want = b;
+                else for (size_t j = 0; j < b.size(); ++j) want[j] = what == 0 ? (uint64_t)std::max((int64_t)want[j], (int64_t)b[j]) : want[j] + b[j];
+            }
+        }
         NCCL_TRY(g_rccl.GroupStart());
         int rc = MMG_OK;
         for (size_t i = 0; i < es.size() && rc == MMG_OK; ++i) {
@@ -304,6 +391,30 @@ std::function<int(int)> make_rccl_reduce(const std::vector<mmg_em *> &es, void *
         const ncclResult_t e = g_rccl.GroupEnd();
         if (rc == MMG_OK && e != ncclSuccess) rc = fail(MMG_ERR_HIP, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(e));
         if (rc != MMG_OK) { const std::string why = mmg_last_error(); abort_group(g); return fail(rc, why); } // members that did enqueue must not wait for ever
+        if (verify) {
+            std::vector<uint64_t> b;
+            for (size_t i = 0; i < es.size(); ++i) {
+                hipError_t e = hipSuccess;
+                if (opt(MMG_OPT_WIRE_CHECK) == 2 && what == 1 && i + 1 == es.size()) { // (failure path: a word of the accumulators is damaged behind the exchange)
+                    void *p = nullptr; size_t cnt = 0;
+                    em_exchange_buffers(es[i], what, &p, &cnt);
+                    const uint64_t bad = ~0ull;
+                    e = hipSetDevice(g->devices[i]);
+                    if (e == hipSuccess) e = hipDeviceSynchronize();
+                    if (e == hipSuccess) e = hipMemcpy((uint64_t *)p + cnt / 2, &bad, 8, hipMemcpyHostToDevice);
+                }
+                if (e == hipSuccess) e = fetch(i, b);
+                if (e != hipSuccess) { abort_group(g); return fail(MMG_ERR_HIP, std::string("wire check (EM buffers behind the exchange): ") + hipGetErrorString(e)); }
+                for (size_t j = 0; j < b.size(); ++j)
+                    if (b[j] != want[j]) {
+                        abort_group(g);
+                        return fail(MMG_ERR_STATE, std::string("wire check: after the EM exchange of ") + (what == 0 ? "exponents (max)" : what == 1 ? "accumulators (sum)" : "column counts (sum)") +
+                                    " device " + std::to_string(g->devices[i]) + " holds " + std::to_string(b[j]) + " at word " + std::to_string(j) + " where the members' own buffers give " +
+                                    std::to_string(want[j]) + ": the exchange between the devices (RCCL) does not deliver the reduction");
+                    }
+            }
+            g->em_verified[what] = true;
+        }
         return rc;
     };
 }

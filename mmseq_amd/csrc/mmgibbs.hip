@@ -28,7 +28,7 @@ extern "C" const char *mmg_last_error(void) { return g_err.c_str(); }
 extern "C" int mmg_abi_version(void) { return MMG_ABI_VERSION; }
 
 // self-test overrides (mmg_selftest_option): -1 = the library decides
-static std::atomic<int> g_opt[MMG_OPT_COUNT_] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
+static std::atomic<int> g_opt[MMG_OPT_COUNT_] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
 int mmg::opt(int o) { return g_opt[o].load(std::memory_order_relaxed); }
 extern "C" int mmg_selftest_option(int option, int value)
 {

@@ -49,7 +49,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 2 ? 4
 
     for (int i = lane; i < 2 * CS * NCH; i += 64) s_cnt[i] = 0;
     if (lane < NCH) s_mu[lane * CS + WIN] = 0.0;
-    if (NCH == 2 && (uint32_t)(uintptr_t)s_mu != 0u) __builtin_trap(); // (the asm gathers of walk_fixed address the windows from LDS offset 0)
 
     auto flush_window = [&](uint32_t base) {
         for (int i = lane; i < WIN; i += 64) {
@@ -167,21 +166,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 2 ? 4
     // interleaved -- chain 1's sweep runs while chain 0's in-group gathers travel.  Same additions, comparisons and draws in the same
     // order per chain: bit-identical to the generic walk (tests/test_gpu_parity.py, test_gpu_fullsize.py).
     // the weights of a group's four hits for the two chains: 4 unpacks, 8 gathers
-    // The gathers of the straight-line walk are issued by inline asm and waited for by HAND (lds_wait: one s_waitcnt per group of
-    // additions).  Left to the compiler every addition gets its own s_waitcnt in front -- it counts the gathers back in one by one --
-    // and a wave issues one instruction per slot: 38 of a tile's ~350.  The rules that make the hand count valid: LDS operations
-    // complete in order, so "at most N outstanding" means everything but the N youngest is there; between a gather and its wait this
-    // code issues nothing but gathers; whatever else is outstanding (count atomics, descriptor loads) only makes a wait longer.
-    // s_mu sits at LDS address 0 (checked at the kernel's head): the immediate offset is the chain's window.
+    // (The gathers are plain loads, waited for by the compiler's counts: one s_waitcnt in front of every addition.  Issuing them from
+    // inline asm with ONE hand-placed wait per group of additions saves 38 of a tile's ~350 instruction slots and measured +0.5 % --
+    // and is unsafe: the compiler believes an asm's result is there at once, so a register copy it places between the load and the
+    // wait (a phi at the end of a switch case, a live-range split at 127 VGPRs) reads the register before the data arrives.  Seen as
+    // a bit difference in one chain of the full-size parity test, one run in three.  Not kept.)
     struct G4 { double w[4][2]; };
     auto lds_mu = [&](uint32_t off, auto chain_tag) -> double {
         constexpr int c = decltype(chain_tag)::value;
-        double w;
-        if constexpr (c == 0) asm volatile("ds_read_b64 %0, %1" : "=v"(w) : "v"(off));
-        else asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(w) : "v"(off), "n"(CS * 8));
-        return w;
+        return *(const double *)((const char *)(s_mu + c * CS) + off);
     };
-#define SM_LDS_WAIT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
     auto gather = [&](uint32_t v) {
         G4 r;
         const uint32_t o0 = SM_OFF0(v), o1 = SM_OFF1(v), o2 = SM_OFF2(v), o3 = SM_OFF3(v);
@@ -205,11 +199,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 2 ? 4
             if (NG > 1) nxt = gather(gw[1]);
 #pragma unroll
             for (int i = 0; i < NG; ++i) {
-                __builtin_amdgcn_sched_barrier(0);
-                // ONE wait for the group's eight gathers (the eight of the next group may still travel) instead of one in front of
-                // every addition: a wave issues one instruction per slot, s_waitcnt included, and they were a fifth of a tile's
-                if (i + 1 < NG) SM_LDS_WAIT(8);
-                else SM_LDS_WAIT(0);
                 __builtin_amdgcn_sched_barrier(0);
                 {   // the two chains' sums side by side: each is a dependent chain of additions
                     double t0 = i == 0 ? cur.w[0][0] : P[i - 1][0] + cur.w[0][0]; // 0.0 + w == w exactly
@@ -281,9 +270,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 2 ? 4
 #undef SMF_HEAD
 #undef SMF_STEP
         auto resolve = [&](int c) {
-            if (c == 0) SM_LDS_WAIT(3); // chain 1's three gathers may still travel
-            else SM_LDS_WAIT(0);
-            __builtin_amdgcn_sched_barrier(0);
             const double p0 = acc[c] + wi[c][0], p1 = p0 + wi[c][1], p2 = p1 + wi[c][2];
             uint32_t s = oo[c][3];
             uint64_t sv, tm;
@@ -632,7 +618,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NCH == 2 ? 4
     }
     __syncthreads();
     flush_window(cur_base);
-#undef SM_LDS_WAIT
 #undef SM_OFF0
 #undef SM_OFF1
 #undef SM_OFF2

@@ -70,7 +70,7 @@ def test_two_ranks_drive_the_library_through_dist_py(orc):
     procs = [ctx.Process(target=_child, args=(r, 2, port, q)) for r in range(2)]
     for pr in procs:
         pr.start()
-    res = sorted(q.get(timeout=600) for _ in range(2))
+    res = sorted(q.get(timeout=240) for _ in range(2))
     for pr in procs:
         pr.join(120)
         assert pr.exitcode == 0

@@ -105,3 +105,72 @@ def test_group_failure_aborts_the_communicators_and_long_chains_recycle_their_ti
         grp.run_chains([s], 1)
     assert e2.value.code == 4 and "aborted" in str(e2.value)
     grp.close(); s.close(); prob.close()
+
+
+@pytest.mark.gpu
+def test_a_groups_first_exchanges_are_verified_against_the_hosts_own_reduction(gpu, orc):
+    """The wire check of mmg_group_* (group.hip): the first count all-reduce of a sharded chain and the first EM exchanges of every
+    kind are compared, on every device, with the reduction of the members' buffers computed on the host from downloads.  No N > 1
+    RCCL run of this code exists (one-GPU boxes): the check is what turns a misbehaving transport on the first multi-GPU node into an
+    error instead of a wrong table.  Here it is forced in a group of ONE device (MMG_OPT_WIRE_CHECK = 1): same results as without,
+    and with a word damaged behind the exchange (= 2) both paths fail loudly, abort the group and name the device."""
+    from mmseq_amd._lib import MMGError
+    p, _ = orc.synth_problem(R=30000, T=1200, avg_hits=6, seed=4)
+    mu0, _ = orc.start_values(p)
+    prob = gpu.Problem.from_csr(p.row_ptr, p.col_idx, p.l)
+    ref = orc.gibbs_keyed(p, mu0, seed=5, chain=0, n_iter=8, trace_len=8)
+    mu_o, _, ll_o = orc.em(p, mu0, max_iter=5, epsilon=-1e308)
+    with gpu.options(wire_check=1):
+        grp = gpu.Group([0])
+        s = gpu.Sampler(prob, mu0, seed=5, gibbs_iter=8, trace_len=8)
+        grp.run_sharded([s], 3)                                   # first iteration step by step with the check, two by the driver threads
+        grp.run_sharded([s], 5)
+        assert np.array_equal(s.trace(0), ref["trace"])
+        mu_g, ll_g = grp.em([prob], mu0, 5)                       # every exchange of the EM (column counts, exponents, accumulators) checked once
+        assert np.array_equal(mu_g, mu_o) and ll_g == ll_o
+        s.close(); grp.close()
+    with gpu.options(wire_check=2):
+        grp = gpu.Group([0])
+        s = gpu.Sampler(prob, mu0, seed=5, gibbs_iter=8, trace_len=8)
+        with pytest.raises(MMGError) as e:
+            grp.run_sharded([s], 3)
+        assert "wire check" in str(e.value) and "device 0" in str(e.value) and e.value.code == 4
+        with pytest.raises(MMGError) as e2:
+            grp.run_sharded([s], 1)
+        assert "aborted" in str(e2.value)
+        s.close(); grp.close()
+        grp = gpu.Group([0])
+        with pytest.raises(MMGError) as e3:
+            grp.em([prob], mu0, 2)
+        assert "wire check" in str(e3.value) and "accumulators" in str(e3.value)
+        grp.close()
+    prob.close()
+
+
+@pytest.mark.gpu
+def test_em_over_two_devices_equals_the_em_of_one(gpu, orc):
+    """The EM twin of tests/test_cli.py::test_two_devices_give_the_output_of_one: mmg_group_em_create over read shards on TWO devices
+    (peer copies of the shards, ncclMax / ncclSum(uint64) between the phases) against mmg_problem_em on one, bit for bit.  Skipped on
+    the one-GPU boxes of the pool; the first box with two devices turns it into evidence."""
+    if gpu.device_count() < 2:
+        pytest.skip("needs two HIP devices")
+    p, _ = orc.synth_problem(R=200_000, T=4000, avg_hits=6, seed=14, far_fraction=0.1)
+    mu0, _ = orc.start_values(p)
+    prob = gpu.Problem.from_csr(p.row_ptr, p.col_idx, p.l)
+    mu_1, it_1, ll_1 = prob.em(mu0, max_iter=40, epsilon=-1e308)
+    b = prob.shard_bounds_timed(mu0, 2)
+    parts = [prob.shard(int(b[i]), int(b[i + 1]), device=i) for i in range(2)]
+    grp = gpu.Group([0, 1])
+    mu_g, ll_g = grp.em(parts, mu0, 40)
+    assert np.array_equal(mu_g, mu_1) and ll_g == ll_1
+    s = [gpu.Sampler(parts[i], mu_1, seed=3, gibbs_iter=32, trace_len=32) for i in range(2)]
+    one = gpu.Sampler(prob, mu_1, seed=3, gibbs_iter=32, trace_len=32)
+    grp.run_sharded(s, 32)
+    one.run(32)
+    assert np.array_equal(s[0].trace(0), one.trace(0)) and np.array_equal(s[1].trace(0), one.trace(0))
+    for x in s + [one]:
+        x.close()
+    grp.close()
+    for q in parts:
+        q.close()
+    prob.close()
