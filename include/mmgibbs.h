@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MMG_ABI_VERSION 6
+#define MMG_ABI_VERSION 7
 /* Version history of the SPEC behind the entry points: under one version a chain is a pure function of (problem, tx_order, seed,
  * chain, iteration); a bump means the same inputs may yield different bits (golden fixtures and the oracle move with it).
  *   3  (round 2) rows with 2 <= k <= 64 draw k categoricals (before: k <= 8), sorted by k inside their class.  The constant moved
@@ -51,7 +51,19 @@ extern "C" {
  *      of the set of rows and the caller's numbering) when the model prices the result a fifth lower: stored order, and with it the
  *      chain, of exactly those problems differ from version 5 (they ran the CSR-tile kernel at 1/29 of the speed).  Problems with
  *      tx_order, kept rows, or locality in the caller's numbering are untouched.  New entry points: mmg_problem_shard_bounds_timed,
- *      mmg_selftest_gibbs_shards; mmg_problem_shard_bounds cuts by modelled cost instead of hits (any cut gives the same chain). */
+ *      mmg_selftest_gibbs_shards; mmg_problem_shard_bounds cuts by modelled cost instead of hits (any cut gives the same chain).
+ *      Also version 6 (recorded late): the canonical layout's step 0 (rows with 2 <= k <= MMG_K_SMALL stored k times) is skipped when it
+ *      would store more than 8 rows per uploaded row (LAYOUT_EXPAND_MAX_RATIO, layout.hip; oracle/binding.py mirrors it): such rows
+ *      keep their k and draw their categoricals in the multiplicity kernel -- stored rows and chain bits of heavily collapsed problems
+ *      differ from version 5.
+ *   7  (round 5) tx_order with GROUPS: the high 32 bits of a key name the transcript's group (the CLI passes the gene, src/mmseq.cpp:
+ *      337-357).  When a canonical problem built on the caller's keys does not fit LDS windows (modelled cost more than 1.25 x that of
+ *      register-path tiles alone: reads that also hit paralogues, whose genes the caller's gene order puts anywhere) the library
+ *      derives an order of the GROUPS from the group-level hit graph (order.hip, the machinery of version 6 on groups) and keeps the
+ *      problem built on it -- the transcripts of a group stay together, in the caller's order -- if the model prices it a fifth lower.
+ *      Stored order and chain of exactly those problems differ from version 6; keys whose high words are all equal (plain ranks) are
+ *      untouched.  mmg_synth_desc gained gene_size / far_family (the struct grew: ABI 7); MMG_OPT_WIRE_CHECK; the first exchanges of an
+ *      mmg_group are verified against the host's own reduction of the members' buffers. */
 /* Layout.  The model does not care about the order of rows or the numbering of transcripts (src/mmseq.cpp:399-418 uses
  * first-seen order for both); the kernels do: they keep a window of consecutive transcripts in LDS and want the 64 rows of a
  * wave to have equal lengths.  mmg_problem_create therefore stores the rows in a CANONICAL order of its own (sorted on the
@@ -97,7 +109,10 @@ typedef struct mmg_problem_desc {
     const uint64_t *tx_order;/* optional, n keys: transcripts are laid out on the device by ascending
                                 (key, index).  A caller that knows which transcripts share reads (the
                                 isoforms of a gene, src/mmseq.cpp:358) passes gene_ordinal << 32 | ordinal
-                                within the gene, so that a read's hits are neighbours.  NULL: the caller's
+                                within the gene, so that a read's hits are neighbours.  The high 32 bits of a key
+                                name the transcript's GROUP: the library may reorder the groups (never the transcripts
+                                inside one) when the rows do not fit LDS windows in the caller's group order -- reads
+                                that also hit paralogues, spec version 7.  NULL: the caller's
                                 numbering is the device numbering -- unless the rows do not fit LDS windows in it
                                 (first-seen numbering, src/mmseq.cpp:399-408) and the layout is canonical: the library
                                 then derives an order from the hit graph, a pure function of the set of rows
@@ -118,6 +133,12 @@ typedef struct mmg_synth_desc {
     uint64_t mapped_reads;/* N in l = efflen * N / 1e9; 0 => rows                         */
     double far_fraction;  /* fraction of the rows (>= 2 hits) whose last drawn hit is replaced by a
                              transcript anywhere in [0, n): reads that also hit a paralogue */
+    uint32_t gene_size;   /* 0: the band generator above.  G > 0 (ABI 7): GENE-BLOCK mode -- transcripts [gG, gG + G) are the isoforms of gene g
+                             and the hits of a read lie inside its gene (row length <= G): what an aligner's output looks like, where
+                             reads of different genes share nothing but paralogues (src/bam2hits.cpp:271-300)              */
+    uint32_t far_family;  /* gene-block mode: 0 = a far hit goes anywhere (as above); F >= 2 = to an isoform of another gene of the read's
+                             PARALOGUE FAMILY: the genes are grouped F at a time by a seeded bijection of the gene indices, so a family's
+                             members lie anywhere in the transcriptome but are the same for every read of a gene                */
 } mmg_synth_desc;
 
 typedef struct mmg_problem_info {
@@ -135,7 +156,8 @@ typedef struct mmg_problem_info {
                               (n_tiles - fast - far - empty) are walked from the CSR                         */
     uint64_t padded_slots; /* hit slots of the sliced-ELL stream incl. padding (>= nnz of the fast tiles) */
     int32_t layout;        /* MMG_LAYOUT_* in force                                       */
-    int32_t tx_renumbered; /* 1: tx_order was given; 2: the library derived an order from the hit graph */
+    int32_t tx_renumbered; /* 1: tx_order was given; 2: the library derived an order from the hit graph; 3: tx_order was given and the
+                              library reordered its groups (the genes) by the group-level hit graph */
     int32_t sample_grid;   /* workgroups of the sample kernel: the resident count (waves the runtime reports x CUs) times the
                               number of generations (1..16: tile ranges of about 24 tiles once the problem is large) */
     int32_t cu_count;
@@ -184,10 +206,13 @@ int mmg_problem_shard(const mmg_problem *full, uint64_t lo, uint64_t hi, int dev
  * expensive ones.  Boundaries are tile starts on even random-stream ids.  Problems on the CSR-tile kernel are cut by hits
  * (mmg_shard_bounds). */
 int mmg_problem_shard_bounds(const mmg_problem *p, int parts, uint64_t *bounds);
-/* The same cut by MEASURED cost: the library runs a few one-chain sample sweeps over p with the weights mu (n doubles, the caller's
- * numbering: the start values or the EM optimum) in which every workgroup times itself, and cuts the stored rows into ranges of equal
- * measured time.  What a model cannot know -- what a far entry costs on this part, hit sets that give most of their reads to one
- * transcript -- is in the measurement.  The chain does not depend on where the rows are cut. */
+/* The same cut by MEASURED cost: every candidate shard is run as what it will be -- the one-chain sample kernels over its interval of
+ * p's tile lists, in ranges cut the way a problem of that size is cut, with replicated count vectors and the weights mu (n doubles, the
+ * caller's numbering: the start values or the EM optimum) -- on p's device, timed with HIP events on the null stream; tiles of a shard
+ * that ran long get dearer in proportion and the rows are cut again, until the slowest shard is within 2 % of the mean: at most 6
+ * rounds of parts x 7 launches behind a 50 ms warm-up (0.09 s at 50 M reads, 0.2-0.3 s at 400 M).  What a model cannot know -- what a
+ * far entry costs on this part, hit sets that give most of their reads to one transcript -- is in the measurement.  The chain does
+ * not depend on where the rows are cut. */
 int mmg_problem_shard_bounds_timed(const mmg_problem *p, const double *mu, int parts, uint64_t *bounds);
 int mmg_problem_get_l(const mmg_problem *p, double *l);
 /* Start values and the unique-hit column, src/mmseq.cpp:617-638: mu0[t] = sum_{i: t in row i}

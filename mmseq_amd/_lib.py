@@ -51,7 +51,7 @@ class ProblemDesc(C.Structure):
 class SynthDesc(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("rows", C.c_uint64), ("row0", C.c_uint64), ("n", C.c_uint32),
                 ("avg_hits", C.c_double), ("uniform", C.c_int32), ("sorted", C.c_int32),
-                ("mapped_reads", C.c_uint64), ("far_fraction", C.c_double)]
+                ("mapped_reads", C.c_uint64), ("far_fraction", C.c_double), ("gene_size", C.c_uint32), ("far_family", C.c_uint32)]
 
 
 class ProblemInfo(C.Structure):

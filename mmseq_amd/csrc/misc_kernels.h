@@ -146,6 +146,10 @@ __global__ __launch_bounds__(256) void k_synth_len(SynthArgs a, uint32_t *lens)
     s.pair(ua, ub);
     uint32_t L = synth_len_from_u(a.len_cdf, ua);
     if (L > a.n) L = a.n;
+    if (a.gene_size) { // gene-block mode: a read's hits are isoforms of its gene
+        const uint32_t g0 = synth_first(a, ub) / a.gene_size, W = min(a.gene_size, a.n - g0 * a.gene_size);
+        if (L > W) L = W;
+    }
     lens[r] = L;
 }
 
@@ -164,9 +168,14 @@ __global__ __launch_bounds__(256) void k_synth_fill(SynthArgs a, double far_frac
     const uint32_t t0 = synth_first(a, ub);
     cols[0] = t0;
     if (L <= 1) return;
-    const uint32_t W = a.uniform ? T : (T < 129u ? T : 129u);
+    uint32_t W = a.uniform ? T : (T < 129u ? T : 129u);
     uint32_t wb = 0;
-    if (!a.uniform) {
+    if (a.gene_size) {
+        wb = (t0 / a.gene_size) * a.gene_size;
+        W = min(a.gene_size, T - wb);
+        if (L > W) L = W;
+        if (L <= 1) return;
+    } else if (!a.uniform) {
         int64_t b = (int64_t)t0 - 64;
         if (b < 0) b = 0;
         if (b + (int64_t)W > (int64_t)T) b = (int64_t)T - (int64_t)W;
@@ -181,7 +190,28 @@ __global__ __launch_bounds__(256) void k_synth_fill(SynthArgs a, double far_frac
     const uint32_t stride = ((uint32_t)(ud * (double)(Wp / 2 ? Wp / 2 : 1)) << 1) | 1u;
     bool far = false;
     uint32_t tfar = 0;
-    if (far_fraction > 0.0 && !a.uniform && T > 2u * W) {
+    if (far_fraction > 0.0 && a.gene_size && a.far_family >= 2u && a.n_genes >= 2u * a.far_family) {
+        // paralogue families: the far hit is an isoform of ANOTHER gene of the read's family (the genes whose images under
+        // g -> fam_a * g mod n_genes share a block of far_family consecutive values: scattered over the transcriptome, fixed per gene)
+        double ue, uf;
+        s.pair(ue, uf);
+        const uint32_t F = a.far_family, g0 = t0 / a.gene_size;
+        const uint32_t pg = (uint32_t)(((uint64_t)a.fam_a * g0) % a.n_genes), fam = pg / F, idx = pg % F;
+        const uint32_t fsize = min(F, a.n_genes - fam * F);
+        if (fsize >= 2u) {
+            far = ue < far_fraction;
+            uint32_t j = 1u + (uint32_t)(uf * (double)(fsize - 1u));
+            if (j > fsize - 1u) j = fsize - 1u;
+            const uint32_t pm = fam * F + (idx + j) % fsize;
+            const uint32_t gm = (uint32_t)(((uint64_t)a.fam_ainv * pm) % a.n_genes);
+            double ug, uh;
+            s.pair(ug, uh);
+            const uint32_t Wm = min(a.gene_size, T - gm * a.gene_size);
+            uint32_t iso = (uint32_t)(ug * (double)Wm);
+            if (iso >= Wm) iso = Wm - 1u;
+            tfar = gm * a.gene_size + iso;            // another gene: outside the read's own, hence distinct from every other hit
+        }
+    } else if (far_fraction > 0.0 && !a.uniform && T > 2u * W) {
         double ue, uf;
         s.pair(ue, uf);
         far = ue < far_fraction;

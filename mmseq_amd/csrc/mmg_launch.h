@@ -65,7 +65,8 @@ double host_start_value(uint64_t a0, uint64_t a1, uint64_t a2, double l);
 
 // ---- order.hip: a transcript order from the hit graph when the caller passes none
 // sorted, duplicate-free directed edges u << 32 | v (both directions) of the co-occurrence graph of a content-hash sample of the rows
-hipError_t order_cooccurrence_edges(bool idx64, uint64_t m, uint64_t nnz, const void *d_rp, const uint32_t *d_col, std::vector<uint64_t> &edges, hipStream_t s);
+hipError_t order_cooccurrence_edges(bool idx64, uint64_t m, uint64_t nnz, const void *d_rp, const uint32_t *d_col, std::vector<uint64_t> &edges, hipStream_t s,
+                                    const uint32_t *d_label = nullptr);
 // pos[t] = position of transcript t in the derived order (level structures from pseudo-peripheral vertices; host code)
 void order_from_edges(uint32_t n, const std::vector<uint64_t> &edges, std::vector<uint32_t> &pos);
 

@@ -160,7 +160,29 @@ struct SynthArgs {
     int32_t uniform;
     const double *cdf;     // n   inclusive running sum of theta*efflen
     const double *len_cdf; // 99  Poisson(avg-1) inclusive cdf
+    // gene-block mode (mmg_synth_desc.gene_size > 0): the hits of a read lie inside its gene (gene_size consecutive transcripts); a far
+    // hit goes to a gene of the read's PARALOGUE FAMILY (far_family genes, scattered over the transcriptome by the bijection
+    // g -> fam_a * g mod n_genes) or, with far_family = 0, anywhere
+    uint32_t gene_size, far_family, n_genes, fam_a, fam_ainv;
 };
+
+// the family bijection of the gene-block generator: a multiplier coprime to n_genes derived from the seed, and its inverse
+MMG_TYPES_HD inline void synth_family_params(uint64_t seed, uint32_t n_genes, uint32_t *a, uint32_t *ainv)
+{
+    if (n_genes < 2) { *a = 1; *ainv = 1 % (n_genes ? n_genes : 1); return; }
+    uint64_t x = (seed + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 31;
+    uint64_t m = 2 + x % (n_genes - 1 ? n_genes - 1 : 1);
+    for (;; m = 2 + (m - 1) % (n_genes - 1 ? n_genes - 1 : 1)) { // smallest candidate from m on that is coprime to n_genes
+        uint64_t u = m, v = n_genes;
+        while (v) { const uint64_t t = u % v; u = v; v = t; }
+        if (u == 1) break;
+    }
+    int64_t t0 = 0, t1 = 1, r0 = n_genes, r1 = (int64_t)m; // extended Euclid: t1 * m == r1 (mod n_genes)
+    while (r1 != 1) { const int64_t q = r0 / r1, r2 = r0 - q * r1, t2 = t0 - q * t1; r0 = r1; r1 = r2; t0 = t1; t1 = t2; }
+    *a = (uint32_t)m;
+    *ainv = (uint32_t)(((t1 % (int64_t)n_genes) + (int64_t)n_genes) % (int64_t)n_genes);
+}
 
 // geometry of the CSR fallback kernel k_sample: tiles of <= K1C_ELEMS - 8 hits and <= K1C_ROWS rows
 constexpr int K1C_ELEMS = 2560, K1C_WIN = 256, K1C_UNR = 4, K1C_BS = 128, K1C_ROWS = 128;

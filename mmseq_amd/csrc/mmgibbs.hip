@@ -572,6 +572,47 @@ extern "C" int mmg_problem_create(const mmg_problem_desc *d, int device, mmg_pro
             }
         }
     }
+    // A transcript order from the caller whose keys name GROUPS (high 32 bits: the gene, src/mmseq.cpp:337-357), and rows that do not
+    // fit LDS windows in the caller's order of the groups -- reads that also hit a paralogue, whose gene a name-sorted gene table puts
+    // anywhere: derive an order of the groups from the group-level hit graph (spec version 7).  The transcripts of a group stay
+    // together in the caller's order; groups that share no row with another keep their relative order behind the linked ones.
+    if (d->tx_order && d->layout == MMG_LAYOUT_CANONICAL && p->m > 0 && d->n > 2 && opt(MMG_OPT_DERIVE_ORDER) != 0) {
+        const uint64_t floor_cost = SELL_FAST_TILE_COST * (p->use_sell ? p->n_sell_tiles : (p->m + 63) / 64);
+        if (modelled_sweep_cost(p) > floor_cost + floor_cost / 4 || opt(MMG_OPT_DERIVE_ORDER) == 1) {
+            std::vector<uint32_t> gkeys(d->n);
+            for (uint32_t t = 0; t < d->n; ++t) gkeys[t] = (uint32_t)(d->tx_order[t] >> 32);
+            std::vector<uint32_t> uniq(gkeys);
+            std::sort(uniq.begin(), uniq.end());
+            uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+            const uint32_t nG = (uint32_t)uniq.size();
+            size_t free_b = 0, total_b = 0;
+            const size_t need = 3 * (size_t)p->device_bytes + std::min<size_t>((size_t)4 << 30, 32 * (size_t)p->nnz + ((size_t)64 << 20));
+            if (nG > 1 && nG < d->n && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= need) {
+                std::vector<uint32_t> group_of_ext(d->n), label(d->n);
+                for (uint32_t t = 0; t < d->n; ++t) group_of_ext[t] = (uint32_t)(std::lower_bound(uniq.begin(), uniq.end(), gkeys[t]) - uniq.begin());
+                for (uint32_t i = 0; i < d->n; ++i) label[i] = group_of_ext[p->h_ext_of_int[i]];   // device column id -> group
+                uint32_t *d_label = nullptr;
+                std::vector<uint64_t> edges;
+                hipError_t e = hipMalloc((void **)&d_label, (size_t)d->n * 4);
+                if (e == hipSuccess) e = hipMemcpy(d_label, label.data(), (size_t)d->n * 4, hipMemcpyHostToDevice);
+                if (e == hipSuccess) e = order_cooccurrence_edges(p->idx64, p->m, p->nnz, p->d_row_ptr, p->d_col, edges, 0, d_label);
+                if (d_label) (void)hipFree(d_label);
+                if (e != hipSuccess) { (void)hipGetLastError(); edges.clear(); }
+                if (!edges.empty() && edges.size() <= (uint64_t)nG * 1024) {
+                    std::vector<uint32_t> posg;
+                    order_from_edges(nG, edges, posg);
+                    std::vector<uint64_t>().swap(edges);
+                    std::vector<uint64_t> keys(d->n);
+                    for (uint32_t t = 0; t < d->n; ++t) keys[t] = ((uint64_t)posg[group_of_ext[t]] << 32) | p->h_int_of_ext[t];
+                    mmg_problem *q = nullptr;
+                    rc = problem_create_checked(d, device, keys.data(), &q);
+                    if (rc) { (void)hipGetLastError(); q = nullptr; rc = MMG_OK; }
+                    if (q && modelled_sweep_cost(q) < modelled_sweep_cost(p) - modelled_sweep_cost(p) / 5) { problem_free(p); p = q; p->groups_reordered = true; }
+                    else if (q) problem_free(q);
+                }
+            } else (void)hipGetLastError();
+        }
+    }
     *out = p;
     return MMG_OK;
 }
@@ -923,6 +964,7 @@ extern "C" int mmg_problem_create_synthetic(const mmg_synth_desc *d, int device,
 {
     if (!d || !out) return fail(MMG_ERR_ARG, "NULL argument");
     if (d->n == 0 || d->rows == 0 || !(d->avg_hits >= 1.0) || !(d->far_fraction >= 0.0 && d->far_fraction <= 1.0)) return fail(MMG_ERR_ARG, "bad synthetic spec");
+    if ((d->gene_size && d->uniform) || (d->far_family && !d->gene_size) || d->far_family == 1) return fail(MMG_ERR_ARG, "bad synthetic spec: gene_size excludes uniform, far_family (0 or >= 2) needs gene_size");
     if (d->sorted && d->rows >= 0xffffffffull) return fail(MMG_ERR_ARG, "the canonical layout needs fewer than 2^32 rows per device");
     int rc = require_device(device);
     if (rc) return rc;
@@ -948,7 +990,12 @@ extern "C" int mmg_problem_create_synthetic(const mmg_synth_desc *d, int device,
     SYN_TRY(hipMalloc((void **)&d_rp64, (d->rows + 1) * sizeof(uint64_t)));
     SYN_TRY(hipMemcpy(d_cdf, cdf.data(), d->n * sizeof(double), hipMemcpyHostToDevice));
     SYN_TRY(hipMemcpy(d_len_cdf, len_cdf.data(), 99 * sizeof(double), hipMemcpyHostToDevice));
-    SynthArgs sa{d->seed, d->row0, d->rows, d->n, d->uniform ? 1 : 0, d_cdf, d_len_cdf};
+    SynthArgs sa{d->seed, d->row0, d->rows, d->n, d->uniform ? 1 : 0, d_cdf, d_len_cdf, 0, 0, 0, 1, 1};
+    if (d->gene_size) {
+        sa.gene_size = d->gene_size; sa.far_family = d->far_family;
+        sa.n_genes = (d->n + d->gene_size - 1) / d->gene_size;
+        synth_family_params(d->seed, sa.n_genes, &sa.fam_a, &sa.fam_ainv);
+    }
     launch_synth_len(sa, d->far_fraction, d_lens, 0);
     SYN_TRY(hipGetLastError());
     SYN_TRY(layout_scan_lens(d->rows, d_lens, d_rp64, 0));
@@ -987,7 +1034,7 @@ extern "C" int mmg_problem_info_get(const mmg_problem *p, mmg_problem_info *info
     info->far_tiles = p->n_far_tiles;
     info->padded_slots = p->padded_slots;
     info->layout = p->layout;
-    info->tx_renumbered = p->renumbered() ? (p->order_derived ? 2 : 1) : 0;
+    info->tx_renumbered = p->renumbered() ? (p->order_derived ? 2 : (p->groups_reordered ? 3 : 1)) : 0;
     info->sample_grid = p->use_sell ? p->grid_sell : p->grid_sample;
     info->cu_count = p->cu_count;
     return MMG_OK;

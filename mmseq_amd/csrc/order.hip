@@ -34,8 +34,11 @@ __device__ __forceinline__ uint64_t order_mix(uint32_t c)
 }
 
 // edges of row r: 2 x (hits other than its smallest transcript) if the row is in the sample, else 0.  EMIT: write them.
+// label: NULL = the vertices of the graph are the column ids; else label[c] = the vertex (group) of column c -- the graph of the GROUPS
+// that share rows (a row inside one group contributes nothing)
 template <typename IdxT, bool EMIT>
 __global__ __launch_bounds__(256) void k_order_edges(uint64_t m, const IdxT *__restrict__ rp, const uint32_t *__restrict__ col, uint64_t mask,
+                                                     const uint32_t *__restrict__ label,
                                                      uint32_t *__restrict__ cnt, const uint64_t *__restrict__ off, uint64_t *__restrict__ keys)
 {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -45,12 +48,12 @@ __global__ __launch_bounds__(256) void k_order_edges(uint64_t m, const IdxT *__r
     if (L >= 2 && L <= ORDER_MAX_ROW) {
         uint64_t h = 0;
         uint32_t lo = 0xffffffffu;
-        for (uint64_t j = b; j < e; ++j) { const uint32_t c = col[j]; h += order_mix(c); lo = min(lo, c); }   // commutative: a row is a set
+        for (uint64_t j = b; j < e; ++j) { const uint32_t c = col[j]; h += order_mix(c); lo = min(lo, label ? label[c] : c); }   // commutative: a row is a set
         h ^= h >> 32;
         if ((h & mask) == 0) {
             uint64_t o = EMIT ? off[r] : 0;
             for (uint64_t j = b; j < e; ++j) {
-                const uint32_t c = col[j];
+                const uint32_t c = label ? label[col[j]] : col[j];
                 if (c == lo) continue;
                 if (EMIT) { keys[o++] = ((uint64_t)lo << 32) | c; keys[o++] = ((uint64_t)c << 32) | lo; }
                 n += 2;
@@ -61,9 +64,10 @@ __global__ __launch_bounds__(256) void k_order_edges(uint64_t m, const IdxT *__r
 }
 
 // Sorted, duplicate-free directed edges (u << 32 | v, both directions of every undirected edge) of the co-occurrence graph of a device
-// CSR whose column ids are the CALLER's transcript ids.  edges: host vector.  Returns hipSuccess with an empty vector when there is
-// nothing to link.
-hipError_t order_cooccurrence_edges(bool idx64, uint64_t m, uint64_t nnz, const void *d_rp, const uint32_t *d_col, std::vector<uint64_t> &edges, hipStream_t s)
+// CSR whose column ids are the CALLER's transcript ids (d_label NULL), or of the groups d_label[column id] (device array).  edges: host
+// vector.  Returns hipSuccess with an empty vector when there is nothing to link.
+hipError_t order_cooccurrence_edges(bool idx64, uint64_t m, uint64_t nnz, const void *d_rp, const uint32_t *d_col, std::vector<uint64_t> &edges, hipStream_t s,
+                                    const uint32_t *d_label)
 {
     edges.clear();
     if (m == 0 || nnz == 0) return hipSuccess;
@@ -81,8 +85,8 @@ hipError_t order_cooccurrence_edges(bool idx64, uint64_t m, uint64_t nnz, const 
     O_TRY(hipMalloc((void **)&d_cnt, m * 4));
     O_TRY(hipMalloc((void **)&d_off, (m + 1) * 8));
     const unsigned g = (unsigned)((m + 255) / 256);
-    if (idx64) hipLaunchKernelGGL((k_order_edges<uint64_t, false>), dim3(g), dim3(256), 0, s, m, (const uint64_t *)d_rp, d_col, mask, d_cnt, (const uint64_t *)nullptr, (uint64_t *)nullptr);
-    else hipLaunchKernelGGL((k_order_edges<uint32_t, false>), dim3(g), dim3(256), 0, s, m, (const uint32_t *)d_rp, d_col, mask, d_cnt, (const uint64_t *)nullptr, (uint64_t *)nullptr);
+    if (idx64) hipLaunchKernelGGL((k_order_edges<uint64_t, false>), dim3(g), dim3(256), 0, s, m, (const uint64_t *)d_rp, d_col, mask, d_label, d_cnt, (const uint64_t *)nullptr, (uint64_t *)nullptr);
+    else hipLaunchKernelGGL((k_order_edges<uint32_t, false>), dim3(g), dim3(256), 0, s, m, (const uint32_t *)d_rp, d_col, mask, d_label, d_cnt, (const uint64_t *)nullptr, (uint64_t *)nullptr);
     O_TRY(hipGetLastError());
     O_TRY(layout_scan_lens(m, d_cnt, d_off, s));
     uint64_t E = 0;
@@ -90,8 +94,8 @@ hipError_t order_cooccurrence_edges(bool idx64, uint64_t m, uint64_t nnz, const 
     if (E == 0) return done(hipSuccess);
     O_TRY(hipMalloc((void **)&d_keys, E * 8));
     O_TRY(hipMalloc((void **)&d_sorted, E * 8));
-    if (idx64) hipLaunchKernelGGL((k_order_edges<uint64_t, true>), dim3(g), dim3(256), 0, s, m, (const uint64_t *)d_rp, d_col, mask, (uint32_t *)nullptr, (const uint64_t *)d_off, d_keys);
-    else hipLaunchKernelGGL((k_order_edges<uint32_t, true>), dim3(g), dim3(256), 0, s, m, (const uint32_t *)d_rp, d_col, mask, (uint32_t *)nullptr, (const uint64_t *)d_off, d_keys);
+    if (idx64) hipLaunchKernelGGL((k_order_edges<uint64_t, true>), dim3(g), dim3(256), 0, s, m, (const uint64_t *)d_rp, d_col, mask, d_label, (uint32_t *)nullptr, (const uint64_t *)d_off, d_keys);
+    else hipLaunchKernelGGL((k_order_edges<uint32_t, true>), dim3(g), dim3(256), 0, s, m, (const uint32_t *)d_rp, d_col, mask, d_label, (uint32_t *)nullptr, (const uint64_t *)d_off, d_keys);
     O_TRY(hipGetLastError());
     size_t tmp = 0;
     O_TRY(rocprim::radix_sort_keys(nullptr, tmp, d_keys, d_sorted, E, 0, 64, s));

@@ -53,9 +53,11 @@ class Problem:
 
     @classmethod
     def synthetic(cls, rows, n, avg_hits, seed=1234, row0=0, uniform=False, mapped_reads=0, device=0,
-                  sort=True, far_fraction=0.0):
+                  sort=True, far_fraction=0.0, gene_size=0, far_family=0):
+        """gene_size > 0: gene-block mode (a read's hits are isoforms of its gene); far_family F >= 2: a far hit goes to another gene of
+        the read's paralogue family of F genes (include/mmgibbs.h: mmg_synth_desc)."""
         lib = _lib.load()
-        d = SynthDesc(seed, rows, row0, n, float(avg_hits), int(uniform), int(sort), mapped_reads, float(far_fraction))
+        d = SynthDesc(seed, rows, row0, n, float(avg_hits), int(uniform), int(sort), mapped_reads, float(far_fraction), int(gene_size), int(far_family))
         h = C.c_void_p()
         check(lib.mmg_problem_create_synthetic(C.byref(d), device, C.byref(h)))
         return cls(h)

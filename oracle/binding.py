@@ -85,6 +85,8 @@ def lib():
     L.orc_synth_row_len.restype = C.c_uint32
     L.orc_synth_csr.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, f64p, f64p, C.c_int, C.c_double, u64p,
                                 C.c_void_p]
+    L.orc_synth_csr_genes.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, f64p, f64p, C.c_double, C.c_uint32, C.c_uint32, u64p,
+                                      C.c_void_p]
     _LIB = L
     return L
 
@@ -399,7 +401,7 @@ def canonical_layout(row_ptr, col_idx, k=None):
 
 
 # ----------------------------------------------------------------------------- synthetic input
-def synth_problem(R, T, avg_hits, seed=1234, uniform=False, row0=0, mapped_reads=None, sort=True, far_fraction=0.0):
+def synth_problem(R, T, avg_hits, seed=1234, uniform=False, row0=0, mapped_reads=None, sort=True, far_fraction=0.0, gene_size=0, far_family=0):
     """Synthetic problem of SURVEY.md App. D: rows [row0,row0+R), k=1. Returns (Problem, tables).  sort: rows in the library's
     canonical order (what mmg_problem_create_synthetic stores with sorted = 1); otherwise generator order."""
     L = lib()
@@ -410,9 +412,15 @@ def synth_problem(R, T, avg_hits, seed=1234, uniform=False, row0=0, mapped_reads
     len_cdf = np.empty(99, np.float64)
     L.orc_synth_len_cdf(float(avg_hits) - 1.0, len_cdf)
     row_ptr = np.empty(R + 1, np.uint64)
-    L.orc_synth_csr(seed, row0, R, T, cdf, len_cdf, int(uniform), float(far_fraction), row_ptr, None)
-    col = np.empty(int(row_ptr[-1]), np.uint32)
-    L.orc_synth_csr(seed, row0, R, T, cdf, len_cdf, int(uniform), float(far_fraction), row_ptr, col.ctypes.data_as(C.c_void_p))
+    if gene_size:                                       # gene-block mode (mmg_synth_desc.gene_size / far_family)
+        assert not uniform
+        L.orc_synth_csr_genes(seed, row0, R, T, cdf, len_cdf, float(far_fraction), int(gene_size), int(far_family), row_ptr, None)
+        col = np.empty(int(row_ptr[-1]), np.uint32)
+        L.orc_synth_csr_genes(seed, row0, R, T, cdf, len_cdf, float(far_fraction), int(gene_size), int(far_family), row_ptr, col.ctypes.data_as(C.c_void_p))
+    else:
+        L.orc_synth_csr(seed, row0, R, T, cdf, len_cdf, int(uniform), float(far_fraction), row_ptr, None)
+        col = np.empty(int(row_ptr[-1]), np.uint32)
+        L.orc_synth_csr(seed, row0, R, T, cdf, len_cdf, int(uniform), float(far_fraction), row_ptr, col.ctypes.data_as(C.c_void_p))
     if sort and R > 0:
         row_ptr, col, _, _ = canonical_layout(row_ptr, col)
     nreads = R if mapped_reads is None else mapped_reads

@@ -1086,6 +1086,126 @@ uint32_t orc_synth_row_len(uint64_t seed, uint64_t row, const double *len_cdf)
     return synth_row_len(len_cdf, ua);
 }
 
+/* gene-block mode of the generator (mmg_synth_desc.gene_size / far_family, include/mmgibbs.h; no reference counterpart: what an
+ * aligner's output looks like, src/bam2hits.cpp:271-300).  The family bijection g -> a g mod n_genes: a multiplier coprime to n_genes
+ * derived from the seed, and its inverse (mmg_types.h: synth_family_params restates this). */
+void orc_synth_family_params(uint64_t seed, uint32_t n_genes, uint32_t *a, uint32_t *ainv)
+{
+    if (n_genes < 2) { *a = 1; *ainv = 1 % (n_genes ? n_genes : 1); return; }
+    uint64_t x = (seed + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 31;
+    const uint64_t span = n_genes - 1 ? n_genes - 1 : 1;
+    uint64_t m = 2 + x % span;
+    for (;; m = 2 + (m - 1) % span) {
+        uint64_t u = m, v = n_genes;
+        while (v) { uint64_t t = u % v; u = v; v = t; }
+        if (u == 1) break;
+    }
+    int64_t t0 = 0, t1 = 1, r0 = n_genes, r1 = (int64_t)m;
+    while (r1 != 1) { int64_t q = r0 / r1, r2 = r0 - q * r1, t2 = t0 - q * t1; r0 = r1; r1 = r2; t0 = t1; t1 = t2; }
+    *a = (uint32_t)m;
+    *ainv = (uint32_t)(((t1 % (int64_t)n_genes) + (int64_t)n_genes) % (int64_t)n_genes);
+}
+
+static uint32_t synth_first_transcript(uint32_t T, const double *cdf, double ub)
+{
+    double target = ub * cdf[T - 1];
+    uint32_t lo = 0, hi = T - 1;
+    while (lo < hi) { uint32_t mid = lo + (hi - lo) / 2; if (target < cdf[mid]) hi = mid; else lo = mid + 1; }
+    return lo;
+}
+
+/* One row of the gene-block generator: the first transcript ~ cdf, the others distinct isoforms of ITS gene (an odd-stride walk over
+ * the gene's other slots); a far row's last drawn hit is an isoform of another gene of the read's paralogue family (far_family >= 2)
+ * or a transcript anywhere outside the gene (far_family = 0).  Sorted ascending.  Returns the length (<= gene size). */
+uint32_t orc_synth_row_genes(uint64_t seed, uint64_t row, uint32_t T, const double *cdf, const double *len_cdf, double far_fraction,
+                             uint32_t gene_size, uint32_t far_family, uint32_t *cols /* >= 100 */)
+{
+    const uint32_t n_genes = (T + gene_size - 1) / gene_size;
+    orc_stream s = stream_make(seed, 0, ORC_TAG_SYNTH_ROW, row, 0);
+    double ua, ub;
+    stream_pair(&s, &ua, &ub);
+    uint32_t L = synth_row_len(len_cdf, ua);
+    if (L > T) L = T;
+    const uint32_t t0 = synth_first_transcript(T, cdf, ub);
+    const uint32_t wb = (t0 / gene_size) * gene_size;
+    const uint32_t W = gene_size < T - wb ? gene_size : T - wb;
+    if (L > W) L = W;
+    cols[0] = t0;
+    if (L <= 1) return L;
+    uint32_t nslots = W - 1, Wp = 1;
+    while (Wp < nslots) Wp <<= 1;
+    double uc, ud;
+    stream_pair(&s, &uc, &ud);
+    uint32_t start = (uint32_t)(uc * (double)Wp);
+    uint32_t stride = ((uint32_t)(ud * (double)(Wp / 2 ? Wp / 2 : 1)) << 1) | 1u;
+    int far = 0;
+    uint32_t tfar = 0;
+    if (far_fraction > 0.0 && far_family >= 2u && n_genes >= 2u * far_family) {
+        uint32_t fa, fainv;
+        orc_synth_family_params(seed, n_genes, &fa, &fainv);
+        double ue, uf;
+        stream_pair(&s, &ue, &uf);
+        const uint32_t F = far_family, g0 = t0 / gene_size;
+        const uint32_t pg = (uint32_t)(((uint64_t)fa * g0) % n_genes), fam = pg / F, idx = pg % F;
+        const uint32_t fsize = F < n_genes - fam * F ? F : n_genes - fam * F;
+        if (fsize >= 2u) {
+            far = ue < far_fraction;
+            uint32_t j = 1u + (uint32_t)(uf * (double)(fsize - 1u));
+            if (j > fsize - 1u) j = fsize - 1u;
+            const uint32_t pm = fam * F + (idx + j) % fsize;
+            const uint32_t gm = (uint32_t)(((uint64_t)fainv * pm) % n_genes);
+            double ug, uh;
+            stream_pair(&s, &ug, &uh);
+            const uint32_t Wm = gene_size < T - gm * gene_size ? gene_size : T - gm * gene_size;
+            uint32_t iso = (uint32_t)(ug * (double)Wm);
+            if (iso >= Wm) iso = Wm - 1u;
+            tfar = gm * gene_size + iso;
+        }
+    } else if (far_fraction > 0.0 && T > 2u * W) {
+        double ue, uf;
+        stream_pair(&s, &ue, &uf);
+        far = ue < far_fraction;
+        tfar = (uint32_t)(uf * (double)T);
+        if (tfar >= T) tfar = T - 1;
+        if (tfar >= wb && tfar < wb + W) tfar = (tfar + W) % T;
+    }
+    uint32_t got = 1, pos = start & (Wp - 1);
+    while (got < L) {
+        if (pos < nslots) {
+            uint32_t t = wb + pos;
+            if (t >= t0) t += 1;
+            if (far && got == L - 1) t = tfar;
+            cols[got++] = t;
+        }
+        pos = (pos + stride) & (Wp - 1);
+    }
+    for (uint32_t i = 1; i < L; ++i) {
+        uint32_t v = cols[i], j = i;
+        while (j > 0 && cols[j - 1] > v) { cols[j] = cols[j - 1]; --j; }
+        cols[j] = v;
+    }
+    return L;
+}
+
+/* CSR of rows [row0, row0 + R) of the gene-block generator; col_idx NULL: sizing pass. */
+void orc_synth_csr_genes(uint64_t seed, uint64_t row0, uint64_t R, uint32_t T, const double *cdf, const double *len_cdf, double far_fraction,
+                         uint32_t gene_size, uint32_t far_family, uint64_t *row_ptr, uint32_t *col_idx)
+{
+    row_ptr[0] = 0;
+    for (uint64_t r = 0; r < R; ++r) {
+        uint32_t tmp[100];
+        row_ptr[r + 1] = row_ptr[r] + orc_synth_row_genes(seed, row0 + r, T, cdf, len_cdf, far_fraction, gene_size, far_family, tmp);
+    }
+    if (!col_idx) return;
+#pragma omp parallel for schedule(static) if (R > 100000)
+    for (int64_t r = 0; r < (int64_t)R; ++r) {
+        uint32_t tmp[100];
+        uint32_t L = orc_synth_row_genes(seed, row0 + (uint64_t)r, T, cdf, len_cdf, far_fraction, gene_size, far_family, tmp);
+        memcpy(col_idx + row_ptr[r], tmp, L * sizeof(uint32_t));
+    }
+}
+
 /* Row contents: first transcript ~ cdf (lower bound of ub*total); the other len-1 are
  * distinct members of a 129-wide index window around it, visited by an odd-stride walk;
  * the row is returned sorted ascending (src/mmseq.cpp:412).  Returns the length. */

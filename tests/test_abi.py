@@ -25,13 +25,13 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libmmgibbs.so does not export %s" % name
     assert sorted(_lib.SYMBOLS) == declared, "python binding table out of sync with include/mmgibbs.h"
-    assert lib.mmg_abi_version() == 6
+    assert lib.mmg_abi_version() == 7
 
 
 def test_struct_layouts_match_header():
     from mmseq_amd import _lib
     assert C.sizeof(_lib.ProblemDesc) == 72
-    assert C.sizeof(_lib.SynthDesc) == 64
+    assert C.sizeof(_lib.SynthDesc) == 72
     assert C.sizeof(_lib.Config) == 48
     assert C.sizeof(_lib.Timing) == 32
     assert C.sizeof(_lib.ProblemInfo) == 112

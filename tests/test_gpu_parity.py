@@ -64,6 +64,66 @@ def test_canonical_layout_is_the_oracles_restatement_and_ignores_the_upload_orde
     assert np.array_equal(traces[0][0], ref["trace"]) and np.array_equal(traces[0][1], ref["cnt"])
 
 
+def test_reads_that_also_hit_a_paralogue_family_get_a_gene_order_that_brings_the_family_together(gpu, orc):
+    """Spec version 7.  An aligner's output: a read's hits are isoforms of ONE gene, and a fifth of the reads also hit an isoform of a
+    paralogue -- a gene of a small fixed family whose other members lie anywhere in the caller's gene order (the CLI's is the name
+    order of a std::map, src/mmseq.cpp:337-357).  The generator's gene-block mode makes such rows (device = oracle restatement, bit
+    for bit); with tx_order = gene << 32 | transcript the library looks at which GENES share rows, reorders the genes so that a family
+    is contiguous (the isoforms of a gene stay together, in the caller's order), and the far rows disappear.  Everything crossing
+    the ABI stays in the caller's numbering; the chain is the oracle's replay of the downloaded rows; the order is a function of the
+    SET of rows."""
+    R, T, G, F = 60000, 6000, 24, 3
+    p, _ = orc.synth_problem(R=R, T=T, avg_hits=10, seed=19, sort=False, far_fraction=0.2, gene_size=G, far_family=F)
+    dev = gpu.Problem.synthetic(R, T, 10, seed=19, sort=False, far_fraction=0.2, gene_size=G, far_family=F)
+    d_rp, d_ci = dev.download()
+    assert np.array_equal(d_rp, p.row_ptr) and np.array_equal(d_ci, p.col_idx)       # the generator on the device = its restatement
+    dev.close()
+    rp = p.row_ptr.astype(np.int64)
+    gene = (p.col_idx // G).astype(np.int64)
+    two = np.minimum.reduceat(gene, rp[:-1]) != np.maximum.reduceat(gene, rp[:-1])
+    assert 0.15 < two.mean() < 0.25                                                  # a fifth of the reads hit a second gene
+    tx_order = ((np.arange(T, dtype=np.uint64) // np.uint64(G)) << np.uint64(32)) | np.arange(T, dtype=np.uint64)
+    with gpu.options(derive_order=0):                                                # spec version 6: the caller's gene order is final
+        v6 = gpu.Problem.from_csr(p.row_ptr, p.col_idx, p.l, tx_order=tx_order)
+        i6 = v6.info
+        assert i6.tx_renumbered == 1 and i6.far_tiles > 0.15 * i6.n_tiles
+        v6.close()
+    prob = gpu.Problem.from_csr(p.row_ptr, p.col_idx, p.l, tx_order=tx_order)
+    inf = prob.info
+    assert inf.tx_renumbered == 3 and inf.sample_kernel == 2
+    assert inf.far_tiles <= 0.05 * inf.n_tiles, (inf.far_tiles, inf.n_tiles)        # a family of 3 genes x 24 isoforms fits an LDS window
+    perm = prob.tx_perm()                                                            # device id of the caller's transcript t
+    assert np.array_equal(np.sort(perm), np.arange(T))
+    for g in range(0, T // G, 17):                                                   # a gene's isoforms: contiguous, in the caller's order
+        assert np.array_equal(perm[g * G:(g + 1) * G], perm[g * G] + np.arange(G))
+    q_rp, q_ci = prob.download()                                                     # stored rows, the caller's numbering
+    ci_q = perm[p.col_idx]
+    for r in range(p.m):
+        ci_q[rp[r]:rp[r + 1]].sort()
+    cq_rp, cq_ci, _, _ = orc.canonical_layout(p.row_ptr, ci_q)
+    assert np.array_equal(q_rp, cq_rp) and np.array_equal(perm[q_ci], cq_ci)         # = the canonical layout of the renumbered rows
+    mu0, _ = prob.start_values()
+    assert np.array_equal(mu0, orc.start_values_exact(orc.Problem(q_rp, q_ci, p.l)))
+    s = gpu.Sampler(prob, mu0, seed=3, n_chains=2, gibbs_iter=8, trace_len=8)
+    s.run(8)
+    for c in range(2):
+        ref = orc.gibbs_keyed(orc.Problem(q_rp, q_ci, p.l), mu0, seed=3, chain=c, n_iter=8, trace_len=8)
+        assert np.array_equal(s.trace(c), ref["trace"]) and np.array_equal(s.counts(c), ref["cnt"])
+    mu_e, it_e, ll_e = prob.em(mu0, max_iter=12, epsilon=-1e308)
+    mu_eo, _, ll_eo = orc.em(orc.Problem(q_rp, q_ci, p.l), mu0, max_iter=12, epsilon=-1e308)
+    assert np.array_equal(mu_e, mu_eo) and ll_e == ll_eo
+    shuffled = np.random.default_rng(8).permutation(p.m)
+    s_rp, s_ci, _ = orc.permute_rows(p.row_ptr, p.col_idx, None, shuffled)
+    again = gpu.Problem.from_csr(s_rp, s_ci, p.l, tx_order=tx_order)
+    a_rp, a_ci = again.download()
+    assert np.array_equal(again.tx_perm(), perm) and np.array_equal(a_rp, q_rp) and np.array_equal(a_ci, q_ci)
+    # far hits that go ANYWHERE (far_family = 0) link every gene to every other: no order helps, the caller's stays
+    pu, _ = orc.synth_problem(R=R, T=T, avg_hits=10, seed=19, sort=False, far_fraction=0.2, gene_size=G, far_family=0)
+    uni = gpu.Problem.from_csr(pu.row_ptr, pu.col_idx, pu.l, tx_order=tx_order)
+    assert uni.info.tx_renumbered == 1
+    uni.close(); again.close(); s.close(); prob.close()
+
+
 def test_first_seen_numbering_with_tx_order_takes_the_fast_kernel(gpu, orc):
     """The reference numbers transcripts in first-seen order (src/mmseq.cpp:399-408), which scatters the isoforms of a gene over
     the index range.  Uploaded like that the rows span the whole range and only the CSR kernel applies; with tx_order (gene

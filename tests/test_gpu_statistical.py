@@ -29,7 +29,7 @@ def test_device_chain_agrees_with_reference_structured_engine(gpu, orc, seed_dev
     with np.errstate(divide="ignore"):
         lref = np.log(ref)
     obs = np.unique(q.col_idx)
-    z, sdr = [], []
+    z, sdr, sdtol = [], [], []
     for t in obs:
         rc, var_b, tau_b, _ = orc.sokal(lref[t].copy())
         var_a, tau_a = dev["var"][t], dev["tau"][t]
@@ -38,11 +38,16 @@ def test_device_chain_agrees_with_reference_structured_engine(gpu, orc, seed_dev
         mc = np.sqrt(tau_a * var_a / S + tau_b * var_b / S)                       # mcse of either mean, :1320-1323
         z.append((dev["log_mean"][t] - lref[t].mean()) / mc)
         sdr.append(np.sqrt(var_a / var_b))
-    z, sdr = np.array(z), np.array(sdr)
+        sdtol.append(5 * np.sqrt(max(tau_a, tau_b) / (2.0 * S)))
+    z, sdr, sdtol = np.array(z), np.array(sdr), np.array(sdtol)
     assert len(z) > 0.9 * len(obs)
-    assert (np.abs(z) <= 5).mean() >= 0.99                                        # App. E.3: |delta log_mu| <= 5 sqrt(mcse_a^2 + mcse_b^2)
-    assert abs(np.median(sdr) - 1) < 0.01                                         # posterior sd: same to 1 %
-    assert abs(z.mean()) < 0.1 and 0.8 < z.var() < 1.3                            # differences are Monte Carlo noise of the stated size
+    # SURVEY App. E.3 AS WRITTEN (the null distribution of these statistics -- one engine against itself, 24 seed pairs each for the
+    # reference-structured and the keyed engine on this very problem, profiles/r05_e3_null_{ref,keyed}.txt -- sits well inside every
+    # bound: |mean| <= 0.017, variance 1.09-1.19, median sd ratio within 0.0023 of 1, all |z| <= 7.2)
+    assert (np.abs(z) <= 5).mean() >= 0.99 and np.abs(z).max() < 8               # |delta log_mu| <= 5 sqrt(mcse_a^2 + mcse_b^2) for >= 99 %, none beyond 8 x
+    assert ((np.abs(sdr - 1) <= sdtol).mean() >= 0.99)                            # sd ratio within 1 +- 5 sqrt(tau / (2 * 1024)) per transcript (two sd estimates: 99 %)
+    assert abs(np.median(sdr) - 1) < 0.01                                         # median ratio within 1 +- 0.01
+    assert abs(z.mean()) < 0.05 and 0.8 < z.var() < 1.3                           # pooled z: |mean| < 0.05, variance in [0.8, 1.3]
     summ.close(); s.close(); prob.close()
 
 
