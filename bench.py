@@ -177,7 +177,7 @@ def cpu_baseline(args, prob, mu0, device=0):
 
 
 def side_measurement(name, rows, transcripts, avg_hits, chains=1, uniform=False, sort=True, far_fraction=0.0, steps=48, warmup=8,
-                     seed=1234, device=0, note="", multiplicities=False, scatter=False):
+                     seed=1234, device=0, note="", multiplicities=False, scatter=False, genes=None):
     """One more workload, same protocol (inputs resident, HIP events on the launch stream), shorter: ms per sweep and which kernel ran.
     multiplicities: the rows get a k array with the distribution a collapsed 50 M-read file of this generator has (93.6 % k = 1,
     5.3 % k = 2, ... 0.12 % k in 9..36: tools/collapse_probe.py) -- what every real hits file produces (src/mmseq.cpp:409-418)."""
@@ -186,8 +186,20 @@ def side_measurement(name, rows, transcripts, avg_hits, chains=1, uniform=False,
     from mmseq_amd import Problem, Sampler
     from mmseq_amd import dist as mdist
     t0 = time.perf_counter()
-    prob = Problem.synthetic(rows, transcripts, avg_hits, seed=seed, uniform=uniform, sort=sort, far_fraction=far_fraction,
-                             mapped_reads=rows, device=device)
+    prob = Problem.synthetic(rows, transcripts, avg_hits, seed=seed, uniform=uniform, sort=sort and not genes, far_fraction=far_fraction,
+                             mapped_reads=rows, device=device, gene_size=genes[0] if genes else 0, far_family=genes[1] if genes else 0)
+    if genes:
+        # an aligner's output (generator gene-block mode): a read's hits are isoforms of one gene, far hits go to a gene of the read's
+        # paralogue family -- uploaded as the CLI uploads a hits file: rows in generator order, tx_order = gene << 32 | transcript, the
+        # genes in the caller's (name) order, which puts a family's members anywhere.  Spec version 7: the library reorders the genes.
+        rp, ci = prob.download()
+        l = prob.l()
+        prob.close()
+        t_ids = np.arange(transcripts, dtype=np.uint64)
+        t1 = time.perf_counter()
+        prob = Problem.from_csr(rp, ci, l, device=device, tx_order=((t_ids // np.uint64(genes[0])) << np.uint64(32)) | t_ids)
+        scatter_create_s = time.perf_counter() - t1
+        del rp, ci
     if scatter:
         # the reference's first-seen numbering (src/mmseq.cpp:399-408): the transcripts get random ids, the rows come in generator order,
         # and NO tx_order is passed -- the library has to find the locality itself (spec version 6: an order derived from the hit graph)
@@ -257,7 +269,7 @@ def side_measurement(name, rows, transcripts, avg_hits, chains=1, uniform=False,
            "far_tiles": (inf.far_tiles / inf.n_tiles) if inf.sample_kernel == 2 and inf.n_tiles else 0.0,
            "stream_bytes": inf.stream_bytes, "n_tiles": inf.n_tiles, "alg_bytes": b_sweep, "alg_frac": b_sweep / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "build_s": round(build_s, 2)}
-    if scatter:
+    if scatter or genes:
         out["tx_renumbered"] = inf.tx_renumbered
         out["create_s"] = round(scatter_create_s, 2)
     smp.close()
@@ -296,6 +308,10 @@ SIDE = [
     ("heavy", "a heavily collapsed file: 5M hit sets, multiplicities 1..20000 (total_k reads)", dict(rows=5_000_000, transcripts=T3, avg_hits=H3, multiplicities="heavy", steps=32)),
     ("far2", "50M x 200k, 2 % of the rows with a hit anywhere in the transcriptome", dict(rows=R3, transcripts=T3, avg_hits=H3, far_fraction=0.02, steps=32)),
     ("far20", "50M x 200k, 20 % of the rows with a hit anywhere", dict(rows=R3, transcripts=T3, avg_hits=H3, far_fraction=0.2, steps=24)),
+    ("gene0", "50M x 200k like an aligner's output: a read's hits are isoforms of ONE gene (32 isoforms per gene), tx_order = the caller's genes",
+     dict(rows=R3, transcripts=T3, avg_hits=H3, genes=(32, 3), steps=32)),
+    ("far20p", "the same with 20 % of the reads also hitting a gene of their paralogue family (3 genes, anywhere in the caller's gene order): the library reorders the genes",
+     dict(rows=R3, transcripts=T3, avg_hits=H3, genes=(32, 3), far_fraction=0.2, steps=32)),
     ("uniform", "50M x 200k, hits uniform over all transcripts (SURVEY App. D worst case)", dict(rows=R3, transcripts=T3, avg_hits=H3, uniform=True, steps=8, warmup=2)),
     ("keeprows", "50M x 200k, rows kept in generator order (MMG_LAYOUT_KEEP_ROWS)", dict(rows=R3, transcripts=T3, avg_hits=H3, sort=False, steps=8, warmup=2)),
     ("scatter", "50M x 200k, transcripts numbered at random (first-seen numbering), rows in generator order, NO tx_order: order derived from the hit graph",
@@ -571,6 +587,9 @@ def main():
             roof["em_hbm_frac"] = (other.get("em") or {}).get("frac")
             roof["real8_chain_it_s"] = g("real8", "chain_it_s")
             roof["far20_ms"] = g("far20", "ms_per_step")
+            roof["gene0_ms"] = g("gene0", "ms_per_step")
+            roof["far20p_ms"] = g("far20p", "ms_per_step")
+            roof["far20p_far_tiles"] = g("far20p", "far_tiles")
             roof["uniform_ms"] = g("uniform", "ms_per_step")
             roof["keeprows_ms"] = g("keeprows", "ms_per_step")
             roof["scatter_no_tx_order_ms"] = g("scatter", "ms_per_step")

@@ -1,7 +1,9 @@
 // synth_hits -- writes the synthetic benchmark workload (mmg_problem_create_synthetic) as a hits FILE, so that the
 // drop-in CLI can be run end to end at sizes no alignment in this image provides (a 50 M-read file).
-//   synth_hits [-t] ROWS TRANSCRIPTS AVG_HITS OUT.hits [FAR_FRACTION [SEED [DEVICE]]]
+//   synth_hits [-t] [-genes G F] ROWS TRANSCRIPTS AVG_HITS OUT.hits [FAR_FRACTION [SEED [DEVICE]]]
 // Reads come in generator order (a name-sorted BAM's order), transcripts in header order with genes of 1..7 consecutive isoforms;
+// -genes G F: the generator's gene-block mode (mmg_synth_desc.gene_size / far_family): genes of G isoforms, a read's hits inside its
+// gene, far hits to a gene of the read's paralogue family of F genes (0: anywhere) -- the header's genes are then those blocks;
 // the rows are generated on the device, downloaded and written with HitsfileWriter (binary schema unless -t).
 #include <cstdio>
 #include <cstdlib>
@@ -18,8 +20,10 @@ int main(int argc, char **argv)
     bool text = false;
     int a = 1;
     if (a < argc && !std::strcmp(argv[a], "-t")) { text = true; ++a; }
+    uint32_t gene_size = 0, far_family = 0;
+    if (a + 2 < argc && !std::strcmp(argv[a], "-genes")) { gene_size = (uint32_t)std::strtoul(argv[a + 1], nullptr, 10); far_family = (uint32_t)std::strtoul(argv[a + 2], nullptr, 10); a += 3; }
     if (argc - a < 4) {
-        std::fprintf(stderr, "usage: synth_hits [-t] ROWS TRANSCRIPTS AVG_HITS OUT.hits [FAR_FRACTION [SEED [DEVICE]]]\n");
+        std::fprintf(stderr, "usage: synth_hits [-t] [-genes G F] ROWS TRANSCRIPTS AVG_HITS OUT.hits [FAR_FRACTION [SEED [DEVICE]]]\n");
         return 1;
     }
     const uint64_t rows = std::strtoull(argv[a], nullptr, 10);
@@ -34,6 +38,7 @@ int main(int argc, char **argv)
     std::memset(&sd, 0, sizeof sd);
     sd.seed = seed; sd.rows = rows; sd.row0 = 0; sd.n = n; sd.avg_hits = avg; sd.uniform = 0; sd.sorted = 0; sd.mapped_reads = rows;
     sd.far_fraction = far;
+    sd.gene_size = gene_size; sd.far_family = far_family;
     mmg_problem *prob = nullptr;
     if (mmg_problem_create_synthetic(&sd, device, &prob)) die("mmg_problem_create_synthetic");
     mmg_problem_info inf;
@@ -61,7 +66,7 @@ int main(int argc, char **argv)
         for (uint32_t t = 0; t < n; ++g) {
             std::snprintf(buf, sizeof buf, "G%06u", g);
             w.addGeneIsoformRecord(buf);
-            const uint32_t size = 1 + (uint32_t)(((uint64_t)g * 2654435761ull >> 7) % 7);
+            const uint32_t size = gene_size ? gene_size : 1 + (uint32_t)(((uint64_t)g * 2654435761ull >> 7) % 7);
             for (uint32_t j = 0; j < size && t < n; ++j, ++t) w.addTranscriptToGeneIsoformRecord(name[t]);
         }
         w.writeHeader();

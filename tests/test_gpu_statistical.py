@@ -45,7 +45,11 @@ def test_device_chain_agrees_with_reference_structured_engine(gpu, orc, seed_dev
     # reference-structured and the keyed engine on this very problem, profiles/r05_e3_null_{ref,keyed}.txt -- sits well inside every
     # bound: |mean| <= 0.017, variance 1.09-1.19, median sd ratio within 0.0023 of 1, all |z| <= 7.2)
     assert (np.abs(z) <= 5).mean() >= 0.99 and np.abs(z).max() < 8               # |delta log_mu| <= 5 sqrt(mcse_a^2 + mcse_b^2) for >= 99 %, none beyond 8 x
-    assert ((np.abs(sdr - 1) <= sdtol).mean() >= 0.99)                            # sd ratio within 1 +- 5 sqrt(tau / (2 * 1024)) per transcript (two sd estimates: 99 %)
+    # sd ratio within 1 +- 5 sqrt(tau / (2 * 1024)) per transcript: DEVIATION from App. E.3, which asks it of every transcript.  The
+    # bound assumes Gaussian samples; log mu of a transcript with few reads is log-Gamma with a heavy left tail, and one engine
+    # against ITSELF holds it for 95.8 % of the transcripts (tools/e3_null.py, profiles/r05_e3_null_sd_clause.txt; 98.3 % within twice
+    # the bound).  Held here at the null's level: a wrong posterior sd would show in the median (next line, as written) long before.
+    assert (np.abs(sdr - 1) <= sdtol).mean() >= 0.94
     assert abs(np.median(sdr) - 1) < 0.01                                         # median ratio within 1 +- 0.01
     assert abs(z.mean()) < 0.05 and 0.8 < z.var() < 1.3                           # pooled z: |mean| < 0.05, variance in [0.8, 1.3]
     summ.close(); s.close(); prob.close()
@@ -98,10 +102,18 @@ def test_real_file_shape_transcripts_and_genes_agree_with_reference_structured_e
         z, sdr = _compare(orc, dev_t, np.log(ref[obs]), obs, S, S, min_frac=0.8)   # (fewer reads per transcript than E.3's shape: more iact >= 20)
         gobs = [g for g, mem in enumerate(genes) if np.isin(mem, obs).any()]
         zg, sdrg = _compare(orc, dev_g, np.log(np.stack([ref[genes[g]].sum(axis=0) for g in gobs])), gobs, S, S, min_frac=0.8)
-    for zz, ss in ((z, sdr), (zg, sdrg)):
-        assert (np.abs(zz) <= 5).mean() >= 0.99 and np.abs(zz).max() < 8             # App. E.3
-        assert abs(np.median(ss) - 1) < 0.015
-        assert abs(zz.mean()) < 0.12 and 0.75 < zz.var() < 1.35
+    # transcripts: SURVEY App. E.3 as written (null of this very shape, the reference-structured engine against itself over 20 seed pairs,
+    # profiles/r05_e3_null_ref_realshape.txt: |mean| <= 0.038, variance 1.13-1.24, median sd ratio within 0.0022 of 1, all |z| <= 5.6)
+    assert (np.abs(z) <= 5).mean() >= 0.99 and np.abs(z).max() < 8
+    assert abs(np.median(sdr) - 1) < 0.01
+    assert abs(z.mean()) < 0.05 and 0.8 < z.var() < 1.3
+    # genes ("same for gene-level rows"): DEVIATION from App. E.3 in two figures.  There are 894 gene series here, not 4 000: in the null
+    # (profiles/r05_e3_null_ref_realshape_genes.txt, 20 seed pairs) the pooled mean reaches 0.057 and the variance 1.298 -- one engine
+    # against itself fails "|mean| < 0.05" once in twenty and sits on "variance < 1.3".  Held at |mean| < 0.08, variance in [0.8, 1.35];
+    # within-5, the 8 x limit and the median sd ratio as written (null: sd ratio within 0.006).
+    assert (np.abs(zg) <= 5).mean() >= 0.99 and np.abs(zg).max() < 8
+    assert abs(np.median(sdrg) - 1) < 0.01
+    assert abs(zg.mean()) < 0.08 and 0.8 < zg.var() < 1.35
     summ.close(); s.close(); prob.close()
 
 

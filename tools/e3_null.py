@@ -98,7 +98,7 @@ def pooled_stats(seed):
 def stats(la, lb):
     n = la.shape[1]
     n2 = 1 << int(np.log2(n))
-    z, sdr = [], []
+    z, sdr, sdtol = [], [], []
     for i in range(la.shape[0]):
         xa, xb = la[i], lb[i]
         if not (np.isfinite(xa).all() and np.isfinite(xb).all()):
@@ -109,18 +109,22 @@ def stats(la, lb):
             continue
         z.append((xa.mean() - xb.mean()) / np.sqrt(ta * va / n + tb * vb / n))
         sdr.append(np.sqrt(va / vb))
-    z, sdr = np.array(z), np.array(sdr)
+        sdtol.append(5 * np.sqrt(max(ta, tb) / (2.0 * n)))
+    z, sdr, sdtol = np.array(z), np.array(sdr), np.array(sdtol)
+    global last_sd_within
+    last_sd_within = ((np.abs(sdr - 1) <= sdtol).mean(), (np.abs(sdr - 1) <= 2 * sdtol).mean())
     return z.mean(), z.var(), (np.abs(z) <= 5).mean(), np.abs(z).max(), np.median(sdr), len(z)
 
 
 rows = []
+last_sd_within = (float('nan'), float('nan'))
 print("# engine %s, %d rows x %d transcripts, avg %.0f hits, %d iterations, burn %d, %d observed transcripts, far %.2f, kmix %d, genes %d, pooled %d" % (
     a.engine, a.rows, a.transcripts, a.avg, S, a.burn, len(obs), a.far, a.kmix, a.genes, a.pooled), flush=True)
 print("# pair  z_mean   z_var  within5  max|z|  median_sd_ratio  used", flush=True)
 for p in range(a.pairs):
     r = pooled_stats(10_000 + 16 * p) if a.pooled else stats(run(10_000 + 2 * p), run(10_001 + 2 * p))
     rows.append(r)
-    print("%5d  %+.4f  %.4f  %.4f  %6.2f  %.5f  %d" % ((p,) + r), flush=True)
+    print("%5d  %+.4f  %.4f  %.4f  %6.2f  %.5f  %d" % ((p,) + r) + ("" if a.pooled else "   sd ratio within 1 +- 5 sqrt(tau / 2n): %.4f, within twice that: %.4f" % last_sd_within), flush=True)
 R = np.array(rows)
 for name, col in (("z_mean", 0), ("z_var", 1), ("within5", 2), ("max|z|", 3), ("median_sd_ratio", 4)):
     x = R[:, col]
