@@ -6,8 +6,9 @@
 
 namespace mmg {
 
-const void *k1_sell_kernel(bool idx64, bool has_k)
+const void *k1_sell_kernel(bool idx64, bool has_k, bool fixed_walk)
 {
+    if (!has_k && fixed_walk) return idx64 ? (const void *)k_sample_sell<uint64_t, false, 8, 1, false, true> : (const void *)k_sample_sell<uint32_t, false, 8, 1, false, true>;
     if (idx64) return has_k ? (const void *)k_sample_sell<uint64_t, true, 8> : (const void *)k_sample_sell<uint64_t, false, 8>;
     return has_k ? (const void *)k_sample_sell<uint32_t, true, 8> : (const void *)k_sample_sell<uint32_t, false, 8>;
 }

@@ -9,7 +9,7 @@
 namespace mmg {
 
 // ---- k1.hip: the sample kernels (src/mmseq.cpp:857-891) and their stream builders
-const void *k1_sell_kernel(bool idx64, bool has_k);   // k_sample_sell, 64 threads per workgroup
+const void *k1_sell_kernel(bool idx64, bool has_k, bool fixed_walk = false);   // k_sample_sell, 64 threads per workgroup
 const void *k1_sell_far_kernel(bool idx64);            // k_sample_sell for the list of far / CSR-walked tiles (far list prefetched), no multiplicities
 const void *k1_sell_multi_kernel(bool idx64, int nch); // k_sample_sell_multi for nch = 2 or 4 chains (no multiplicities), 64 threads
 const void *k1_csr_kernel(bool idx64, bool has_k);    // k_sample, K1C_BS threads per workgroup

@@ -219,7 +219,7 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
 #undef SELL_TRY
     auto resident_raw = [&](bool has_k) { // workgroups of the kernel the device holds at once
         int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k1_sell_kernel(p->idx64, has_k), 64, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 16; }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k1_sell_kernel(p->idx64, has_k, false), 64, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 16; }
         if (per_cu > 32) per_cu = 32;
         if (opt(MMG_OPT_SELL_WAVES_PER_CU) >= 1 && opt(MMG_OPT_SELL_WAVES_PER_CU) < per_cu) per_cu = opt(MMG_OPT_SELL_WAVES_PER_CU);
         return (uint64_t)p->cu_count * per_cu;
@@ -323,6 +323,7 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
     p->n_fast_tiles = n_fast;
     p->n_far_tiles = n_far;
     p->padded_slots = slots;
+    p->k1_fixed_walk = n_fast > 0 && slots < 4 * 256 * n_fast;
     const size_t alloc = p->sell_bytes + 64 + 8 * 256; // head room: tiles without a block prefetch the head of the stream
     HIP_TRY(hipMalloc((void **)&p->d_sell, alloc));
     HIP_TRY(hipMemset(p->d_sell, 0, alloc));
@@ -869,7 +870,7 @@ extern "C" int mmg_problem_shard_bounds_timed(const mmg_problem *p, const double
         if (g1) {
             const SellTile *ts = d_t1;
             void *kargs[] = {(void *)&rp, (void *)&ci, (void *)&kk, (void *)&ts, (void *)&hdr1, (void *)&mup, (void *)&ss, (void *)&cnt, (void *)&a};
-            e = hipLaunchKernel(k1_sell_kernel(p->idx64, false), dim3(g1), dim3(64), kargs, 0, 0);
+            e = hipLaunchKernel(k1_sell_kernel(p->idx64, false, p->k1_fixed_walk), dim3(g1), dim3(64), kargs, 0, 0);
         }
         if (e == hipSuccess && gk) {
             const SellTile *ts = p->d_sell_tiles_k;

@@ -180,7 +180,7 @@ static int sampler_sample(mmg_sampler *s, bool fold)
             const double *mu = s->d_mu + (size_t)c0 * p->n;
             int32_t *cnt = s->d_cnt + (size_t)c0 * p->n;
             void *kargs[] = {(void *)&rp, (void *)&ci, (void *)&kk, (void *)&ts, (void *)&cs, (void *)&mu, (void *)&ss, (void *)&cnt, (void *)&a};
-            const void *fn = kind == 2 ? k1_sell_far_kernel(p->idx64) : k1_sell_kernel(p->idx64, kind == 1);
+            const void *fn = kind == 2 ? k1_sell_far_kernel(p->idx64) : k1_sell_kernel(p->idx64, kind == 1, kind == 0 && p->k1_fixed_walk);
             HIP_TRY(hipLaunchKernel(fn, dim3(grid, nc), dim3(64), kargs, 0, s->cur));
             return MMG_OK;
         };

@@ -165,7 +165,10 @@ struct RowViewFarTile {
 // FARPF: the instantiation that walks the list of far (and CSR-walked) tiles: the far count and the first far transcript of every lane
 // travel with the block's prefetch, and the first far weight is gathered while the window part is walked.  Without it a far tile is
 // three dependent memory round trips in the middle of its walk (count -> transcript id -> weight): 10 x a register-path tile.
-template <typename IdxT, bool HAS_K, int NGC, int REP = 1, bool FARPF = false>
+// FIXW: register-path tiles of at most 8 groups take straight-line code per group count (walk_fixed) -- the instantiation for problems
+// of SHORT rows (fewer than 4 groups per tile on average: BASELINE configs[1], 8 hits per read, K1 -5 %); at 20 hits per read the
+// stream bounds the kernel and the generic walk is 0.7 % ahead (less code), so the host picks per problem (mmg_problem::k1_fixed_walk)
+template <typename IdxT, bool HAS_K, int NGC, int REP = 1, bool FARPF = false, bool FIXW = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : (FARPF ? 6 : 7), HAS_K ? 5 : (FARPF ? 6 : 7)))) void k_sample_sell(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
                                                     const uint32_t *__restrict__ kmult, const SellTile *__restrict__ tiles, const uint64_t *__restrict__ chunk_tile,
                                                     const double *__restrict__ gmu /* [grid.y][n] */, const uint8_t *__restrict__ stream,
@@ -305,6 +308,120 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
         const uint32_t b0 = (uint32_t)__builtin_amdgcn_ds_bpermute(sb, (int)x0), b1 = (uint32_t)__builtin_amdgcn_ds_bpermute(sb, (int)x1);
         xrowA = (pa & 1u) ? a1 : a0;
         xrowB = (pb & 1u) ? b1 : b0;
+    };
+
+    // ---- the walk of a register-path tile of at most 8 groups, written out per group count (the k = 1 kernel without far lists) -----
+    // One body for every ng (walk, below) costs a scalar test per group, a copy of the running sum behind every conditional group and a
+    // branch ladder into the pick's sweep.  Here a tile's ng selects straight-line code: the boundaries are the sums themselves (no
+    // copies), the sweep has no entry branches, PIPE: the gathers of group i + 1 are in flight while group i is added.  Same additions,
+    // comparisons and draw in the same order: bit-identical (tests/test_gpu_parity.py, test_gpu_fullsize.py, tools/fuzz_parity.py).
+    auto walk_fixed = [&](const SellTile &d, const Buf &bf, uint32_t which, auto ng_tag) {
+        constexpr int NG = decltype(ng_tag)::value;
+        constexpr bool PIPE = true; // (the gathers of group i + 1 in flight while group i is added: still 72 VGPRs)
+        static_assert(!HAS_K && NG >= 1 && NG <= 8, "k = 1 kernel, cached groups only");
+        const uint32_t gw[8] = {bf.g0, bf.g1, bf.g2, bf.g3, bf.g4, bf.g5, bf.g6, bf.g7};
+        struct G4 { double w[4]; };
+        auto gather = [&](uint32_t v) {
+            G4 r;
+            const uint32_t o0 = SELL_OFF0(v), o1 = SELL_OFF1(v), o2 = SELL_OFF2(v), o3 = SELL_OFF3(v);
+            r.w[0] = wo(o0); r.w[1] = wo(o1); r.w[2] = wo(o2); r.w[3] = wo(o3);
+            return r;
+        };
+        double P[NG];
+        {
+            G4 cur = gather(gw[0]), nxt = cur;
+            if (PIPE && NG > 1) nxt = gather(gw[1]);
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                __builtin_amdgcn_sched_barrier(0);
+                double t = i == 0 ? cur.w[0] : P[i - 1] + cur.w[0]; // 0.0 + w == w exactly
+                t += cur.w[1]; t += cur.w[2]; t += cur.w[3];
+                P[i] = t;
+                __builtin_amdgcn_sched_barrier(0);
+                if (PIPE) { cur = nxt; if (i + 2 < NG) nxt = gather(gw[i + 2]); }
+                else if (i + 1 < NG) cur = gather(gw[i + 1]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t x = which ? xrowB : xrowA;
+        const double ts = P[NG - 1] * 0x1p-32, hs = ts * 0.5;
+        const double target = draw_target(x, ts, hs); // mmg_math.h
+        uint32_t v;
+        double acc;
+        {
+            uint64_t sv, tm;
+#define SF_STEP(i, prev) "v_cmpx_lt_f64_e64 %[tm], %[t], %[p" #i "]\n\t" "v_mov_b32 %[v], %[g" #i "]\n\t" "v_mov_b64 %[acc], " prev "\n\t"
+#define SF_HEAD "s_mov_b64 %[sv], exec\n\t" "v_mov_b32 %[v], 0\n\t" "v_mov_b64 %[acc], 0\n\t"
+#define SF_TAIL "s_mov_b64 exec, %[sv]"
+#define SF_OUT [v] "=&v"(v), [acc] "=&v"(acc), [sv] "=&s"(sv), [tm] "=&s"(tm)
+#define SF_IN(n) [t] "v"(target), [p0] "v"(P[0]), [p1] "v"(P[n > 1 ? 1 : 0]), [p2] "v"(P[n > 2 ? 2 : 0]), [p3] "v"(P[n > 3 ? 3 : 0]),       \
+                 [p4] "v"(P[n > 4 ? 4 : 0]), [p5] "v"(P[n > 5 ? 5 : 0]), [p6] "v"(P[n > 6 ? 6 : 0]), [p7] "v"(P[n > 7 ? 7 : 0]),            \
+                 [g0] "v"(gw[0]), [g1] "v"(gw[n > 1 ? 1 : 0]), [g2] "v"(gw[n > 2 ? 2 : 0]), [g3] "v"(gw[n > 3 ? 3 : 0]), [g4] "v"(gw[n > 4 ? 4 : 0]), \
+                 [g5] "v"(gw[n > 5 ? 5 : 0]), [g6] "v"(gw[n > 6 ? 6 : 0]), [g7] "v"(gw[n > 7 ? 7 : 0])
+#define SF_S0 SF_STEP(0, "0")
+#define SF_S1 SF_STEP(1, "%[p0]") SF_S0
+#define SF_S2 SF_STEP(2, "%[p1]") SF_S1
+#define SF_S3 SF_STEP(3, "%[p2]") SF_S2
+#define SF_S4 SF_STEP(4, "%[p3]") SF_S3
+#define SF_S5 SF_STEP(5, "%[p4]") SF_S4
+#define SF_S6 SF_STEP(6, "%[p5]") SF_S5
+#define SF_S7 SF_STEP(7, "%[p6]") SF_S6
+            if constexpr (NG == 1) asm volatile(SF_HEAD SF_S0 SF_TAIL : SF_OUT : SF_IN(1));
+            else if constexpr (NG == 2) asm volatile(SF_HEAD SF_S1 SF_TAIL : SF_OUT : SF_IN(2));
+            else if constexpr (NG == 3) asm volatile(SF_HEAD SF_S2 SF_TAIL : SF_OUT : SF_IN(3));
+            else if constexpr (NG == 4) asm volatile(SF_HEAD SF_S3 SF_TAIL : SF_OUT : SF_IN(4));
+            else if constexpr (NG == 5) asm volatile(SF_HEAD SF_S4 SF_TAIL : SF_OUT : SF_IN(5));
+            else if constexpr (NG == 6) asm volatile(SF_HEAD SF_S5 SF_TAIL : SF_OUT : SF_IN(6));
+            else if constexpr (NG == 7) asm volatile(SF_HEAD SF_S6 SF_TAIL : SF_OUT : SF_IN(7));
+            else asm volatile(SF_HEAD SF_S7 SF_TAIL : SF_OUT : SF_IN(8));
+#undef SF_S0
+#undef SF_S1
+#undef SF_S2
+#undef SF_S3
+#undef SF_S4
+#undef SF_S5
+#undef SF_S6
+#undef SF_S7
+#undef SF_IN
+#undef SF_OUT
+#undef SF_TAIL
+#undef SF_HEAD
+#undef SF_STEP
+        }
+        const uint32_t o0 = SELL_OFF0(v), o1 = SELL_OFF1(v), o2 = SELL_OFF2(v), o3 = SELL_OFF3(v);
+        double w0 = wo(o0), w1 = wo(o1), w2 = wo(o2);
+        asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2)); // all three requested before the first is waited for
+        const double p0 = acc + w0, p1 = p0 + w1, p2 = p1 + w2;
+        uint32_t sel = o3;
+        {
+            uint64_t sv, tm;
+            asm volatile("s_mov_b64 %[sv], exec\n\t"
+                         "v_cmpx_lt_f64_e64 %[tm], %[t], %[p2]\n\t" "v_mov_b32 %[sel], %[o2]\n\t"
+                         "v_cmpx_lt_f64_e64 %[tm], %[t], %[p1]\n\t" "v_mov_b32 %[sel], %[o1]\n\t"
+                         "v_cmpx_lt_f64_e64 %[tm], %[t], %[p0]\n\t" "v_mov_b32 %[sel], %[o0]\n\t"
+                         "s_mov_b64 exec, %[sv]"
+                         : [sel] "+&v"(sel), [sv] "=&s"(sv), [tm] "=&s"(tm)
+                         : [t] "v"(target), [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [o0] "v"(o0), [o1] "v"(o1), [o2] "v"(o2));
+        }
+        if (v == 0u) { // rare: no row in this lane, a degenerate total, rounding (a stored group word is never 0)
+            uint32_t L = 0;
+#pragma unroll
+            for (int i = 0; i < NG; ++i) L += sell_group_hits(gw[i]);
+            auto off_of = [&](uint32_t j) -> uint32_t {
+                uint32_t r = gw[0];
+                asm("" : "+v"(r));
+#pragma unroll
+                for (int i = 1; i < NG; ++i) { r = ((j >> 2) == (uint32_t)i) ? gw[i] : r; asm("" : "+v"(r)); }
+                return ((r >> (8u * (j & 3u))) & 0xffu) << 3;
+            };
+            const double tc = P[NG - 1];
+            if (L == 0) sel = (uint32_t)WIN * 8u; // the count of the pad slot, which is never flushed
+            else if (!(tc > 0.0) || !(tc < __builtin_huge_val())) {
+                const uint32_t j = (uint32_t)(u32_unit(x) * (double)L);
+                sel = off_of(j < L ? j : L - 1);
+            } else sel = off_of(L - 1); // rounding left target >= total: the last real hit
+        }
+        atomicAdd((int32_t *)((char *)s_cnt + rep_off + sel), 1);
     };
 
     // FAR (a tag type): the walk of a far tile -- the same code plus the far list behind the window part; a separate instantiation, so
@@ -572,7 +689,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
             cur_base = d.wbase;
             __syncthreads();
         }
-        if (d.flags() & SELL_FAST) walk(d, bf, which, BoolTag<false>());
+        if (d.flags() & SELL_FAST) {
+            if constexpr (!HAS_K && !FARPF && FIXW) {
+                switch (d.ng()) { // uniform
+                case 1: walk_fixed(d, bf, which, IntTag<1>()); break;
+                case 2: walk_fixed(d, bf, which, IntTag<2>()); break;
+                case 3: walk_fixed(d, bf, which, IntTag<3>()); break;
+                case 4: walk_fixed(d, bf, which, IntTag<4>()); break;
+                case 5: walk_fixed(d, bf, which, IntTag<5>()); break;
+                case 6: walk_fixed(d, bf, which, IntTag<6>()); break;
+                case 7: walk_fixed(d, bf, which, IntTag<7>()); break;
+                case 8: walk_fixed(d, bf, which, IntTag<8>()); break;
+                default: walk(d, bf, which, BoolTag<false>()); break; // rows of more than 32 hits
+                }
+            } else walk(d, bf, which, BoolTag<false>());
+        }
         else if (!HAS_K && (d.flags() & SELL_FAR)) walk(d, bf, which, BoolTag<true>());
         else if (d.flags() & SELL_FAR) far_tile(d); // with multiplicities: the generic row walk over the tile's block
         else slow_tile(d);
