@@ -35,6 +35,7 @@ struct mmg_sampler {
     std::vector<hipEvent_t> mark_pool;
     std::vector<int> mark_free;
     std::deque<std::pair<int, int>> marks;                 // {iterations completed when the event fires, index into mark_pool}
+    int fired_upto = 0;                                    // iterations known to have completed: the last mark seen fired (recycled or waited for)
     double acc_sample_ms = 0, acc_update_ms = 0;
     uint64_t acc_sample_n = 0, acc_update_n = 0;
 };
@@ -253,6 +254,7 @@ static int mark_iteration(mmg_sampler *s)
 {
     while (!s->marks.empty()) {
         if (hipEventQuery(s->mark_pool[s->marks.front().second]) != hipSuccess) { (void)hipGetLastError(); break; }
+        s->fired_upto = std::max(s->fired_upto, s->marks.front().first);
         s->mark_free.push_back(s->marks.front().second);
         s->marks.pop_front();
     }
@@ -391,13 +393,18 @@ extern "C" int mmg_sampler_wait_iterations(mmg_sampler *s, int n_done)
     if (!s) return fail(MMG_ERR_ARG, "NULL sampler");
     if (n_done < 0 || n_done > s->iter) return fail(MMG_ERR_ARG, "wait for iterations that were not enqueued");
     HIP_TRY(hipSetDevice(s->device));
-    // the first mark at or behind n_done; without one (n_done behind the last stored sample) the whole stream
+    // a mark that has fired covers it (marks are recycled as they fire: without this the fallback below would wait for the chunk the
+    // caller has just enqueued AHEAD -- the overlap this function exists for)
+    if (n_done <= s->fired_upto) return MMG_OK;
+    // the first mark at or behind n_done; without one (n_done behind the last mark: marks follow every 16th stored sample) the stream
     size_t k = 0;
     while (k < s->marks.size() && s->marks[k].first < n_done) ++k;
     if (k == s->marks.size()) {
-        if (n_done > 0) HIP_TRY(hipStreamSynchronize(s->cur));
+        HIP_TRY(hipStreamSynchronize(s->cur));
+        s->fired_upto = s->iter;
     } else {
         HIP_TRY(hipEventSynchronize(s->mark_pool[s->marks[k].second]));
+        s->fired_upto = std::max(s->fired_upto, s->marks[k].first);
         ++k;
     }
     for (size_t i = 0; i < k; ++i) { s->mark_free.push_back(s->marks.front().second); s->marks.pop_front(); }

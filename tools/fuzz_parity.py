@@ -12,8 +12,11 @@ def one_case(seed, gpu, orc, verbose=True):
     avg = float(rng.choice([1.5, 3, 8, 20, 45]))
     sort = bool(rng.integers(0, 4) != 0)
     far = float(rng.choice([0.0, 0.0, 0.03, 0.5]))      # rows with a hit anywhere in the transcriptome: far tiles
+    genes = int(rng.choice([0, 0, 0, 6, 24]))             # gene-block mode of the generator: a read's hits inside one gene ...
+    uni = bool(rng.integers(0, 5) == 0) and not genes
     p, _ = orc.synth_problem(R=R, T=T, avg_hits=avg, seed=int(rng.integers(1, 1 << 30)), sort=sort,
-                             uniform=bool(rng.integers(0, 5) == 0), far_fraction=far)
+                             uniform=uni, far_fraction=far, gene_size=genes,
+                             far_family=int(rng.choice([0, 2, 3])) if genes else 0)   # ... far hits to a paralogue family of 2 / 3 genes, or anywhere
     if rng.integers(0, 4) == 0:                          # hits of a row in arbitrary order: the canonical layout sorts them
         rp64 = p.row_ptr.astype(np.int64)
         rid = np.repeat(np.arange(p.m), np.diff(rp64))
@@ -42,6 +45,8 @@ def one_case(seed, gpu, orc, verbose=True):
     tx_order = None
     if rng.integers(0, 3) == 0:                          # device renumbering: random gene sizes over a random scatter
         tx_order = (rng.permutation(T).astype(np.uint64) // np.uint64(int(rng.integers(1, 9)))) << np.uint64(32)
+    elif genes:                                          # the CLI's keys for the generator's genes: gene << 32 | transcript (spec 7: the genes may be reordered)
+        tx_order = ((np.arange(T, dtype=np.uint64) // np.uint64(genes)) << np.uint64(32)) | np.arange(T, dtype=np.uint64)
     with gpu.options(**opts):
         mu0, uh = orc.start_values(pk)
         if rng.integers(0, 3) == 0: mu0[rng.integers(0, T, size=max(1, T // 20))] = 0.0
