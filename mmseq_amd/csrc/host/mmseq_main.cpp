@@ -892,8 +892,9 @@ int main(int argc, char **argv)
         if (stage.on) {
             mmg_problem_info inf;
             MMG_TRY(mmg_problem_info_get(prob, &inf));
-            fprintf(stderr, "[timing] sample kernel %d (2 sliced-ELL stream, 0 CSR tiles), %llu of %llu tiles on the register path, %.1f MB on the device\n",
-                    inf.sample_kernel, (unsigned long long)inf.fast_tiles, (unsigned long long)inf.n_tiles, inf.device_bytes / 1e6);
+            fprintf(stderr, "[timing] sample kernel %d (2 sliced-ELL stream, 0 CSR tiles), %llu of %llu tiles on the register path, %llu with far lists, %.1f MB on the device%s\n",
+                    inf.sample_kernel, (unsigned long long)inf.fast_tiles, (unsigned long long)inf.n_tiles, (unsigned long long)inf.far_tiles, inf.device_bytes / 1e6,
+                    inf.tx_renumbered == 3 ? "; the genes reordered by the gene-level hit graph (reads that also hit paralogues)" : "");
         }
     }
 
