@@ -13,8 +13,12 @@ HIP events bracket K1 and K2 on every --time-every-th step INSIDE the timed regi
 roofline (K1 = k_sample_sell, the dominant kernel; the same block for the chain-pair kernel and the EM kernel in `roofline_other`):
   bound        "hbm".  K1 is bound by the stream it reads: with the same stream served from the caches it runs 21 % faster
                (DESIGN.md section 4), and the instruction side (VALU issue) sits right behind it
-  traffic      HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes of this exact kernel build (profiles/pmc_counters.json,
-               written by tools/pmc_summary.py, stamped with a hash of the kernel sources and build flags; null if they changed since)
+  traffic      HBM bytes per launch of K1, measured IN THIS RUN at --gpus 1: two short child runs of this script under rocprofv3, one
+               per counter (FETCH_SIZE, WRITE_SIZE; --kernel-trace --pmc only), while this process idles behind its timed region
+               (roofline.traffic_source says so; --no-live-pmc, no rocprofv3 on PATH, or a failed pass: the committed passes of this
+               exact kernel build instead -- profiles/pmc_counters.json, written by tools/pmc_summary.py, stamped with a hash of the
+               kernel sources and build flags; null if they changed since).  The other counters (VALU, LDS, wave cycles) and the
+               chain-pair / EM blocks always come from the committed passes
   achieved     traffic / avg_launch_ms in GB/s;  peak 8000 GB/s (MI355X_MICROARCH.md);  frac = hbm_counter_frac = achieved / peak
   pattern_read_peak_gbs   what a pure read with K1's access pattern reaches on this part (tools/stream_bench.hip: 6.5-6.7 TB/s)
   algorithmic_x_peak      SURVEY 8(d)'s figure: bytes of the u32 CSR / time / 8 TB/s.  The kernel streams a 1.1 byte-per-hit encoding of
@@ -77,11 +81,56 @@ def pmc_entry(entry):
     return None
 
 
-def roofline_block(kernel_name, entry, t_s, launches, n_tiles, stream_bytes=None, algorithmic_bytes=None):
-    """The roofline object of one kernel: t_s = average launch duration in seconds (HIP events in this run), PMC figures from `entry`."""
+def live_traffic(args, kernel_substr="k_sample_sell<"):
+    """HBM bytes per launch of the dominant kernel measured IN THIS RUN: two child runs of this very script (same workload, 8 steps) under
+    rocprofv3, one per counter -- FETCH_SIZE and WRITE_SIZE in separate --kernel-trace --pmc passes, as MI355X_MICROARCH.md prescribes
+    (TCC slots: both do not fit one pass), FETCH doubled per its gfx950 correction, both in KiB.  PMC counters cannot be read from inside
+    a process; children can (started as child processes, program directly behind `--`).  None when rocprofv3 is missing or a pass fails:
+    the committed passes of the same kernel build (profiles/pmc_counters.json) then stand in, as before."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None                                       # no profiler here, or this process itself runs under one
+    got = {}
+    t0 = time.perf_counter()
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="mmseq_pmc_", dir="/tmp")
+        cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+               "--no-extra", "--no-cpu-baseline", "--no-live-pmc", "--steps", "8", "--warmup", "2", "--settle-iters", "0", "--rows", str(args.rows),
+               "--transcripts", str(args.transcripts), "--avg-hits", str(args.avg_hits), "--seed", str(args.seed)]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                        vals.append(float(row["Counter_Value"]))
+            if r.returncode != 0 or len(vals) < 4:
+                return None
+            got[ctr] = (sum(vals) / len(vals), len(vals))
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {"hbm_read_bytes_per_launch": 2 * 1024 * got["FETCH_SIZE"][0], "hbm_write_bytes_per_launch": 1024 * got["WRITE_SIZE"][0],
+            "launches": got["FETCH_SIZE"][1], "seconds": time.perf_counter() - t0,
+            "source": "this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, two child passes of bench.py over the same workload "
+                      "(KiB; FETCH doubled per MI355X_MICROARCH.md)"}
+
+
+def roofline_block(kernel_name, entry, t_s, launches, n_tiles, stream_bytes=None, algorithmic_bytes=None, live=None):
+    """The roofline object of one kernel: t_s = average launch duration in seconds (HIP events in this run), PMC figures from `entry`;
+    live: HBM bytes per launch measured in this run (live_traffic), which then take the place of the committed passes' bytes."""
     pmc = pmc_entry(entry)
     c = (pmc or {}).get("counters_per_launch", {})
     traffic = ((pmc["hbm_read_bytes_per_launch"] or 0) + (pmc["hbm_write_bytes_per_launch"] or 0)) if pmc and pmc.get("hbm_read_bytes_per_launch") else None
+    committed_traffic = traffic
+    if live:
+        traffic = live["hbm_read_bytes_per_launch"] + live["hbm_write_bytes_per_launch"]
     ach = traffic / t_s / 1e9 if traffic else None
     clk = c.get("GRBM_GUI_ACTIVE")
     # effective clock of the profiled pass: its GRBM_GUI_ACTIVE (summed over the 8 XCDs) / its own mean kernel duration
@@ -104,6 +153,10 @@ def roofline_block(kernel_name, entry, t_s, launches, n_tiles, stream_bytes=None
                                              if k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_INSTS_SMEM")}
                                             if c and n_tiles else None),
            "pmc_source": (pmc or {}).get("source")}
+    if live:
+        out["traffic_source"] = live["source"]
+        out["traffic_live_passes_s"] = live["seconds"]
+        out["traffic_committed_passes"] = committed_traffic
     if stream_bytes is not None:
         out["stream_bytes_per_launch"] = stream_bytes
         out["stream_frac_of_peak"] = stream_bytes / t_s / 1e9 / HBM_PEAK_GBS
@@ -353,6 +406,8 @@ def main():
     ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000, help="rows of the sample the CPU thread count is picked on")
     ap.add_argument("--cpu-iters", type=int, default=8, help="iterations of the CPU baseline on the full problem")
     ap.add_argument("--full-json", default="", help="also write the unabridged record (every field of every measurement) to this file")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not collect FETCH_SIZE / WRITE_SIZE of K1 in child runs under rocprofv3 "
+                    "(roofline.traffic then comes from the committed passes of the same kernel build)")
     args = ap.parse_args()
 
     import numpy as np
@@ -494,8 +549,12 @@ def main():
         # 1-GPU run on every GPU (k1_ms is rank 0's own launch time): the same counter entry applies.  A read shard is another problem
         # (fewer tiles per launch): no counter entry, the fraction then comes from the shard's own stream bytes (stream_frac_of_peak).
         entry = "k1_1chain" if C == 1 and args.mode == "chains" and (args.rows, args.transcripts, args.avg_hits) == (50_000_000, 200_000, 20.0) else "none"
+        # roofline.traffic measured in THIS run (1 GPU, 1 chain): two short child passes under rocprofv3 while this process idles
+        live = None
+        if world == 1 and C == 1 and args.mode == "chains" and not args.no_live_pmc and inf.sample_kernel == 2:
+            live = live_traffic(args)
         full_roof = roofline_block(kname + " (K1)", entry, k1_ms * 1e-3, tm["sample_launches"], inf.n_tiles,
-                                   stream_bytes=inf.stream_bytes, algorithmic_bytes=b_k1)
+                                   stream_bytes=inf.stream_bytes, algorithmic_bytes=b_k1, live=live)
         if full_roof["frac"] is None:
             # no counter pass of this exact launch: what the kernel must read (its stream) + the algorithmic mu / count bytes, over its time
             full_roof["traffic_is"] = "stream bytes + 12 n (no PMC pass of this launch shape)"
@@ -509,7 +568,7 @@ def main():
         full_roof["k_update_avg_launch_ms"] = k2_ms
         # the contract's six first, then one scalar per BASELINE config and side measurement (filled in below), then the detail
         roof = {k: full_roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms")}
-        for k in ("shard_balance", "rank_balance", "k1_ms_per_rank_max", "k1_ms_per_rank_mean", "traffic_is"):
+        for k in ("shard_balance", "rank_balance", "k1_ms_per_rank_max", "k1_ms_per_rank_mean", "traffic_is", "traffic_source", "traffic_live_passes_s", "traffic_committed_passes"):
             if k in full_roof:
                 roof[k] = full_roof[k]
         out = {

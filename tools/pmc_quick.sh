@@ -13,7 +13,7 @@ for L in "${LIBS[@]}"; do
   D=/tmp/pmcq_$(basename $L .so)
   rm -rf $D
   export MMSEQ_AMD_LIB=$REPO/$L
-  rocprofv3 --kernel-trace --pmc $CNT --output-format csv -d $D -- python3 $REPO/bench.py --no-extra --no-cpu-baseline --settle-iters 0 "$@" > /dev/null 2> $D.err
+  rocprofv3 --kernel-trace --pmc $CNT --output-format csv -d $D -- python3 $REPO/bench.py --no-extra --no-cpu-baseline --no-live-pmc --settle-iters 0 "$@" > /dev/null 2> $D.err
   python3 - "$D" "$SUB" "$L" <<'PY'
 import csv, glob, sys, collections
 d, sub, lib = sys.argv[1:4]

@@ -14,6 +14,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+case "$SCRIPT" in *bench.py) ARGS="$ARGS --no-live-pmc";; esac   # (bench.py's own counter passes are child runs under rocprofv3: not inside one)
 SHORT="$ARGS"
 case "$SCRIPT" in *bench.py) SHORT="$ARGS --steps 8 --warmup 2 --settle-iters 0";; esac
 rocprofv3 --kernel-trace --stats -d "$OUT/${TAG}_kt" -- python3 "$REPO/$SCRIPT" $ARGS > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_kt.err"
