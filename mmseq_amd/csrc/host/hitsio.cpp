@@ -1,7 +1,12 @@
 // hitsio.cpp -- see hitsio.hpp.  Written from the format description;
 // behaviour notes cite the reference lines they reproduce.
 #include "hitsio.hpp"
+#include "pinflate.hpp"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <chrono>
@@ -29,7 +34,8 @@ public:
         int c = std::fgetc(fp);
         if (c != EOF) std::ungetc(c, fp);
         compressed = (c == 0x78); // "lazy but sufficient" zlib sniff, src/hitsio.cpp:258
-        if (compressed) {
+        if (compressed) open_parallel(fileName);
+        if (compressed && !par) {
             std::memset(&zs, 0, sizeof zs);
             if (inflateInit(&zs) != Z_OK) { ok = false; return; }
             zinit = true;
@@ -43,8 +49,14 @@ public:
             worker.join();
         }
         if (zinit) inflateEnd(&zs);
+        if (par) {
+            delete par;
+            if (map_base) munmap((void *)map_base, map_len);
+            if (std::getenv("MMSEQ_TIMING"))
+                std::fprintf(stderr, "[timing] hits file: inflated by %d threads (host/pinflate.hpp); the reader waited for inflated data %.1f s\n", par_threads, t_reader_wait);
+        }
         if (fp) std::fclose(fp);
-        if (compressed && std::getenv("MMSEQ_TIMING"))
+        if (compressed && !map_base && std::getenv("MMSEQ_TIMING"))
             std::fprintf(stderr, "[timing] hits file: inflate thread busy %.1f s, waited for a free slab %.1f s; the reader waited for inflated data %.1f s\n",
                          t_inflate, t_inflate_wait, t_reader_wait);
     }
@@ -104,9 +116,55 @@ private:
     static constexpr int NSLAB = 256;
     static constexpr size_t SLAB = 1u << 20;
     struct Slab { std::vector<char> data; size_t len = 0; int state = 0; }; // 0 free, 1 filled, 2 being read
+    // A large compressed file of its own (not a pipe) is inflated by several threads: host/pinflate.hpp.  MMSEQ_INFLATE_THREADS (default:
+    // half the CPUs of the container's quota, at most 8; 1 = zlib on one thread as before), MMSEQ_INFLATE_CHUNK (compressed bytes per
+    // chunk, default 4 MB) and MMSEQ_INFLATE_MIN (smallest file that takes this path, default 8 MB) are for tests and measurements.
+    static long env_long(const char *name, long dflt)
+    {
+        const char *v = std::getenv(name);
+        return v && *v ? std::atol(v) : dflt;
+    }
+    static int default_inflate_threads()
+    {
+        long cpus = (long)std::thread::hardware_concurrency();
+        if (FILE *q = std::fopen("/sys/fs/cgroup/cpu.max", "r")) { // cgroup v2 quota: "max" or "<quota> <period>"
+            char a[32];
+            long per = 0;
+            if (std::fscanf(q, "%31s %ld", a, &per) == 2 && std::strcmp(a, "max") != 0 && per > 0) cpus = std::min(cpus, (std::atol(a) + per - 1) / per);
+            std::fclose(q);
+        }
+        return (int)std::max(1L, std::min(8L, cpus / 2));
+    }
+    void open_parallel(const std::string &fileName)
+    {
+        par_threads = (int)env_long("MMSEQ_INFLATE_THREADS", default_inflate_threads());
+        if (par_threads < 2) return;
+        struct stat st;
+        if (fstat(fileno(fp), &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < env_long("MMSEQ_INFLATE_MIN", 8L << 20)) return;
+        void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(fp), 0);
+        if (m == MAP_FAILED) return;
+        (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+        map_base = (const uint8_t *)m;
+        map_len = (size_t)st.st_size;
+        par = new pinflate::Stream(map_base, map_len, par_threads, (size_t)env_long("MMSEQ_INFLATE_CHUNK", 4L << 20));
+    }
     bool fill()
     {
         pos = len = 0;
+        if (par) {
+            const uint8_t *p = nullptr;
+            size_t n = 0;
+            const auto w0 = std::chrono::steady_clock::now();
+            const bool more = par->next(p, n);
+            t_reader_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+            if (!more) {
+                if (!par->error().empty()) { std::cerr << par->error() << "\n"; hits_die(); }
+                return false;
+            }
+            buf = (const char *)p;
+            len = n;
+            return true;
+        }
         if (!compressed) {
             len = std::fread(raw, 1, sizeof raw, fp);
             buf = raw;
@@ -181,6 +239,10 @@ private:
     std::condition_variable cv;
     std::thread worker;
     double t_inflate = 0.0, t_inflate_wait = 0.0, t_reader_wait = 0.0; // MMSEQ_TIMING: which of the two threads paces the reader
+    pinflate::Stream *par = nullptr;     // the parallel inflater over the mapped file, when it applies
+    const uint8_t *map_base = nullptr;
+    size_t map_len = 0;
+    int par_threads = 1;
 };
 
 // ---------------------------------------------------------------- output (plain or zlib level 1)

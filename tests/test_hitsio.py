@@ -116,3 +116,30 @@ def test_t2g_hits_gene_level_records(tmp_path):
         assert r.returncode == 0 and r.stdout == exp
     r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 1 and b"Usage: t2g_hits" in r.stderr
+
+
+def test_binary_hits_file_read_through_the_parallel_inflate(tmp_path):
+    """A binary hits file is ONE zlib stream (src/hitsio.cpp:127).  Large files are inflated by several threads (host/pinflate.hpp:
+    block finder, marker decode, window chain; tests/test_pinflate.py holds it to zlib); here the READER is forced onto that path for a
+    small file with chunks of a few hundred compressed bytes, and every tool must print what it prints on the one-thread zlib path --
+    records, header, gene-level records -- and reject a damaged file with zlib's message class."""
+    h = _dataset(4, n_t=60, n_reads=4000, long_ids=True)
+    p = tmp_path / "b.hits"
+    p.write_bytes(H.write_hits_binary(h))
+    forced = dict(os.environ, MMSEQ_INFLATE_THREADS="4", MMSEQ_INFLATE_CHUNK="700", MMSEQ_INFLATE_MIN="0", MMSEQ_TIMING="1")
+    plain = dict(os.environ, MMSEQ_INFLATE_THREADS="1")
+    for cmd in ("t", "header", "inspect"):
+        a = subprocess.run([TOOLS, cmd, str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=plain, check=True)
+        b = subprocess.run([TOOLS, cmd, str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=forced, check=True)
+        assert a.stdout == b.stdout and len(a.stdout) > 1000
+        assert b"inflated by 4 threads" in b.stderr and b"inflated by" not in a.stderr
+    assert subprocess.run([TOOLS, "t", str(p)], stdout=subprocess.PIPE, env=forced, check=True).stdout == H.write_hits_text(h)
+    exe = os.path.join(BIN_DIR, "t2g_hits")
+    assert subprocess.run([exe, str(p)], stdout=subprocess.PIPE, env=forced, check=True).stdout == subprocess.run([exe, str(p)], stdout=subprocess.PIPE, env=plain, check=True).stdout
+    bad = bytearray(p.read_bytes())
+    bad[len(bad) // 2] ^= 0xff
+    q = tmp_path / "bad.hits"
+    q.write_bytes(bytes(bad))
+    for env in (plain, forced):
+        r = subprocess.run([TOOLS, "t", str(q)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert r.returncode == 1 and b"Error decompressing hits file" in r.stderr
