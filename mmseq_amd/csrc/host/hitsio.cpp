@@ -101,6 +101,9 @@ public:
         }
         return true;
     }
+    // the bytes already inflated and not yet consumed, for parsers that work on the buffer itself; advance(n <= size) consumes
+    void span(const char *&p, size_t &n) { if (pos == len) (void)fill(); p = buf + pos; n = len - pos; }
+    void advance(size_t n) { pos += n; }
     bool readU32(uint32_t &v)
     {
         unsigned char b[4];
@@ -655,6 +658,59 @@ bool HitsfileReader::readReadMapRecordTranscriptIndices(std::vector<uint32_t> &o
         out[at + i] = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
     }
     countReadMapRecord = 0;
+    return true;
+}
+
+static_assert(__BYTE_ORDER__ == __ORDER_LITTLE_ENDIAN__, "readReadMapRecordsBulk copies the format's little-endian u32s as they are");
+bool HitsfileReader::readReadMapRecordsBulk(std::vector<uint32_t> &lens, std::vector<uint32_t> &idx, size_t max_records)
+{
+    const size_t n_header = headerTranscriptName.size();
+    for (size_t got = 0; got < max_records;) {
+        if (hitsfileSchema == 1) {
+            // fast path: records that lie inside the inflated buffer are parsed in place (src/hitsio.cpp:413-439: the name line -- empty
+            // when delta-coded: count byte or 0xFF + u32, middle part, count byte --, u32 count, count x u32 indices, little-endian)
+            const char *p;
+            size_t avail;
+            src->span(p, avail);
+            const char *q = p, *const e = p + avail;
+            size_t at = idx.size();
+            while (got < max_records) {
+                const char *r = q;
+                const char *nl = (const char *)std::memchr(r, '\n', (size_t)(e - r));
+                if (!nl) break;
+                if (nl == r) { // delta-coded name
+                    ++r;
+                    auto small = [&]() { if (r >= e) return false; const unsigned char b = (unsigned char)*r++; if (b == 255) { if (e - r < 4) return false; r += 4; } return true; };
+                    if (!small()) break;
+                    nl = (const char *)std::memchr(r, '\n', (size_t)(e - r));
+                    if (!nl) break;
+                    r = nl + 1;
+                    if (!small()) break;
+                } else r = nl + 1;
+                if (e - r < 4) break;
+                uint32_t cnt;
+                std::memcpy(&cnt, r, 4); // (little-endian host: the format's byte order)
+                r += 4;
+                if (cnt > n_header) { std::cerr << "Hits file looks malformed.\n"; hits_die(); }
+                if ((size_t)(e - r) < (size_t)cnt * 4) break;
+                if (idx.size() < at + cnt) idx.resize(std::max(idx.size() * 2, at + cnt + 1024));
+                std::memcpy(idx.data() + at, r, (size_t)cnt * 4);
+                at += cnt;
+                q = r + (size_t)cnt * 4;
+                lens.push_back(cnt);
+                ++got;
+            }
+            idx.resize(at);
+            src->advance((size_t)(q - p));
+            if (got >= max_records) return true;
+        }
+        // a record that straddles the end of the buffer (or the text schema): one record through the byte-wise reader
+        if (!skipReadMapRecordReadID()) return false;
+        const size_t before = idx.size();
+        readReadMapRecordTranscriptIndices(idx);
+        lens.push_back((uint32_t)(idx.size() - before));
+        ++got;
+    }
     return true;
 }
 

@@ -88,6 +88,10 @@ public:
     // appended to `out`.
     bool skipReadMapRecordReadID();
     bool readReadMapRecordTranscriptIndices(std::vector<uint32_t> &out);
+    // Additive: up to max_records whole records at once -- record r contributes len[r] indices to idx, both appended.  What the two
+    // calls above do record by record, but parsed straight from the inflated buffer while a record lies inside it (binary schema).
+    // Returns false when the file is exhausted (records read before that are in len / idx).
+    bool readReadMapRecordsBulk(std::vector<uint32_t> &len, std::vector<uint32_t> &idx, size_t max_records);
     int schema() const { return hitsfileSchema; }
 
 private:

@@ -2,6 +2,7 @@
 // built purely on hitsio).  Usage: hitstools inspect|header|t|b hits_file      (output on stdout)
 #include <cstdlib>
 #include <iostream>
+#include <vector>
 
 #include "hitsio.hpp"
 
@@ -19,6 +20,29 @@ int main(int argc, char **argv)
 {
     if (argc != 3) { usage(); return 1; }
     const std::string cmd = argv[1];
+    if (cmd == "hitsets") {
+        // (additive, for tests: the records as the mmseq CLI reads them -- HitsfileReader::readReadMapRecordsBulk, no read names -- one
+        // line per read: its transcripts' header indices)
+        HitsfileReader reader(argv[2]);
+        std::vector<std::string> names;
+        std::map<std::string, double> efflen;
+        std::map<std::string, int> truelen;
+        std::map<std::string, std::vector<std::string>> genes;
+        std::vector<std::vector<std::string>> identical;
+        reader.readHeader(&names, &efflen, &truelen, &genes, &identical);
+        std::vector<uint32_t> len, idx;
+        for (bool more = true; more;) {
+            len.clear(); idx.clear();
+            more = reader.readReadMapRecordsBulk(len, idx, 1000);
+            size_t at = 0;
+            for (uint32_t l : len) {
+                for (uint32_t j = 0; j < l; ++j) std::cout << (j ? " " : "") << idx[at + j];
+                std::cout << "\n";
+                at += l;
+            }
+        }
+        return 0;
+    }
     if (cmd != "inspect" && cmd != "header" && cmd != "t" && cmd != "b") { usage(); return 1; }
     HitsfileReader reader(argv[2]);
     HitsfileWriter writer(cmd == "b" ? "b" : "t");

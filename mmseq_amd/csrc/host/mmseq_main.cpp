@@ -512,6 +512,19 @@ int main(int argc, char **argv)
         }
         vector<uint64_t> table(table_size, EMPTY);
         vector<uint64_t> row_hash;
+        {
+            // The arrays of the hit sets grow to GIGABYTES at 50 M reads (4 GB of column indices): grown by doubling they are copied
+            // 8 GB worth and fault in twice their final pages -- on the thread every other stage waits for.  Address space is
+            // reserved from the file's size instead (a binary record of c hits is >= 16 compressed bytes and inflates about 2.5 x;
+            // untouched pages cost nothing); a reservation the system refuses is simply not made.
+            struct stat st_;
+            const uint64_t fsz = stat(hits_file.c_str(), &st_) == 0 ? (uint64_t)st_.st_size : 0;
+            try {
+                col_idx.reserve((size_t)min<uint64_t>(fsz * 3 / 4, 3ull << 30));
+                const size_t rows = (size_t)min<uint64_t>(fsz / 24, 1ull << 28);
+                row_ptr.reserve(rows + 1); row_hash.reserve(rows); k.reserve(rows);
+            } catch (const std::bad_alloc &) {}
+        }
         auto grow = [&]() {
             vector<uint64_t> bigger(table.size() * 2, EMPTY);
             const size_t mask = bigger.size() - 1;
@@ -524,12 +537,14 @@ int main(int argc, char **argv)
         };
         // Four stages over a ring of blocks of reads, each stage its own thread(s): (1) the reader -- inflate (a thread of its own inside
         // hitsio) + record decode, strictly sequential (src/hitsio.hpp:77-79); (2) first-seen transcript numbering (:399-408),
-        // sequential as well; (3) two threads, alternate blocks: every read's hit set sorted and freed of repeats, its hash -- the
+        // sequential as well; (3) NSORT threads, alternate blocks: every read's hit set sorted and freed of repeats, its hash -- the
         // longest stage at 50 M reads; (4) this thread: the hit-set table.
         struct Block { vector<uint32_t> len, idx, dups; vector<uint64_t> hash; bool last = false; };
-        constexpr int NB = 8, NSORT = 2;
+        // (round 5: with the file inflated by several threads and the records parsed in place, the two sorters of round 4 became the
+        // pace of the pipeline -- reader and numberer both waited 4.7 s of a 6.3 s read: four, over a ring twice as deep)
+        constexpr int NB = 16, NSORT = 4;
         Block blocks[NB];
-        int state[NB] = {0, 0, 0, 0, 0, 0, 0, 0}; // 0: free for the reader, 1: decoded, 2: numbered, 3: prepared for the table
+        int state[NB] = {0}; // 0: free for the reader, 1: decoded, 2: numbered, 3: prepared for the table
         mutex mtx;
         condition_variable cv;
         atomic<uint32_t> n_seen{0}; // transcripts numbered so far (progress line only)
@@ -546,11 +561,7 @@ int main(int argc, char **argv)
                 wait_for(b, 0, 0);
                 Block &B = blocks[b];
                 B.len.clear(); B.idx.clear();
-                while (B.len.size() < 65536 && (more = hitsfileReader.skipReadMapRecordReadID())) { // the read names are not used (:395-441)
-                    const size_t before = B.idx.size();
-                    hitsfileReader.readReadMapRecordTranscriptIndices(B.idx);
-                    B.len.push_back((uint32_t)(B.idx.size() - before));
-                }
+                more = hitsfileReader.readReadMapRecordsBulk(B.len, B.idx, 65536); // the read names are not used (:395-441)
                 B.last = !more;
                 set_state(b, 1);
             }

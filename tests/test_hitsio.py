@@ -143,3 +143,19 @@ def test_binary_hits_file_read_through_the_parallel_inflate(tmp_path):
     for env in (plain, forced):
         r = subprocess.run([TOOLS, "t", str(q)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
         assert r.returncode == 1 and b"Error decompressing hits file" in r.stderr
+
+
+@pytest.mark.parametrize("env", [{"MMSEQ_INFLATE_THREADS": "1"}, {"MMSEQ_INFLATE_THREADS": "3", "MMSEQ_INFLATE_CHUNK": "500", "MMSEQ_INFLATE_MIN": "0"}])
+def test_bulk_record_reader_gives_the_hit_sets_of_the_file(tmp_path, env):
+    """HitsfileReader::readReadMapRecordsBulk -- what the mmseq CLI reads a file with: whole records parsed in place in the inflated
+    buffer, the byte-wise reader for records that straddle a buffer end (with 500-byte inflate chunks: most of them) -- against the
+    Python restatement of the format, both schemas, plain and delta-coded names incl. the 0xFF + u32 escape."""
+    for seed, long_ids in ((5, False), (6, True)):
+        h = _dataset(seed, n_t=50, n_reads=3000, long_ids=long_ids)
+        index = {n: i for i, n in enumerate(h.names)}
+        want = "".join(" ".join(str(index[t]) for t in ts) + "\n" for _, ts in h.reads).encode()
+        for data in (H.write_hits_binary(h), H.write_hits_text(h)):
+            p = tmp_path / "in.hits"
+            p.write_bytes(data)
+            r = subprocess.run([TOOLS, "hitsets", str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+            assert r.returncode == 0 and r.stdout == want
