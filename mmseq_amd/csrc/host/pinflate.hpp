@@ -401,6 +401,17 @@ public:
         }
     }
     const std::string &error() const { return err; }
+    // the most compressed bytes ONE decode has to cover: the longest stretch between two candidate starts (or to the end).  A stream of
+    // stored / fixed blocks has no candidates at all: one thread would decode all of it into 16-bit symbols -- callers with a plain
+    // zlib path should take that instead when this is large
+    uint64_t longest_stretch_bytes() const
+    {
+        uint64_t last = 16, worst = 0;
+        for (size_t i = 1; i < starts.size(); ++i)
+            if (starts[i] != ~0ull) { worst = std::max(worst, starts[i] - last); last = starts[i]; }
+        worst = std::max(worst, (uint64_t)(end - base) * 8 - last);
+        return worst / 8;
+    }
     // chunks whose decode was used / chunks dropped (no candidate, or a candidate that was not a block boundary)
     void stats(size_t &accepted, size_t &dropped)
     {
