@@ -399,3 +399,28 @@ def test_two_devices_give_the_output_of_one(tmp_path, gpu):
         a = gzip.open(outs["one"] + ext, "rb").read()
         assert a == gzip.open(outs["two"] + ext, "rb").read(), ext
         assert a == gzip.open(outs["two_em1"] + ext, "rb").read(), ext
+
+
+@pytest.mark.gpu
+def test_ingest_through_the_parallel_inflate_writes_the_same_files(tmp_path, gpu):
+    """Round 5's ingest: the hits file's zlib stream inflated by several threads (host/pinflate.hpp) and the records parsed in place
+    (HitsfileReader::readReadMapRecordsBulk).  Forced here on a small file -- inflate chunks of 600 bytes, so that most records
+    straddle a buffer end -- every output must be byte for byte what the one-thread zlib path writes (.k and .M show the row order,
+    src/mmseq.cpp:412-418; the tables and traces everything else)."""
+    h = dataset(seed=11, n_t=80, n_reads=20000)
+    p = tmp_path / "in.hits"
+    p.write_bytes(H.write_hits_binary(h))
+    outs = {}
+    for tag, env in (("plain", {"MMSEQ_INFLATE_THREADS": "1"}),
+                     ("parallel", {"MMSEQ_INFLATE_THREADS": "4", "MMSEQ_INFLATE_CHUNK": "600", "MMSEQ_INFLATE_MIN": "0", "MMSEQ_TIMING": "1"})):
+        out = str(tmp_path / tag)
+        r = run(["-gibbs_iter", "1024", "-debug", str(p), out], env=dict(os.environ, **env), timeout=300)
+        assert r.returncode == 0, r.stderr.decode()
+        if tag == "parallel":
+            assert b"inflated by 4 threads" in r.stderr
+        outs[tag] = {f[len(tag):]: open(os.path.join(str(tmp_path), f), "rb").read() for f in sorted(os.listdir(str(tmp_path))) if f.startswith(tag + ".")}
+    assert set(outs["plain"]) == set(outs["parallel"]) and ".k" in outs["plain"] and ".M" in outs["plain"] and ".mmseq" in outs["plain"]
+    for name in outs["plain"]:
+        assert outs["plain"][name] == outs["parallel"][name], name
+    g = H.ingest(h)                                      # and both are what the Python restatement of the ingest expects (:682-684)
+    assert outs["parallel"][".k"].decode().split() == [str(v) for v in g["k"]]
