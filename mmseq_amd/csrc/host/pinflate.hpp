@@ -289,7 +289,10 @@ static inline void decode_chunk(const uint8_t *base, const uint8_t *end, Chunk &
             for (;;) {
                 if (o + 320 > cap) grow(320);
                 // one refill serves a whole literal / length + distance group: 15 + 5 + 15 + 13 bits at most
-                if (in.cnt < 48) in.refill();
+                if (in.cnt < 48) {
+                    in.refill();
+                    if (in.over) return fail(); // (a truncated stream: the zero bits behind its end would decode as symbols for ever)
+                }
                 int s;
                 {
                     const uint16_t e = L->fast[in.peek(11)];
