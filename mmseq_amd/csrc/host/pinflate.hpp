@@ -223,6 +223,7 @@ struct Chunk {
     uint64_t end_bit = 0;             // where it ended (a block boundary, or the end of the final block)
     bool final_seen = false;          // its decode reached the end of the stream's final block
     bool failed = false;              // invalid data met (a false candidate, or a damaged stream)
+    bool too_big = false;             // ... or more symbols than one chunk may hold
     uint16_t *sym_buf = nullptr;      // decoded symbols (malloc): byte, or 0x8000 | window position
     size_t sym_len = 0;
     std::vector<uint8_t> window_in;   // the 32 KB before it (filled in file order)
@@ -257,8 +258,13 @@ static inline void decode_chunk(const uint8_t *base, const uint8_t *end, Chunk &
     size_t cap = 1u << 20, o = 0;
     if (first_target < starts.size() && starts[first_target] != ~0ull) cap = std::max<size_t>(cap, (size_t)((starts[first_target] - c.start_bit) / 8) * 3);
     uint16_t *out = (uint16_t *)std::malloc(cap * 2);
+    // (a chunk is held in memory whole, as 16-bit symbols: one that inflates beyond MAX_SYMBOLS -- deflate reaches 1032 : 1 on runs of one
+    // byte -- is refused rather than allowed to take the machine's memory; zlib on one thread streams such a file through fixed buffers)
+    constexpr size_t MAX_SYMBOLS = (size_t)1 << 30;
+    bool too_big = false;
     auto grow = [&](size_t need) {
         while (o + need > cap) cap *= 2;
+        if (cap > MAX_SYMBOLS * 2) { too_big = true; cap = o + need + 1024; }
         out = (uint16_t *)std::realloc(out, cap * 2);
     };
     auto finish = [&]() { c.sym_buf = out; c.sym_len = o; c.end_bit = in.bitpos(); };
@@ -275,7 +281,7 @@ static inline void decode_chunk(const uint8_t *base, const uint8_t *end, Chunk &
             in.drop(in.cnt & 7); // to the byte boundary
             const uint32_t len = in.take(16), nlen = in.take(16);
             if (in.over || (len ^ 0xffffu) != nlen) return fail();
-            if (o + len + 320 > cap) grow(len + 320);
+            if (o + len + 320 > cap) { grow(len + 320); if (too_big) { c.too_big = true; return fail(); } }
             for (uint32_t k = 0; k < len; ++k) out[o++] = (uint16_t)in.take(8);
             if (in.over) return fail();
         } else if (btype == 3) return fail();
@@ -287,7 +293,7 @@ static inline void decode_chunk(const uint8_t *base, const uint8_t *end, Chunk &
                 L = &lit; D = &dist;
             }
             for (;;) {
-                if (o + 320 > cap) grow(320);
+                if (o + 320 > cap) { grow(320); if (too_big) { c.too_big = true; return fail(); } }
                 // one refill serves a whole literal / length + distance group: 15 + 5 + 15 + 13 bits at most
                 if (in.cnt < 48) {
                     in.refill();
@@ -444,6 +450,7 @@ private:
             }
             if (c.state != 2) return;       // not decoded yet
             if (c.start_bit != expect_bit) return fail("inflate: lost the block chain (internal error)");
+            if (c.failed && c.too_big) return fail("Error decompressing hits file (a stretch of the deflate stream inflates to more than 2 GB: set MMSEQ_INFLATE_THREADS=1).");
             if (c.failed) return fail("Error decompressing hits file (invalid deflate data).");
             c.window_in = window;           // (chunk 0: zeros, never referenced)
             // the window behind it: its last 32 K symbols over the window before it

@@ -113,3 +113,15 @@ def test_parallel_inflate_rejects_what_zlib_rejects(tmp_path):
                 assert rc == 0 and got == zlib.decompress(bytes(bad)), what
             else:
                 assert rc == 2 and err.strip(), (what, threads, chunk, rc)
+
+
+def test_parallel_inflate_on_streams_cut_anywhere(tmp_path):
+    """A truncated stream must end in an error wherever it is cut (the bits behind the end read as zeros, which decode as symbols: the
+    first version decoded them for ever -- found by tools/pinflate_fuzz.py)."""
+    rng = np.random.default_rng(9)
+    for name in ("hits", "text", "zeros"):
+        comp = zlib.compress(PAYLOADS[name], 1)
+        for cut in [2, 3, 7, len(comp) - 1, len(comp) - 4, len(comp) - 5] + [int(x) for x in rng.integers(8, len(comp) - 6, size=12)]:
+            for threads, chunk in ((2, 150000), (5, 900)):
+                rc, got, err = run(tmp_path, comp[:cut], threads, chunk)
+                assert rc == 2 and err.strip(), (name, cut, threads, chunk, rc)
