@@ -103,7 +103,7 @@ def live_traffic(args, kernel_substr="k_sample_sell<"):
                "--no-extra", "--no-cpu-baseline", "--no-live-pmc", "--steps", "8", "--warmup", "2", "--settle-iters", "0", "--rows", str(args.rows),
                "--transcripts", str(args.transcripts), "--avg-hits", str(args.avg_hits), "--seed", str(args.seed)]
         try:
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=150)
             vals = []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
