@@ -65,7 +65,7 @@ struct mmg_problem {
     int grid_sample = 1;
     uint64_t *d_colcnt = nullptr;               // hits per transcript, for the EM scale words (lazy)
     bool order_derived = false;                 // the renumbering came from the hit graph (order.hip), not from the caller's tx_order
-    bool k1_fixed_walk = false;    // the k = 1 sample kernel's straight-line instantiation (short rows: fewer than 4 groups per register-path tile on average)
+    bool k1_fixed_walk = false;    // the k = 1 sample kernel's straight-line instantiation (fewer than 5 groups per register-path tile on average)
     bool groups_reordered = false; // tx_order given and the library reordered its groups (spec version 7)
     bool renumbered() const { return !h_int_of_ext.empty(); }
 };

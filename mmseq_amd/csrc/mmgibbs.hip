@@ -323,7 +323,7 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
     p->n_fast_tiles = n_fast;
     p->n_far_tiles = n_far;
     p->padded_slots = slots;
-    p->k1_fixed_walk = n_fast > 0 && slots < 4 * 256 * n_fast;
+    p->k1_fixed_walk = n_fast > 0 && slots < 5 * 256 * n_fast; // fewer than 5 groups per register-path tile on average (sell_kernels.h: FIXW)
     const size_t alloc = p->sell_bytes + 64 + 8 * 256; // head room: tiles without a block prefetch the head of the stream
     HIP_TRY(hipMalloc((void **)&p->d_sell, alloc));
     HIP_TRY(hipMemset(p->d_sell, 0, alloc));

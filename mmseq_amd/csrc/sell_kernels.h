@@ -166,8 +166,10 @@ struct RowViewFarTile {
 // travel with the block's prefetch, and the first far weight is gathered while the window part is walked.  Without it a far tile is
 // three dependent memory round trips in the middle of its walk (count -> transcript id -> weight): 10 x a register-path tile.
 // FIXW: register-path tiles of at most 8 groups take straight-line code per group count (walk_fixed) -- the instantiation for problems
-// of SHORT rows (fewer than 4 groups per tile on average: BASELINE configs[1], 8 hits per read, K1 -5 %); at 20 hits per read the
-// stream bounds the kernel and the generic walk is 0.7 % ahead (less code), so the host picks per problem (mmg_problem::k1_fixed_walk)
+// of fewer than 5 groups per tile on average.  Same-box A/B of K1, generic -> straight-line: 5 M reads x 8 hits (BASELINE configs[1])
+// 0.0258 -> 0.0246 ms; 20 M x 12 hits 0.0792 -> 0.0762; 50 M x 16 hits 0.1859 -> 0.1816; at 50 M x 20 hits (5.4 groups per tile: the
+// headline) the stream bounds the kernel and the generic walk is 0.4-0.7 % ahead (0.2254 vs 0.2264): the host picks per problem
+// (mmg_problem::k1_fixed_walk)
 template <typename IdxT, bool HAS_K, int NGC, int REP = 1, bool FARPF = false, bool FIXW = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : (FARPF ? 6 : 7), HAS_K ? 5 : (FARPF ? 6 : 7)))) void k_sample_sell(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
                                                     const uint32_t *__restrict__ kmult, const SellTile *__restrict__ tiles, const uint64_t *__restrict__ chunk_tile,
