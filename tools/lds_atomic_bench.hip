@@ -8,7 +8,8 @@
 #include <cmath>
 #define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("%s: %s\n",#x,hipGetErrorString(e)); exit(1);} }while(0)
 
-template <int MODE> // 0: ds_add_u64 x1, 1: ds_add_u64 x2 (two arrays), 2: ds_add_u32, 3: ds_read_b64 gather, 4: ds_max_i32
+template <int MODE> // 0: ds_add_u64 x1, 1: ds_add_u64 x2 (two arrays), 2: ds_add_u32, 3: ds_read_b64 gather, 4: ds_max_i32,
+                    // 5: ds_add_rtn_u64 + carry test, 6: the EM mix (b64 gather, b32 read, 2 adds), 7: the mix with ONE returned add
 __global__ __launch_bounds__(64) void k(const uint16_t *__restrict__ idx, int per_lane, uint64_t *out)
 {
     __shared__ uint64_t a[257], b[257];
@@ -27,6 +28,13 @@ __global__ __launch_bounds__(64) void k(const uint16_t *__restrict__ idx, int pe
             if (MODE == 2) atomicAdd(&c[o[q]], 1u);
             if (MODE == 3) acc += a[o[q]];
             if (MODE == 4) atomicMax((int *)&c[o[q]], (int)j);
+            if (MODE == 5 || MODE == 7) { // one returned add; the carry out of the 64 bits goes to the second array (rare)
+                const uint64_t y = 0x0123456789abcdefull + o[q];
+                const uint64_t old = atomicAdd((unsigned long long *)&a[o[q]], (unsigned long long)y);
+                if (old + y < y) atomicAdd((unsigned long long *)&b[o[q]], 1ull);
+            }
+            if (MODE == 6 || MODE == 7) acc += a[o[q]] + c[o[q]];     // the gather and the scale word of an EM hit
+            if (MODE == 6) { atomicAdd((unsigned long long *)&a[o[q]], 3ull); atomicAdd((unsigned long long *)&b[o[q]], 5ull); }
         }
     }
     __syncthreads();
@@ -55,8 +63,8 @@ int main()
         }
         if (ptn == 1) for (size_t i = 0; i < n; ++i) h[i] = (uint16_t)(((i % per_lane) * 13 + (i / ((size_t)per_lane * 64))) & 255);
         CK(hipMemcpy(d, h.data(), n * 2, hipMemcpyHostToDevice));
-        const char *names[] = {"ds_add_u64", "2 x ds_add_u64", "ds_add_u32", "ds_read_b64 gather", "ds_max_i32"};
-        for (int m = 0; m < 5; ++m) {
+        const char *names[] = {"ds_add_u64", "2 x ds_add_u64", "ds_add_u32", "ds_read_b64 gather", "ds_max_i32", "ds_add_rtn_u64+carry", "EM mix, 2 adds", "EM mix, 1 rtn add"};
+        for (int m = 0; m < 8; ++m) {
             hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
             float best = 1e9;
             for (int rep = 0; rep < 4; ++rep) {
@@ -66,6 +74,9 @@ int main()
                 if (m == 2) hipLaunchKernelGGL(k<2>, dim3(grid), dim3(64), 0, 0, d, per_lane, out);
                 if (m == 3) hipLaunchKernelGGL(k<3>, dim3(grid), dim3(64), 0, 0, d, per_lane, out);
                 if (m == 4) hipLaunchKernelGGL(k<4>, dim3(grid), dim3(64), 0, 0, d, per_lane, out);
+                if (m == 5) hipLaunchKernelGGL(k<5>, dim3(grid), dim3(64), 0, 0, d, per_lane, out);
+                if (m == 6) hipLaunchKernelGGL(k<6>, dim3(grid), dim3(64), 0, 0, d, per_lane, out);
+                if (m == 7) hipLaunchKernelGGL(k<7>, dim3(grid), dim3(64), 0, 0, d, per_lane, out);
                 CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
             }
