@@ -104,6 +104,15 @@ struct CliOption {
 // the background writer of .k / .M (if any) finishes its files before the process leaves on a device error: the reference has
 // written both by then (src/mmseq.cpp:682-695), and exit() must not run under a thread that is still formatting
 static std::thread *g_background_writer = nullptr;
+// the thread that brings the HIP runtime up while the file is read: exit() under a thread that is still INSIDE the runtime's
+// initialisation tears the runtime down under its feet (found by tools/hitsio_fuzz.py: 7 of 800 runs on damaged headers ended in the
+// sanitizer's allocator instead of with exit code 1) -- every exit of the main thread waits for it
+static std::thread *g_device_warmup = nullptr;
+[[noreturn]] static void leave(int code)
+{
+    if (g_device_warmup && g_device_warmup->joinable()) g_device_warmup->join();
+    exit(code);
+}
 // Worker threads (the trace writers and their fetchers) never call exit(): exit() runs the atexit handlers and the HIP / RCCL
 // teardown under the main thread's feet, and two workers failing together would both join the background writer.  A worker RECORDS
 // its error (first one wins) and returns; the main thread sees the flag, stops the workers (g_stop_workers: wakes them, joins them)
@@ -125,7 +134,7 @@ static bool worker_failed(int rc, const char *what)
     cerr << "Error: " << msg << endl;
     if (g_stop_workers) { auto f = g_stop_workers; g_stop_workers = nullptr; f(); }
     if (g_background_writer && g_background_writer->joinable()) g_background_writer->join();
-    exit(1);
+    leave(1);
 }
 #define MMG_TRY(expr)                                                                     \
     do {                                                                                  \
@@ -449,7 +458,8 @@ int main(int argc, char **argv)
         uint32_t out[6];
         (void)mmg_selftest_philox(device, ctr, key, out);
     });
-    struct WarmupJoiner { std::thread &t; ~WarmupJoiner() { if (t.joinable()) t.join(); } } device_warmup_join{device_warmup};
+    g_device_warmup = &device_warmup;
+    struct WarmupJoiner { std::thread &t; ~WarmupJoiner() { if (t.joinable()) t.join(); g_device_warmup = nullptr; } } device_warmup_join{device_warmup};
 
     // ---- header (src/mmseq.cpp:332-379)
     map<string, double> sidLen;
@@ -466,7 +476,7 @@ int main(int argc, char **argv)
             for (auto &t : g.second) {
                 if (transcript2gene.count(t) > 0) {
                     cerr << "Error: transcripts must be nested within genes in GeneIsoforms metadata.\n";
-                    exit(1);
+                    leave(1);
                 }
                 transcriptListGI.push_back(t);
                 transcript2gene[t] = g.first;
@@ -476,16 +486,16 @@ int main(int argc, char **argv)
         sort(b.begin(), b.end());
         if ((size_t)(unique(a.begin(), a.end()) - a.begin()) != transcriptList.size()) {
             cerr << "Error: duplicate transcripts in @TranscriptMetaData entries.\n";
-            exit(1);
+            leave(1);
         }
         if ((size_t)(unique(b.begin(), b.end()) - b.begin()) != transcriptListGI.size()) {
             cerr << "Error: duplicate transcripts in @GeneIsoforms entries.\n";
-            exit(1);
+            leave(1);
         }
         for (auto &t : transcriptList)
             if (transcript2gene.count(t) == 0) {
                 cerr << "Error: " << t << " does not belong to a gene in the @GeneIsoforms header entries.\n";
-                exit(1);
+                leave(1);
             }
     }
     const size_t nHeader = transcriptList.size();
@@ -682,7 +692,7 @@ int main(int argc, char **argv)
     }
     const uint32_t n = (uint32_t)obs2hdr.size();
     const uint64_t m = k.size();
-    if (n == 0 || m == 0) { cerr << "Error: no reads with transcript hits found in the hits file.\n"; exit(1); }
+    if (n == 0 || m == 0) { cerr << "Error: no reads with transcript hits found in the hits file.\n"; leave(1); }
     auto sid = [&](uint32_t t) -> const string & { return transcriptList[obs2hdr[t]]; };
     auto obs_of = [&](const string &name) -> int32_t { // sidIndex lookup by name
         static map<string, int32_t> cache;
@@ -695,9 +705,9 @@ int main(int argc, char **argv)
     // ---- l[t] (src/mmseq.cpp:593-608)
     vector<double> l(n);
     for (uint32_t t = 0; t < n; t++) {
-        if (sidLen.count(sid(t)) == 0) { cerr << "Error: transcript '" << sid(t) << "' has no length.\n"; exit(1); }
+        if (sidLen.count(sid(t)) == 0) { cerr << "Error: transcript '" << sid(t) << "' has no length.\n"; leave(1); }
         l[t] = (double)sidLen[sid(t)] * (double)numbermappedreads / 1000000000.0;
-        if (l[t] <= 0) { cerr << "Error: transcript '" << sid(t) << "' has a length of zero.\n"; exit(1); }
+        if (l[t] <= 0) { cerr << "Error: transcript '" << sid(t) << "' has a length of zero.\n"; leave(1); }
     }
 
     // ---- start values and unique hits (src/mmseq.cpp:610-638) come from the device once the problem is there
