@@ -64,10 +64,23 @@ int main(int argc, char **argv)
     writer.writeHeader();
     if (cmd != "header") {
         std::string id, tid;
-        while (reader.readReadMapRecordReadID(id)) {
-            writer.addReadMapRecord(id);
-            while (reader.readReadMapRecordTranscriptID(tid)) writer.addTranscriptToReadMapRecord(tid);
-            writer.writeReadMapRecord();
+        if (reader.schema() == 1) {
+            // a binary file stores header indices, and the writer's index is the order of the addTranscriptMetaData calls above --
+            // the header's: the records pass through without a name lookup per hit (10^9 of them in a 50 M-read file)
+            std::vector<uint32_t> idx;
+            while (reader.readReadMapRecordReadID(id)) {
+                writer.addReadMapRecord(id);
+                idx.clear();
+                reader.readReadMapRecordTranscriptIndices(idx);
+                for (uint32_t i : idx) writer.addTranscriptIndexToReadMapRecord(i);
+                writer.writeReadMapRecord();
+            }
+        } else {
+            while (reader.readReadMapRecordReadID(id)) {
+                writer.addReadMapRecord(id);
+                while (reader.readReadMapRecordTranscriptID(tid)) writer.addTranscriptToReadMapRecord(tid);
+                writer.writeReadMapRecord();
+            }
         }
     }
     writer.close();
