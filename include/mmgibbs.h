@@ -95,7 +95,10 @@ typedef struct mmg_sampler mmg_sampler; /* chains' state: mu, counts, trace, mom
 /* Host description of the sparse problem: the reference's boolMat M (m x n), vector<int> k
  * and vector<double> l  (src/mmseq.cpp:117, :385, :593-608).  Rows are hit sets (or single
  * reads, k == NULL => all 1), columns the observed transcripts in first-seen order (:403);
- * within a row columns ascend (:412). */
+ * within a row columns ascend (:412) -- the canonical layout sorts them itself, any order may be passed.
+ * A column that occurs twice in a row counts twice (weight and pick): the reference's boolean matrix
+ * cannot hold that case, its reader drops the second occurrence (:404-409) and so does the CLI of this
+ * build; device and oracle agree on the list semantics (tools/fuzz_parity.py, `dups`). */
 typedef struct mmg_problem_desc {
     uint64_t m;              /* rows                                                    */
     uint32_t n;              /* columns (observed transcripts)                          */

@@ -21,6 +21,13 @@ def one_case(seed, gpu, orc, verbose=True):
         rp64 = p.row_ptr.astype(np.int64)
         rid = np.repeat(np.arange(p.m), np.diff(rp64))
         p.col_idx[:] = p.col_idx[np.lexsort((rng.random(p.col_idx.size), rid))]
+    dups = bool(rng.integers(0, 5) == 0)                 # a transcript twice in a row (the ABI takes rows as lists: its weight counts twice)
+    if dups and p.col_idx.size > 4:
+        rp64 = p.row_ptr.astype(np.int64)
+        rows = rng.choice(np.nonzero(np.diff(rp64) >= 2)[0], size=max(1, p.m // 7))
+        for r in rows:
+            b, e = rp64[r], rp64[r + 1]
+            p.col_idx[rng.integers(b, e)] = p.col_idx[rng.integers(b, e)]
     k = None
     if rng.integers(0, 2):
         k = rng.choice([1, 1, 1, 2, 3, 8, 9, 40, 70, 150, 700, 5000], size=p.m).astype(np.uint32)   # 70 / 150 / 700: draws or binomial chain by row length
@@ -78,8 +85,8 @@ def one_case(seed, gpu, orc, verbose=True):
         info = prob.info
         prob.close()
         if verbose:
-            print("seed %d ok: R=%d T=%d avg=%g far=%g sort=%s k=%s keep=%s tx=%s kernel=%d tiles %d fast %d far %d opts=%s" % (
-                seed, pk.m, T, avg, far, sort, k is not None, keep_rows, tx_order is not None, info.sample_kernel, info.n_tiles, info.fast_tiles,
+            print("seed %d ok: R=%d T=%d avg=%g far=%g sort=%s dups=%s k=%s keep=%s tx=%s kernel=%d tiles %d fast %d far %d opts=%s" % (
+                seed, pk.m, T, avg, far, sort, dups, k is not None, keep_rows, tx_order is not None, info.sample_kernel, info.n_tiles, info.fast_tiles,
                 info.far_tiles, opts), flush=True)
 
 
