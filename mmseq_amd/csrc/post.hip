@@ -327,7 +327,7 @@ extern "C" int mmg_summary_get_rows(mmg_summary *q, int kind, int first_sample, 
     case MMG_SERIES_GENE: src = q->d_gene; width = q->ng; break;
     default: return fail(MMG_ERR_ARG, "rows exist for the proportion, identical-set and gene traces");
     }
-    if (first_sample < 0 || n_samples < 0 || (uint32_t)(first_sample + n_samples) > q->S) return fail(MMG_ERR_ARG, "bad sample range");
+    if (first_sample < 0 || n_samples < 0 || (int64_t)first_sample + n_samples > (int64_t)q->S) return fail(MMG_ERR_ARG, "bad sample range");
     if ((uint32_t)(first_sample + n_samples) > q->done) return fail(MMG_ERR_STATE, "rows of samples that were not yet handed to mmg_summary_advance");
     HIP_TRY(hipSetDevice(q->device));
     if (width && n_samples) {

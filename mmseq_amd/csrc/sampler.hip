@@ -447,7 +447,7 @@ extern "C" int mmg_sampler_get_trace_rows(mmg_sampler *s, int chain, int first, 
 {
     int rc = check_chain(s, chain);
     if (rc) return rc;
-    if (!out || first < 0 || count < 0 || first + count > s->cfg.trace_len) return fail(MMG_ERR_ARG, "bad sample range");
+    if (!out || first < 0 || count < 0 || (int64_t)first + count > s->cfg.trace_len) return fail(MMG_ERR_ARG, "bad sample range");
     if (!s->d_trace) return fail(MMG_ERR_STATE, "sampler was created with keep_trace == 0");
     HIP_TRY(hipSetDevice(s->device));
     const size_t n = s->p->n, S = (size_t)s->cfg.trace_len;
@@ -474,7 +474,7 @@ extern "C" int mmg_sampler_get_trace_rows_done(mmg_sampler *s, int chain, int fi
 {
     int rc = check_chain(s, chain);
     if (rc) return rc;
-    if (!out || first < 0 || count < 0 || first + count > s->cfg.trace_len) return fail(MMG_ERR_ARG, "bad sample range");
+    if (!out || first < 0 || count < 0 || (int64_t)first + count > s->cfg.trace_len) return fail(MMG_ERR_ARG, "bad sample range");
     if (!s->d_trace) return fail(MMG_ERR_STATE, "sampler was created with keep_trace == 0");
     if (count == 0) return MMG_OK;
     HIP_TRY(hipSetDevice(s->device));
