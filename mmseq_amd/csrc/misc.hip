@@ -1,12 +1,14 @@
 // misc.hip -- device TU: K2, trace read-out, start values, synthetic generator, self tests (kernels in misc_kernels.h)
 #include "misc_kernels.h"
 #include "mmg_launch.h"
+#include <hip/hip_ext.h>
 
 namespace mmg {
 
-void launch_update(const UpdateArgs &a, hipStream_t s)
+void launch_update(const UpdateArgs &a, hipStream_t s, hipEvent_t start, hipEvent_t stop)
 {
-    hipLaunchKernelGGL(k_update, dim3((a.n + 255u) / 256u, a.n_chains), dim3(256), 0, s, a);
+    if (start || stop) hipExtLaunchKernelGGL(k_update, dim3((a.n + 255u) / 256u, a.n_chains), dim3(256), 0, s, start, stop, 0, a);
+    else hipLaunchKernelGGL(k_update, dim3((a.n + 255u) / 256u, a.n_chains), dim3(256), 0, s, a);
 }
 
 void launch_transpose(const double *in, double *out, uint32_t n, uint32_t S, const uint32_t *int_of_ext, hipStream_t s)

@@ -38,7 +38,7 @@ void launch_em_apply(uint32_t n, double *mu, const double *l, const uint32_t *wo
                      int32_t *sexp, hipStream_t s);
 
 // ---- misc.hip: Gamma redraw / trace (src/mmseq.cpp:896-917), read-out, start values, generator, self tests
-void launch_update(const UpdateArgs &a, hipStream_t s);
+void launch_update(const UpdateArgs &a, hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr); // events: the launch's own time stamps (hipExtLaunchKernel)
 // out[t_ext * S + smp] = in[smp * n + int_of_ext[t_ext]]   (int_of_ext == nullptr: identity)
 void launch_transpose(const double *in, double *out, uint32_t n, uint32_t S, const uint32_t *int_of_ext, hipStream_t s);
 // out[r * n + t_ext] = in[r * n + int_of_ext[t_ext]] for r < rows (element size 4 or 8 bytes)

@@ -1,0 +1,4 @@
+for r in 1 2 3; do
+for lib in build_ab/lib_evrec.so mmseq_amd/csrc/libmmgibbs.so; do
+  MMSEQ_AMD_LIB=$lib timeout 200 python bench.py --no-extra --no-cpu-baseline --no-live-pmc --steps 20 --warmup 5 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$lib', d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline']['k_update_avg_launch_ms'])"
+done; done
