@@ -8,7 +8,8 @@ round-1 review asked for (config 2, 8 chains, uniform hits, rows kept in generat
 run and reported in the `extra` block of the same JSON line.
 
 HIP events bracket K1 and K2 on every --time-every-th step INSIDE the timed region, on the stream the kernels are launched on
-(default 4: an event pair costs about 9 us of stream time); roofline.avg_launch_ms is the mean over those launches.
+(default 4; the library attaches them to the launches -- hipExtLaunchKernel, the dispatch's own time stamps -- so that a timed step costs
+the stream next to nothing); roofline.avg_launch_ms is the mean over those launches.
 
 roofline (K1 = k_sample_sell, the dominant kernel; the same block for the chain-pair kernel and the EM kernel in `roofline_other`):
   bound        "hbm".  K1 is bound by the stream it reads: with the same stream served from the caches it runs 21 % faster
@@ -398,7 +399,7 @@ def main():
     ap.add_argument("--mode", choices=["chains", "shard"], default="chains")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--time-every", type=int, default=4, help="HIP-event pairs around K1/K2 on every N-th step of the timed region "
-                    "(a pair costs about 9 us of stream time; 1 = every step)")
+                    "(1 = every step)")
     ap.add_argument("--settle-iters", type=int, default=256, help="iterations of a scratch chain before the warm-up steps (GPU clock ramp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the side measurements")
