@@ -63,7 +63,18 @@ extern "C" {
  *      problem built on it -- the transcripts of a group stay together, in the caller's order -- if the model prices it a fifth lower.
  *      Stored order and chain of exactly those problems differ from version 6; keys whose high words are all equal (plain ranks) are
  *      untouched.  mmg_synth_desc gained gene_size / far_family (the struct grew: ABI 7); MMG_OPT_WIRE_CHECK; the first exchanges of an
- *      mmg_group are verified against the host's own reduction of the members' buffers. */
+ *      mmg_group are verified against the host's own reduction of the members' buffers.
+ *   8  (round 6) multiplicities: a row draws its k categoricals one by one while k <= min(MMG_K_SMALL, MMG_K_DRAWS_PER_HIT * (hits - 1))
+ *      (version 5: the LARGER of the two limits); above, the conditional-binomial chain.  The chain's rows are no longer drawn in the
+ *      lane of a tile that owns them but from a list of their own, a lane per row running ahead of its neighbours (k_sample_bigk), at a
+ *      third of the old cost per binomial; k categorical draws beyond 64 then cost more than the hits - 1 binomials they were meant to
+ *      save (bench.py `heavy`: 0.74 -> 0.40 ms per sweep, `collapsed`: 0.30 -> 0.15, of which the new boundary is 0.21 and 0.11).
+ *      Step 0 of the canonical layout follows the rule: the rows stored k times are the rows that draw categoricals (rows of ONE hit and
+ *      empty rows are never stored twice: they need no draw).  Chains and stored rows of problems with rows of
+ *      MMG_K_SMALL < k <= MMG_K_DRAWS_PER_HIT * (hits - 1), with k > MMG_K_DRAWS_PER_HIT * (hits - 1) on rows of 2-4 hits, or with
+ *      k >= 2 on rows of one hit differ from version 7.  tests/golden/keyed_chain_tiny.json has no such row and is byte for byte what
+ *      it was; keyed_chain_k_draws.json was regenerated for the new boundary (tools/gen_golden.py).  The conditional binomials themselves
+ *      (mmg_math.h: binomial) are unchanged, uniform for uniform.  MMG_OPT_BIGK_PER_WAVE, MMG_OPT_BIGK_SIDE_STREAM. */
 /* Layout.  The model does not care about the order of rows or the numbering of transcripts (src/mmseq.cpp:399-418 uses
  * first-seen order for both); the kernels do: they keep a window of consecutive transcripts in LDS and want the 64 rows of a
  * wave to have equal lengths.  mmg_problem_create therefore stores the rows in a CANONICAL order of its own (sorted on the
@@ -83,9 +94,9 @@ enum {
     MMG_ERR_IO = 5
 };
 
-/* rows with k <= MMG_K_SMALL, or k <= MMG_K_DRAWS_PER_HIT * (hits - 1), draw k categoricals (a draw costs a fraction of a
- * microsecond once the row's prefix sums are there); above, a conditional-binomial chain over the row's hits (one binomial per
- * hit but the last, whatever k).  Rows with 2 <= k <= MMG_K_SMALL are stored k times by the canonical layout. */
+/* rows with k <= MMG_K_SMALL and k <= MMG_K_DRAWS_PER_HIT * (hits - 1) draw k categoricals; above either limit, a conditional-binomial
+ * chain over the row's hits (one binomial per hit but the last, whatever k: src/mmseq.cpp:880's gsl_ran_multinomial).  The rows that
+ * draw k >= 2 categoricals are stored k times by the canonical layout. */
 #define MMG_K_SMALL 64u
 #define MMG_K_DRAWS_PER_HIT 16u
 
@@ -396,7 +407,9 @@ enum {
     MMG_OPT_GROUP_FAIL = 7,        /* v >= 0: member v % size of a group fails in its second iteration of the next run call (error path) */
     MMG_OPT_DERIVE_ORDER = 8,      /* 0: never derive a transcript order from the hit graph, 1: try it on every canonical problem without tx_order */
     MMG_OPT_WIRE_CHECK = 9,        /* 0: no verification of a group's first exchanges, 1: verify in groups of one device too, 2: 1 + damage a word behind the exchange (the failure path) */
-    MMG_OPT_COUNT_ = 10
+    MMG_OPT_BIGK_PER_WAVE = 10,    /* list entries per workgroup of k_sample_bigk (the rows on the conditional-binomial chain)                      */
+    MMG_OPT_BIGK_SIDE_STREAM = 11, /* 0: k_sample_bigk on the sampler's stream, in front of the tile kernels instead of beside them                    */
+    MMG_OPT_COUNT_ = 12
 };
 int mmg_selftest_option(int option, int value);
 /* The sharded EM of mmg_group_em_create with every shard on ONE device and the exchange done by plain kernels: `sweeps` sweeps from

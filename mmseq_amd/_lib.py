@@ -39,7 +39,7 @@ class MMGError(RuntimeError):
 
 LAYOUT_CANONICAL, LAYOUT_KEEP_ROWS = 0, 1
 # mmg_selftest_option ids
-OPT_SAMPLE_KERNEL, OPT_FORCE_IDX64, OPT_SELL_WAVES_PER_CU, OPT_EM_KERNEL, OPT_EM_GRID, OPT_FUSE_CHAINS, OPT_CNT_REPLICAS, OPT_GROUP_FAIL, OPT_DERIVE_ORDER, OPT_WIRE_CHECK = range(10)
+OPT_SAMPLE_KERNEL, OPT_FORCE_IDX64, OPT_SELL_WAVES_PER_CU, OPT_EM_KERNEL, OPT_EM_GRID, OPT_FUSE_CHAINS, OPT_CNT_REPLICAS, OPT_GROUP_FAIL, OPT_DERIVE_ORDER, OPT_WIRE_CHECK, OPT_BIGK_PER_WAVE, OPT_BIGK_SIDE_STREAM = range(12)
 
 
 class ProblemDesc(C.Structure):

@@ -195,7 +195,8 @@ struct RowViewGlobal {
 };
 
 // One row: restates src/mmseq.cpp:871-889.  add(col, v) adds v to the count of transcript col.
-template <bool HAS_K, typename View, typename Add>
+// CHAIN = false: the rows on the conditional-binomial chain are left to k_sample_bigk (bigk_kernels.h; the sliced-ELL kernels)
+template <bool HAS_K, bool CHAIN = true, typename View, typename Add>
 __device__ __forceinline__ void allocate_row(const View &v, Add add, uint32_t kk, const SampleArgs &a, uint64_t row_id)
 {
     const uint32_t L = v.L;
@@ -219,6 +220,7 @@ __device__ __forceinline__ void allocate_row(const View &v, Add add, uint32_t kk
         }
         return;
     }
+    if (!CHAIN) return;
     // conditional-binomial chain (the published gsl_ran_multinomial scheme, src/mmseq.cpp:880)
     Stream2 q(a.seed, a.chain, TAG_ROW, row_id, a.iter);
     uint32_t remaining = kk;

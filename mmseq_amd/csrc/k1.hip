@@ -2,6 +2,7 @@
 #include "gibbs_kernels.h"
 #include "sell_kernels.h"
 #include "sell_multi_kernels.h"
+#include "bigk_kernels.h"
 #include "mmg_launch.h"
 
 namespace mmg {
@@ -24,6 +25,17 @@ const void *k1_sell_multi_kernel(bool idx64, int nch)
     if (nch == 4) return idx64 ? (const void *)k_sample_sell_multi<uint64_t, 4> : (const void *)k_sample_sell_multi<uint32_t, 4>;
     return nullptr;
 }
+
+const void *k1_bigk_kernel(bool idx64) { return idx64 ? (const void *)k_sample_bigk<uint64_t> : (const void *)k_sample_bigk<uint32_t>; }
+
+#if defined(MMG_BIGK_STATS)
+extern "C" int mmg_selftest_bigk_stats(unsigned long long *out) // reads and clears the counters (diagnostics build only)
+{
+    unsigned long long zero[16] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bigk_stats), sizeof(zero)) != hipSuccess) return 1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_bigk_stats), zero, sizeof(zero)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 const void *k1_csr_kernel(bool idx64, bool has_k)
 {

@@ -10,6 +10,8 @@
 #include <algorithm>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
 #include "mmg_launch.h"
 
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256) void k_row_keys(uint64_t m, const uint64_t *__
             const uint64_t mid = med >> LAYOUT_BAND_SHIFT;
             band = (mid > 1 ? mid : 1) - 1;
         }
-        const uint64_t kclass = kk <= 1 ? 0 : (kk <= K_SMALL ? 1 : (draws_categoricals(kk, (uint32_t)(L > 1 ? L : 2)) ? 2 : 3));
+        const uint64_t kclass = kk <= 1 ? 0 : (draws_categoricals(kk, (uint32_t)(L < 0xffffffffull ? L : 0xffffffffull)) ? 1 : 3);
         const uint64_t ksmall = kclass == 1 ? kk : k_bucket(kk); // rows that draw k times sort by k first: a tile draws max k times per lane;
                                                                  // rows of the binomial chain (class 3) never share more than one tile per band with them
         kv = ((uint64_t)(near ? 0 : 1) << 63) | (band << 18) | (kclass << 16) | (ksmall << 9) | (L < 0x1ff ? L : 0x1ff);
@@ -210,15 +212,20 @@ hipError_t layout_scan_lens(uint64_t m, const uint32_t *d_len, uint64_t *d_rp, h
 }
 
 // ---- step 0 of the canonical layout: rows with a small multiplicity are stored as that many rows of multiplicity 1
-__global__ __launch_bounds__(256) void k_expand_count(uint64_t m, const uint32_t *__restrict__ k, uint32_t *__restrict__ reps, unsigned long long *stats)
+__global__ __launch_bounds__(256) void k_expand_count(uint64_t m, const uint64_t *__restrict__ rp, const uint32_t *__restrict__ k, uint32_t *__restrict__ reps,
+                                                      unsigned long long *stats)
 {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= m) return;
-    const uint32_t kk = k[r];
-    const bool ex = kk >= 2u && kk <= K_SMALL;
-    reps[r] = ex ? kk : 1u;
-    if (ex) atomicAdd(&stats[0], 1ull);                    // rows that expand
-    else if (kk != 1u) atomicAdd(&stats[1], 1ull);         // multiplicities that stay (0, or the conditional-binomial class)
+    const uint32_t kk = r < m ? k[r] : 1u;
+    const uint64_t L = r < m ? rp[r + 1] - rp[r] : 0;
+    const bool ex = r < m && kk >= 2u && L >= 1 && draws_categoricals(kk, (uint32_t)(L < 0xffffffffull ? L : 0xffffffffull)); // (an empty row stays one row)
+    if (r < m) reps[r] = ex ? kk : 1u;
+    // one atomic per wave (an atomic per row had every row of a collapsed file queue up at two addresses: 25 ms for 5 M rows)
+    const uint32_t n_ex = (uint32_t)__popcll(__ballot(ex)), n_stay = (uint32_t)__popcll(__ballot(r < m && !ex && kk != 1u));
+    if ((threadIdx.x & 63u) == 0u) {
+        if (n_ex) atomicAdd(&stats[0], (unsigned long long)n_ex);     // rows that expand
+        if (n_stay) atomicAdd(&stats[1], (unsigned long long)n_stay); // multiplicities that stay (0, a single hit, or the conditional-binomial class)
+    }
 }
 
 __global__ __launch_bounds__(256) void k_expand_rows(uint64_t m, const uint64_t *__restrict__ rp, const uint32_t *__restrict__ k,
@@ -265,7 +272,7 @@ hipError_t layout_expand_rows(uint64_t *m_io, uint64_t *nnz_io, uint64_t **d_rp,
     X_TRY(hipMalloc((void **)&d_stats, 16));
     X_TRY(hipMemsetAsync(d_stats, 0, 16, s));
     const unsigned g = blocks_of(m);
-    hipLaunchKernelGGL(k_expand_count, dim3(g), dim3(256), 0, s, m, (const uint32_t *)*d_k, reps, d_stats);
+    hipLaunchKernelGGL(k_expand_count, dim3(g), dim3(256), 0, s, m, (const uint64_t *)*d_rp, (const uint32_t *)*d_k, reps, d_stats);
     X_TRY(hipGetLastError());
     X_TRY(hipMemcpyAsync(stats, d_stats, 16, hipMemcpyDeviceToHost, s));
     X_TRY(hipStreamSynchronize(s));
@@ -432,6 +439,58 @@ hipError_t layout_max_row_len(uint64_t m, const uint64_t *d_rp, uint32_t *max_le
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (d) (void)hipFree(d);
     return e;
+}
+
+// ---- the list of the rows on the conditional-binomial chain (mmg_types.h: bigk_row; sampled by k_sample_bigk) -------------------
+template <typename IdxT>
+struct BigkRowPred {
+    const IdxT *rp;
+    const uint32_t *k;
+    __device__ bool operator()(const uint64_t &r) const { return bigk_row(k[r], (uint64_t)rp[r + 1] - (uint64_t)rp[r]); }
+};
+template <typename IdxT>
+__global__ __launch_bounds__(256) void k_bigk_count(uint64_t m, const IdxT *__restrict__ rp, const uint32_t *__restrict__ k, unsigned long long *count)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool is = r < m && bigk_row(k[r], (uint64_t)rp[r + 1] - (uint64_t)rp[r]);
+    const uint32_t c = (uint32_t)__popcll(__ballot(is));
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, (unsigned long long)c);
+}
+template <typename IdxT>
+static hipError_t bigk_rows(uint64_t m, const IdxT *d_rp, const uint32_t *d_k, uint64_t **d_list, uint64_t *n_list, hipStream_t s)
+{
+    unsigned long long *d_n = nullptr;
+    void *d_tmp = nullptr;
+    uint64_t *out = nullptr;
+    auto done = [&](hipError_t rc) { if (d_n) (void)hipFree(d_n); if (d_tmp) (void)hipFree(d_tmp); if (rc != hipSuccess && out) (void)hipFree(out); return rc; };
+#define L_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return done(_e); } while (0)
+    L_TRY(hipMalloc((void **)&d_n, 16));
+    L_TRY(hipMemsetAsync(d_n, 0, 16, s));
+    hipLaunchKernelGGL(k_bigk_count<IdxT>, dim3(blocks_of(m)), dim3(256), 0, s, m, d_rp, d_k, d_n);
+    L_TRY(hipGetLastError());
+    unsigned long long n = 0;
+    L_TRY(hipMemcpyAsync(&n, d_n, 8, hipMemcpyDeviceToHost, s));
+    L_TRY(hipStreamSynchronize(s));
+    if (n == 0) return done(hipSuccess);
+    L_TRY(hipMalloc((void **)&out, n * sizeof(uint64_t)));
+    const BigkRowPred<IdxT> pred{d_rp, d_k};
+    rocprim::counting_iterator<uint64_t> rows(0);
+    size_t tmp = 0;
+    L_TRY(rocprim::select(nullptr, tmp, rows, out, d_n + 1, (size_t)m, pred, s));
+    L_TRY(hipMalloc(&d_tmp, tmp ? tmp : 8));
+    L_TRY(rocprim::select(d_tmp, tmp, rows, out, d_n + 1, (size_t)m, pred, s));
+    L_TRY(hipStreamSynchronize(s));
+#undef L_TRY
+    *d_list = out;
+    *n_list = n;
+    return done(hipSuccess);
+}
+hipError_t layout_bigk_rows(bool idx64, uint64_t m, const void *d_rp, const uint32_t *d_k, uint64_t **d_list, uint64_t *n_list, hipStream_t s)
+{
+    *d_list = nullptr;
+    *n_list = 0;
+    if (m == 0 || !d_k) return hipSuccess;
+    return idx64 ? bigk_rows<uint64_t>(m, (const uint64_t *)d_rp, d_k, d_list, n_list, s) : bigk_rows<uint32_t>(m, (const uint32_t *)d_rp, d_k, d_list, n_list, s);
 }
 
 } // namespace mmg

@@ -36,6 +36,13 @@ struct mmg_problem {
     uint64_t *d_sell_chunk_k = nullptr;
     int grid_sell_k = 0;
     uint64_t n_hask_tiles = 0;
+    // the rows on the conditional-binomial chain (mmg_types.h: bigk_row): their stored positions, ascending -- sampled by k_sample_bigk in
+    // pieces of bigk_per_wave list entries per workgroup (the tile kernel skips them); h_bigk_list: the host's copy (the timed shard cut)
+    uint64_t *d_bigk_list = nullptr;
+    uint64_t n_bigk = 0;
+    uint32_t bigk_per_wave = 0;
+    int grid_bigk = 0;
+    std::vector<uint64_t> h_bigk_list;
     // chains advanced in pairs: k_sample_sell_multi walks the register-path tiles without multiplicities (d_sell_tiles_f; the whole
     // list when every tile is like that) in its own ranges (2 and 4 chains: fewer resident waves); the other tiles without
     // multiplicities -- far tiles, CSR-walked tiles -- are a third list (d_sell_tiles_x) that k_sample_sell walks for all the

@@ -13,6 +13,7 @@ const void *k1_sell_kernel(bool idx64, bool has_k, bool fixed_walk = false);   /
 const void *k1_sell_far_kernel(bool idx64);            // k_sample_sell for the list of far / CSR-walked tiles (far list prefetched), no multiplicities
 const void *k1_sell_multi_kernel(bool idx64, int nch); // k_sample_sell_multi for nch = 2 or 4 chains (no multiplicities), 64 threads
 const void *k1_csr_kernel(bool idx64, bool has_k);    // k_sample, K1C_BS threads per workgroup
+const void *k1_bigk_kernel(bool idx64);                 // k_sample_bigk: the rows on the conditional-binomial chain, from their list (64 threads)
 void launch_tile_desc(bool idx64, const void *row_ptr, const uint32_t *col, const uint32_t *kmult, const uint64_t *tile_row, uint64_t n_tiles,
                       TileDesc *out, hipStream_t s);
 void launch_tile_far(bool idx64, const void *row_ptr, const uint32_t *col, const uint64_t *key, const uint64_t *tile_row,
@@ -91,5 +92,8 @@ hipError_t layout_narrow_row_ptr(uint64_t m, const uint64_t *d_rp64, uint32_t *d
 // d_rp[0..m] = running sum of d_len[0..m)
 hipError_t layout_scan_lens(uint64_t m, const uint32_t *d_len, uint64_t *d_rp, hipStream_t s);
 hipError_t layout_max_row_len(uint64_t m, const uint64_t *d_rp, uint32_t *max_len, hipStream_t s);
+// The stored positions (ascending) of the rows on the conditional-binomial chain (mmg_types.h: bigk_row): *d_list is a NEW device buffer
+// of *n_list entries (nullptr / 0 without such rows or without multiplicities).  d_rp: the problem's row offsets (u32 or u64).
+hipError_t layout_bigk_rows(bool idx64, uint64_t m, const void *d_rp, const uint32_t *d_k, uint64_t **d_list, uint64_t *n_list, hipStream_t s);
 
 } // namespace mmg

@@ -13,10 +13,18 @@
 
 namespace mmg {
 
-constexpr uint32_t K_SMALL = MMG_K_SMALL;   // rows with k <= K_SMALL draw k categoricals (and are stored k times by the canonical layout)
+constexpr uint32_t K_SMALL = MMG_K_SMALL;   // no row draws more than K_SMALL categoricals
 constexpr uint32_t K_DRAWS_PER_HIT = MMG_K_DRAWS_PER_HIT;
-// k categorical draws, or the conditional-binomial chain (L - 1 binomials)?  L = hits of the row (>= 2 here)
-MMG_TYPES_HD inline bool draws_categoricals(uint32_t k, uint32_t L) { return k <= K_SMALL || (uint64_t)k <= (uint64_t)K_DRAWS_PER_HIT * (L - 1u); }
+// k categorical draws, or the conditional-binomial chain (L - 1 binomials)?  L = hits of the row (>= 1).  Draws while there are at most
+// K_DRAWS_PER_HIT of them per binomial they replace, and never more than K_SMALL (spec version 8; a row of one hit needs neither).
+MMG_TYPES_HD inline bool draws_categoricals(uint32_t k, uint32_t L)
+{
+    const uint64_t per_hit = (uint64_t)K_DRAWS_PER_HIT * (L - 1u);
+    return k <= 1u || (uint64_t)k <= (per_hit < K_SMALL ? per_hit : (uint64_t)K_SMALL);
+}
+// the rows on the conditional-binomial chain (kclass 3 below) with something to draw: at least two hits, reads to allocate, and more of
+// them than categorical draws pay for.  They are sampled from a list of their own (bigk_kernels.h), not by the tile kernel.
+MMG_TYPES_HD inline bool bigk_row(uint32_t k, uint64_t L) { return L >= 2 && k > 0 && !draws_categoricals(k, (uint32_t)(L < 0xffffffffull ? L : 0xffffffffull)); }
 // rows above K_SMALL sort by this bucket of k inside their class (7 bits: 8 steps per power of two from 64 on): the rows of a tile
 // draw about equally often
 MMG_TYPES_HD inline uint32_t k_bucket(uint32_t k)
@@ -31,17 +39,18 @@ MMG_TYPES_HD inline uint32_t k_bucket(uint32_t k)
 // Rows are exchangeable in the model (src/mmseq.cpp:857-891 visits them in file order only because that is how they were
 // read), and a row is a SET of transcripts (the reference walks it in ascending order, :871).  The library puts every row's hits in
 // ascending order and stores the rows sorted by row_key, ties by the tie word below, then by the caller's position.
-//   step 0  a row with 2 <= k <= K_SMALL is stored as k rows with k = 1 (layout.hip: layout_expand_rows): identical reads -- what every
-//           collapsed hits file carries (src/mmseq.cpp:409-418) -- then run on the register path and in fused chain pairs like any
-//           other read, instead of through the multiplicity kernel (50M-read file shape: 0.39 -> 0.34 ms per sweep, 8 chains 2.5k ->
-//           4.0k chain-iterations/s); an all-ones k array is dropped.  Rows with k > K_SMALL (conditional-binomial chain) and k = 0 stay.
-//           The step is skipped when it would store more than LAYOUT_EXPAND_MAX_RATIO rows per uploaded row (a heavily collapsed file
-//           would be un-collapsed: memory and work would scale with the reads again) or 2^32 rows: such rows keep their k.
+//   step 0  a row that draws k >= 2 categoricals (draws_categoricals: k <= min(K_SMALL, K_DRAWS_PER_HIT (hits - 1))) is stored as k rows
+//           with k = 1 (layout.hip: layout_expand_rows): identical reads -- what every collapsed hits file carries (src/mmseq.cpp:409-418) --
+//           then run on the register path and in fused chain pairs like any other read, instead of through the multiplicity kernel (50M-read
+//           file shape: 0.39 -> 0.34 ms per sweep, 8 chains 2.5k -> 4.0k chain-iterations/s); an all-ones k array is dropped.  Rows on the
+//           conditional-binomial chain, rows of one hit and k = 0 stay.  The step is skipped when it would store more than
+//           LAYOUT_EXPAND_MAX_RATIO rows per uploaded row (a heavily collapsed file would be un-collapsed: memory and work would scale
+//           with the reads again) or 2^32 rows: such rows keep their k and draw their categoricals in the tile kernel.
 //   lead    = smallest transcript of the row >> LAYOUT_BAND_SHIFT       (bands of 64 consecutive transcripts)
 //   near    = every hit of the row lies in [lead * 64, lead * 64 + LAYOUT_NEAR_SPAN) and the row has <= 255 hits
 //   band    = lead for a near row; for a far row its HOME band: max(median hit >> LAYOUT_BAND_SHIFT, 1) - 1 (lower median,
 //             hit[(len - 1) / 2] of the ascending row): the window starting one band below the row's middle holds its bulk
-//   kclass  = 0 (k <= 1), 1 (k <= K_SMALL), 2 (above, k categorical draws: draws_categoricals), 3 (conditional-binomial chain)
+//   kclass  = 0 (k <= 1), 1 (k categorical draws: draws_categoricals), 3 (conditional-binomial chain, or k >= 2 on a row of one hit)
 //   key     = !near << 63 | band << 18 | kclass << 16 | (kclass == 1 ? k : k_bucket(k)) << 9 | min(len, 0x1ff)      (an empty row: key 0)
 //   hash    = fold of (len, k, the ascending hits)
 //   csum    = sum of (hit - band * 64) over the hits inside the window [band * 64, band * 64 + SELL_WIN)  (<= 255 * 254 < 2^16)
@@ -83,7 +92,8 @@ struct TileDesc {
 // CSR (rows of more than 255 hits, rows kept in an order that is not "window hits first").
 // HASK: some row of the tile has a multiplicity other than 1.  A problem with multiplicities is sampled by TWO launches, each over its own
 // list of tile descriptors: k_sample_sell<.., false> walks the tiles without the flag exactly as it walks a problem without a k array
-// (identical reads are a minority, and the canonical order groups them: key field kclass), k_sample_sell<.., true> the flagged ones.
+// (identical reads are a minority, and the canonical order groups them: key field kclass), k_sample_sell<.., true> the flagged ones --
+// but for their rows on the conditional-binomial chain, which a THIRD launch samples from a list (k_sample_bigk, bigk_kernels.h).
 enum : uint32_t { SELL_FAST = 1, SELL_FAR = 2, SELL_EMPTY = 4, SELL_HASK = 8 };
 
 struct SellTile {

@@ -28,7 +28,7 @@ extern "C" const char *mmg_last_error(void) { return g_err.c_str(); }
 extern "C" int mmg_abi_version(void) { return MMG_ABI_VERSION; }
 
 // self-test overrides (mmg_selftest_option): -1 = the library decides
-static std::atomic<int> g_opt[MMG_OPT_COUNT_] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
+static std::atomic<int> g_opt[MMG_OPT_COUNT_] = {{-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
 int mmg::opt(int o) { return g_opt[o].load(std::memory_order_relaxed); }
 extern "C" int mmg_selftest_option(int option, int value)
 {
@@ -80,7 +80,7 @@ static void problem_free(mmg_problem *p)
     if (!p) return;
     (void)hipSetDevice(p->device);
     for (void *x : {(void *)p->d_row_ptr, (void *)p->d_col, (void *)p->d_k, (void *)p->d_l, (void *)p->d_int_of_ext, (void *)p->d_ext_of_int,
-                    (void *)p->d_sell, (void *)p->d_sell_tiles, (void *)p->d_sell_chunk, (void *)p->d_sell_chunk_k, (void *)p->d_sell_tiles_1, (void *)p->d_sell_tiles_k, (void *)p->d_sell_chunk_m[0], (void *)p->d_sell_chunk_m[1], (void *)(p->owns_tiles_f ? p->d_sell_tiles_f : nullptr), (void *)p->d_sell_tiles_x, (void *)p->d_sell_chunk_x,
+                    (void *)p->d_sell, (void *)p->d_sell_tiles, (void *)p->d_sell_chunk, (void *)p->d_sell_chunk_k, (void *)p->d_sell_tiles_1, (void *)p->d_sell_tiles_k, (void *)p->d_sell_chunk_m[0], (void *)p->d_sell_chunk_m[1], (void *)(p->owns_tiles_f ? p->d_sell_tiles_f : nullptr), (void *)p->d_sell_tiles_x, (void *)p->d_sell_chunk_x, (void *)p->d_bigk_list,
                     (void *)p->d_tiles, (void *)p->d_chunk_tile,
                     (void *)p->d_colcnt})
         if (x) (void)hipFree(x);
@@ -154,6 +154,19 @@ static hipError_t upload_ranges(const std::vector<uint64_t> &chunk, const std::v
     hipError_t e = hipMalloc((void **)d_out, h.size() * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMemcpy(*d_out, h.data(), h.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
     return e;
+}
+
+// List entries per workgroup of k_sample_bigk (one wave; a lane that finishes a row fetches the next of the piece).  Long pieces keep the
+// lanes busy (the last rows of a piece run in a thinning wave), but every SIMD should have waves to interleave: about BIGK_WAVES_PER_SIMD
+// pieces per SIMD of the device, between 64 and 512 entries each: a full wave per piece even when that leaves SIMDs without one (the phases
+// of a thin wave run for a handful of lanes each: what a launch costs is the instructions per SIMD, and those go with the runs).
+constexpr uint64_t BIGK_WAVES_PER_SIMD = 3;
+static uint32_t bigk_piece(uint64_t n_list, int cu_count)
+{
+    if (opt(MMG_OPT_BIGK_PER_WAVE) >= 1) return (uint32_t)opt(MMG_OPT_BIGK_PER_WAVE);
+    const uint64_t waves = (uint64_t)cu_count * 4 * BIGK_WAVES_PER_SIMD;
+    const uint64_t per = (n_list + waves - 1) / waves;
+    return (uint32_t)std::min<uint64_t>(512, std::max<uint64_t>(64, per));
 }
 
 // Sliced-ELL stream: tiles of <= 64 rows that never cross a (near, band) boundary of the canonical order, one window per tile.
@@ -402,6 +415,16 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
             HIP_TRY(upload_ranges(rx, sx, &p->d_sell_chunk_x));
             p->grid_sell_x = (int)(rx.size() - 1);
             p->device_bytes += sx.size() * sizeof(SellTile);
+        }
+    }
+    if (p->d_k) { // the rows on the conditional-binomial chain: a list of their own (bigk_kernels.h)
+        HIP_TRY(layout_bigk_rows(p->idx64, p->m, p->d_row_ptr, p->d_k, &p->d_bigk_list, &p->n_bigk, 0));
+        if (p->n_bigk) {
+            p->h_bigk_list.resize(p->n_bigk);
+            HIP_TRY(hipMemcpy(p->h_bigk_list.data(), p->d_bigk_list, p->n_bigk * sizeof(uint64_t), hipMemcpyDeviceToHost));
+            p->bigk_per_wave = bigk_piece(p->n_bigk, p->cu_count);
+            p->grid_bigk = (int)((p->n_bigk + p->bigk_per_wave - 1) / p->bigk_per_wave);
+            p->device_bytes += p->n_bigk * sizeof(uint64_t);
         }
     }
     launch_encode_sell(p->idx64, p->d_row_ptr, p->d_col, p->d_sell_tiles, nt, p->d_sell, 0);
@@ -865,7 +888,7 @@ extern "C" int mmg_problem_shard_bounds_timed(const mmg_problem *p, const double
     SampleArgs a;
     a.seed = 0x5eed; a.row_id_base = p->row_id_base; a.n = p->n; a.chain = 1u << 30; a.iter = 0;
     a.cnt_rep_stride = p->n; a.cnt_rep_mask = CNT_REPLICAS - 1u;     // (shards have many ranges per band: replicated count vectors)
-    auto launch_part = [&](const uint64_t *hdr1, unsigned g1, const uint64_t *hdrk, unsigned gk) -> hipError_t {
+    auto launch_tiles = [&](const uint64_t *hdr1, unsigned g1, const uint64_t *hdrk, unsigned gk) -> hipError_t {
         hipError_t e = hipSuccess;
         if (g1) {
             const SellTile *ts = d_t1;
@@ -879,6 +902,19 @@ extern "C" int mmg_problem_shard_bounds_timed(const mmg_problem *p, const double
         }
         return e;
     };
+    // the part's rows on the conditional-binomial chain: its interval of the list (k_sample_bigk)
+    auto launch_bigk = [&](uint64_t r_lo, uint64_t r_hi) -> hipError_t {
+        if (!p->n_bigk) return hipSuccess;
+        const uint64_t lo = (uint64_t)(std::lower_bound(p->h_bigk_list.begin(), p->h_bigk_list.end(), r_lo) - p->h_bigk_list.begin());
+        const uint64_t hi = (uint64_t)(std::lower_bound(p->h_bigk_list.begin(), p->h_bigk_list.end(), r_hi) - p->h_bigk_list.begin());
+        if (hi <= lo) return hipSuccess;
+        const uint64_t *list = p->d_bigk_list + lo;
+        uint64_t n_list = hi - lo;
+        uint32_t per = bigk_piece(n_list, p->cu_count);
+        void *kargs[] = {(void *)&rp, (void *)&ci, (void *)&kk, (void *)&list, (void *)&n_list, (void *)&per, (void *)&mup, (void *)&cnt, (void *)&a};
+        return hipLaunchKernel(k1_bigk_kernel(p->idx64), dim3((unsigned)((n_list + per - 1) / per)), dim3(64), kargs, 0, 0);
+    };
+    auto row_of_tile = [&](uint64_t t) { return t < nt ? p->h_tile_row[t] : p->m; };
     for (int round = 0; round < 6; ++round) {
         // cut the tiles by the current cost
         double total = 0.0;
@@ -906,24 +942,28 @@ extern "C" int mmg_problem_shard_bounds_timed(const mmg_problem *p, const double
                 if (hik > lok) { ranges_of(p->h_cumk, lok, hik, true, chunk); T_TRY(upload_ranges(chunk, tk, &d_hdr[2 * i + 1])); gk[i] = (unsigned)(chunk.size() - 1); }
             }
         }
+        auto launch_part = [&](int i) -> hipError_t {
+            const hipError_t e = launch_tiles(d_hdr[2 * i], g1[i], d_hdr[2 * i + 1], gk[i]);
+            return e == hipSuccess ? launch_bigk(row_of_tile(tb[i]), row_of_tile(tb[i + 1])) : e;
+        };
         if (round == 0) { // clocks up: the whole problem for about 50 ms
-            for (int w = 0; w < 4; ++w) for (int i = 0; i < parts; ++i) { a.iter++; T_TRY(launch_part(d_hdr[2 * i], g1[i], d_hdr[2 * i + 1], gk[i])); }
+            for (int w = 0; w < 4; ++w) for (int i = 0; i < parts; ++i) { a.iter++; T_TRY(launch_part(i)); }
             T_TRY(hipDeviceSynchronize());
             hipEvent_t &e0 = ev[0], &e1 = ev[1];
             T_TRY(hipEventRecord(e0, 0));
-            for (int i = 0; i < parts; ++i) { a.iter++; T_TRY(launch_part(d_hdr[2 * i], g1[i], d_hdr[2 * i + 1], gk[i])); }
+            for (int i = 0; i < parts; ++i) { a.iter++; T_TRY(launch_part(i)); }
             T_TRY(hipEventRecord(e1, 0));
             T_TRY(hipEventSynchronize(e1));
             float ms = 0.f;
             T_TRY(hipEventElapsedTime(&ms, e0, e1));
             const int more = ms > 0.f ? std::min(2000, (int)(50.0f / ms)) : 0;
-            for (int w = 0; w < more; ++w) for (int i = 0; i < parts; ++i) { a.iter++; T_TRY(launch_part(d_hdr[2 * i], g1[i], d_hdr[2 * i + 1], gk[i])); }
+            for (int w = 0; w < more; ++w) for (int i = 0; i < parts; ++i) { a.iter++; T_TRY(launch_part(i)); }
         }
         for (int r = 0; r < reps; ++r)
             for (int i = 0; i < parts; ++i) {
                 a.iter++;
                 T_TRY(hipEventRecord(ev[((size_t)r * parts + i) * 2], 0));
-                T_TRY(launch_part(d_hdr[2 * i], g1[i], d_hdr[2 * i + 1], gk[i]));
+                T_TRY(launch_part(i));
                 T_TRY(hipEventRecord(ev[((size_t)r * parts + i) * 2 + 1], 0));
             }
         T_TRY(hipDeviceSynchronize());

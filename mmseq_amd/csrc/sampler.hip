@@ -16,6 +16,10 @@ struct mmg_sampler {
     int device = 0;
     mmg_config cfg{};
     hipStream_t own = nullptr, cur = nullptr;
+    // the launch of the rows on the conditional-binomial chain (k_sample_bigk: few waves, long chains of arithmetic) runs beside the tile
+    // kernels (bound by the stream of hits) on a stream of its own, forked from and joined to `cur` inside every sample()
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     double *d_mu = nullptr, *d_scale = nullptr, *d_trace = nullptr, *d_mom = nullptr; // mom: [2][C][n]
     int32_t *d_cnt = nullptr, *d_cnt_last = nullptr;
     int iter = 0;          // completed iterations
@@ -26,7 +30,7 @@ struct mmg_sampler {
     // as it has completed, so the pool stays as large as the launches in flight however long the chain
     std::vector<hipEvent_t> ev_pool;
     std::vector<int> ev_free;                              // indices into ev_pool
-    std::deque<std::array<int, 3>> ev_pending;             // {start, stop, 0 sample | 1 update} in enqueue order
+    std::deque<std::array<int, 4>> ev_pending;             // {start, stop, 0 sample | 1 update, stop of the side launch or -1} in enqueue order
     hipStream_t reader = nullptr;                          // mmg_sampler_get_trace_rows_done: copies that do not queue behind the chain
     double *d_reader_tmp = nullptr;                        // its gather buffer, kept (hipFree would wait for the running chain)
     size_t reader_cap = 0;
@@ -50,6 +54,9 @@ static void sampler_free(mmg_sampler *s)
     for (auto e : s->mark_pool) (void)hipEventDestroy(e);
     for (void *x : {(void *)s->d_mu, (void *)s->d_scale, (void *)s->d_trace, (void *)s->d_mom, (void *)s->d_cnt, (void *)s->d_cnt_last})
         if (x) (void)hipFree(x);
+    if (s->side) { (void)hipStreamSynchronize(s->side); (void)hipStreamDestroy(s->side); }
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+    if (s->ev_join) (void)hipEventDestroy(s->ev_join);
     if (s->own) (void)hipStreamDestroy(s->own);
     if (s->reader) (void)hipStreamDestroy(s->reader);
     if (s->d_reader_tmp) (void)hipFree(s->d_reader_tmp);
@@ -83,6 +90,11 @@ extern "C" int mmg_sampler_create(const mmg_problem *p, const mmg_config *cfg, c
 #define S_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return bail(fail(MMG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); } while (0)
     S_TRY(hipStreamCreateWithFlags(&s->own, hipStreamNonBlocking));
     s->cur = s->own;
+    if (p->grid_bigk > 0) {
+        S_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+        S_TRY(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+        S_TRY(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+    }
     S_TRY(hipMalloc((void **)&s->d_mu, C * n * sizeof(double)));
     S_TRY(hipMalloc((void **)&s->d_scale, n * sizeof(double)));
     S_TRY(hipMalloc((void **)&s->d_mom, 2 * C * n * sizeof(double)));
@@ -117,14 +129,23 @@ extern "C" int mmg_sampler_set_stream(mmg_sampler *s, void *hip_stream)
 static int ev_harvest(mmg_sampler *s, bool wait)
 {
     while (!s->ev_pending.empty()) {
-        const std::array<int, 3> pr = s->ev_pending.front();
+        const std::array<int, 4> pr = s->ev_pending.front();
         if (!wait) {
-            const hipError_t q = hipEventQuery(s->ev_pool[pr[1]]);
-            if (q == hipErrorNotReady) { (void)hipGetLastError(); break; }
-            if (q != hipSuccess) return fail(MMG_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(q));
+            for (int q_i : {1, 3}) {
+                if (pr[q_i] < 0) continue;
+                const hipError_t q = hipEventQuery(s->ev_pool[pr[q_i]]);
+                if (q == hipErrorNotReady) { (void)hipGetLastError(); return MMG_OK; }
+                if (q != hipSuccess) return fail(MMG_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(q));
+            }
         }
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, s->ev_pool[pr[0]], s->ev_pool[pr[1]]));
+        if (pr[3] >= 0) { // the side launch may end after the last launch of the main stream: K1's time is to the later of the two
+            float ms2 = 0;
+            HIP_TRY(hipEventElapsedTime(&ms2, s->ev_pool[pr[0]], s->ev_pool[pr[3]]));
+            ms = std::max(ms, ms2);
+            s->ev_free.push_back(pr[3]);
+        }
         if (pr[2] == 0) { s->acc_sample_ms += ms; s->acc_sample_n++; } else { s->acc_update_ms += ms; s->acc_update_n++; }
         s->ev_free.push_back(pr[0]); s->ev_free.push_back(pr[1]);
         s->ev_pending.pop_front();
@@ -165,7 +186,8 @@ static int sampler_sample(mmg_sampler *s, bool fold)
         rc = ev_get(s, e1); if (rc) return rc;
         ev_start = s->ev_pool[e0]; ev_stop = s->ev_pool[e1];
     }
-    int n_launched = 0;
+    int n_launched = 0, e2 = -1;
+    bool joined = true;
     auto launch = [&](const void *fn, dim3 grid, dim3 block, void **kargs) -> hipError_t {
         const hipError_t e = timed ? hipExtLaunchKernel(fn, grid, block, kargs, 0, s->cur, n_launched == 0 ? ev_start : nullptr, ev_stop, 0)
                                    : hipLaunchKernel(fn, grid, block, kargs, 0, s->cur);
@@ -197,6 +219,29 @@ static int sampler_sample(mmg_sampler *s, bool fold)
             HIP_TRY(launch(fn, dim3(grid, nc), dim3(64), kargs));
             return MMG_OK;
         };
+        if (p->use_sell && p->grid_bigk > 0) {
+            // The rows on the conditional-binomial chain, from their list, for every chain (grid.y): few waves with long dependent chains
+            // of arithmetic.  They start first, on the side stream (ordered behind everything enqueued on `cur` so far -- the update that
+            // wrote mu), and the tile kernels below fill the device around them; sample() ends with `cur` waiting for the side stream.
+            SampleArgs a = args_of(0);
+            const double *mu = s->d_mu;
+            int32_t *cnt = s->d_cnt;
+            const uint64_t *list = p->d_bigk_list;
+            uint64_t n_list = p->n_bigk;
+            uint32_t per = p->bigk_per_wave;
+            void *kargs[] = {(void *)&rp, (void *)&ci, (void *)&kk, (void *)&list, (void *)&n_list, (void *)&per, (void *)&mu, (void *)&cnt, (void *)&a};
+            // (not beside the legacy NULL stream or the per-thread stream: special handles, which the event calls below do not take here)
+            const bool beside = opt(MMG_OPT_BIGK_SIDE_STREAM) != 0 && s->cur != hipStreamLegacy && s->cur != hipStreamPerThread;
+            if (beside) {
+                HIP_TRY(hipEventRecord(s->ev_fork, s->cur));
+                HIP_TRY(hipStreamWaitEvent(s->side, s->ev_fork, 0));
+                if (timed) { int rc = ev_get(s, e2); if (rc) return rc; }
+                HIP_TRY(timed ? hipExtLaunchKernel(k1_bigk_kernel(p->idx64), dim3(p->grid_bigk, C), dim3(64), kargs, 0, s->side, nullptr, s->ev_pool[e2], 0)
+                              : hipLaunchKernel(k1_bigk_kernel(p->idx64), dim3(p->grid_bigk, C), dim3(64), kargs, 0, s->side));
+                HIP_TRY(hipEventRecord(s->ev_join, s->side));
+                joined = false;
+            } else HIP_TRY(launch(k1_bigk_kernel(p->idx64), dim3(p->grid_bigk, C), dim3(64), kargs));
+        }
         if (p->use_sell) {
             // Chains are advanced in fused pairs over the register-path tiles without multiplicities (measured at config 3 with 8
             // chains: 3470 chain-iterations/s one chain per launch, 3780 in pairs at 4 waves per SIMD, 2970 in fours at 2 waves
@@ -247,9 +292,10 @@ static int sampler_sample(mmg_sampler *s, bool fold)
             }
         }
     }
+    if (!joined) HIP_TRY(hipStreamWaitEvent(s->cur, s->ev_join, 0));
     if (timed) {
         if (n_launched == 0) { HIP_TRY(hipEventRecord(ev_start, s->cur)); HIP_TRY(hipEventRecord(ev_stop, s->cur)); } // (a problem without rows)
-        s->ev_pending.push_back({e0, e1, 0});
+        s->ev_pending.push_back({e0, e1, 0, e2});
     }
     if (fold && p->m > 0 && p->cnt_replicas > 1) {
         launch_fold_counts(s->d_cnt, (uint64_t)s->cfg.n_chains * p->n, (size_t)s->cfg.n_chains * p->n, s->cur);
@@ -312,7 +358,7 @@ extern "C" int mmg_sampler_update(mmg_sampler *s)
     }
     launch_update(a, s->cur, timed ? s->ev_pool[e0] : nullptr, timed ? s->ev_pool[e1] : nullptr); // (the events ride on the launch: sampler_sample)
     HIP_TRY(hipGetLastError());
-    if (timed) s->ev_pending.push_back({e0, e1, 1});
+    if (timed) s->ev_pending.push_back({e0, e1, 1, -1});
     if (sample_idx >= 0) s->n_kept++;
     s->iter++;
     s->sampled = false;

@@ -10,7 +10,8 @@
 // tiles homogeneous in length) with the offset of the window's 0.0 slot: every lane walks the same number of groups, a pad adds an
 // exact 0.0 and can never be selected, so the draw equals the oracle's plain sequential walk bit for bit -- same keyed stream, same
 // additions in the same order.  Rows with hits outside the window keep those in a far list behind the block (far tiles); problems
-// with multiplicities run the tiles that hold them through the HAS_K instantiation in a second launch (mmg_types.h).
+// with multiplicities run the tiles that hold them through the HAS_K instantiation in a second launch (mmg_types.h), and the rows
+// on the conditional-binomial chain from a list of their own in a third (bigk_kernels.h).
 #pragma once
 
 namespace mmg {
@@ -627,22 +628,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
             }
             return;
         }
-        // conditional-binomial chain, as allocate_row (the published gsl_ran_multinomial scheme, src/mmseq.cpp:880)
-        Stream2 q(a.seed, a.chain, TAG_ROW, row_id, a.iter);
-        uint32_t remaining = kk;
-        double rem_w = t;
-#pragma unroll 1
-        for (uint32_t j = 0; j + 1 < L && remaining > 0; ++j) {
-            const uint32_t off = off_of(j);
-            const double w = wo(off);
-            double pr = degenerate ? 1.0 / (double)(L - j) : (rem_w > 0.0 ? w / rem_w : 1.0);
-            if (pr > 1.0) pr = 1.0;
-            const uint32_t x = binomial(q, remaining, pr);
-            if (x) add(off, (int32_t)x);
-            remaining -= x;
-            rem_w -= w;
-        }
-        if (remaining > 0) add(off_of(L - 1), (int32_t)remaining);
+        // (a row on the conditional-binomial chain is not drawn here: k_sample_bigk walks the list of those rows, bigk_kernels.h)
     };
 #undef SELL_GROUPS
 #undef SELL_OFF0
@@ -662,7 +648,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
                 else global_count_add(gcnt, col, x);
             };
             RowViewGlobalWin<WIN> v{col_idx + st, L, wbase, s_mu, gmu};
-            allocate_row<HAS_K>(v, add, HAS_K ? kmult[d.r0 + lane] : 1u, a, a.row_id_base + d.r0 + lane);
+            allocate_row<HAS_K, false>(v, add, HAS_K ? kmult[d.r0 + lane] : 1u, a, a.row_id_base + d.r0 + lane);
         }
     };
 
@@ -678,7 +664,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
                 else global_count_add(gcnt, col, x);
             };
             const RowViewFarTile v{(const uint32_t *)blk + lane, (const uint32_t *)(fb + 64) + lane, Ln, Ln + fb[lane], wbase, s_mu, gmu};
-            allocate_row<HAS_K>(v, add, HAS_K ? kmult[d.r0 + lane] : 1u, a, a.row_id_base + d.r0 + lane);
+            allocate_row<HAS_K, false>(v, add, HAS_K ? kmult[d.r0 + lane] : 1u, a, a.row_id_base + d.r0 + lane);
         }
     };
 

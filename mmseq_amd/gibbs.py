@@ -471,7 +471,7 @@ def selftest_option(option, value):
 
 OPT = dict(sample_kernel=_lib.OPT_SAMPLE_KERNEL, force_idx64=_lib.OPT_FORCE_IDX64, sell_waves_per_cu=_lib.OPT_SELL_WAVES_PER_CU,
            em_kernel=_lib.OPT_EM_KERNEL, em_grid=_lib.OPT_EM_GRID, fuse_chains=_lib.OPT_FUSE_CHAINS, cnt_replicas=_lib.OPT_CNT_REPLICAS, group_fail=_lib.OPT_GROUP_FAIL, derive_order=_lib.OPT_DERIVE_ORDER,
-           wire_check=_lib.OPT_WIRE_CHECK)
+           wire_check=_lib.OPT_WIRE_CHECK, bigk_per_wave=_lib.OPT_BIGK_PER_WAVE, bigk_side_stream=_lib.OPT_BIGK_SIDE_STREAM)
 
 
 class options:

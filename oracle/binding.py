@@ -290,9 +290,18 @@ K_DRAWS_PER_HIT = 16
 SELL_WIN = 255  # transcripts per LDS window (mmg_types.h)
 
 
+def draws_categoricals(k, L):
+    """mmg_types.h: draws_categoricals (spec version 8): k categorical draws while k <= min(K_SMALL, K_DRAWS_PER_HIT * (hits - 1)), or k <= 1;
+    above: the conditional-binomial chain.  k, L: integer arrays (L >= 1)."""
+    k = np.asarray(k).astype(np.uint64)
+    L = np.asarray(L).astype(np.uint64)
+    cap = np.minimum(np.uint64(K_DRAWS_PER_HIT) * (L - np.uint64(1)), np.uint64(K_SMALL))
+    return (k <= 1) | (k <= cap)
+
+
 def row_keys(row_ptr, col_idx, k=None):
     """(key, tie) per row: key = !near << 63 | band << 18 | kclass << 16 | (kclass == 1 ? k : k_bucket(k)) << 9 | min(len, 0x1ff) (0 for an empty
-    row); kclass 0 (k <= 1), 1 (k <= K_SMALL), 2 (above, k categorical draws), 3 (conditional-binomial chain); band = the band
+    row); kclass 0 (k <= 1), 1 (k categorical draws: draws_categoricals), 3 (conditional-binomial chain); band = the band
     of the smallest hit for a near row, the home band (one below the band of hit[(len - 1) // 2]) for a far row;
     tie = csum << 48 | hash >> 16, hash = fold of (len, k, hits in stored order), csum = sum of (hit - 64 * band) over the hits inside
     [64 * band, 64 * band + SELL_WIN).  Spec: mmseq_amd/csrc/mmg_types.h."""
@@ -313,8 +322,7 @@ def row_keys(row_ptr, col_idx, k=None):
         mid = col[starts + (L[ne] - 1) // 2].astype(np.uint64) >> np.uint64(LAYOUT_BAND_SHIFT)
         band = np.where(near, band, np.maximum(mid, np.uint64(1)) - np.uint64(1))
         kn = kk[ne]
-        draws = kn.astype(np.uint64) <= np.uint64(K_DRAWS_PER_HIT) * (np.maximum(Ln, np.uint64(2)) - np.uint64(1))   # spec version 5
-        kclass = np.where(kn <= 1, 0, np.where(kn <= K_SMALL, 1, np.where(draws, 2, 3))).astype(np.uint64)
+        kclass = np.where(kn <= 1, 0, np.where(draws_categoricals(kn, Ln), 1, 3)).astype(np.uint64)   # spec version 8: no class 2
         # class 2 rows sort by a logarithmic bucket of k (spec version 5; mmg_types.h: k_bucket)
         kb = np.maximum(kn, 65).astype(np.uint64)
         e = np.floor(np.log2(kb.astype(np.float64))).astype(np.uint64)      # exact for k < 2^32: log2 of an integer below 2^53
@@ -369,14 +377,17 @@ def sort_hits(row_ptr, col_idx):
 def canonical_layout(row_ptr, col_idx, k=None):
     """Rows in the library's stored order (spec: mmseq_amd/csrc/mmg_types.h): hits ascending within every row, rows sorted by
     (key, hash), ties in the caller's order; a far row then keeps the hits inside its home window in front of the others.
-    A caller row with 2 <= k <= K_SMALL is stored as k rows with k = 1 (k comes back as None when no other multiplicity is left).
+    A caller row that draws k >= 2 categoricals (draws_categoricals) is stored as k rows with k = 1 (k comes back as None when no other
+    multiplicity is left).
     Returns (row_ptr, col_idx, k, perm) with perm[stored row] = caller row."""
     col_sorted = sort_hits(row_ptr, col_idx)
     src = None
     if k is not None:
-        # step 0 (ABI 4): a row with 2 <= k <= K_SMALL is stored as k rows with k = 1; an array of ones is no array
+        # step 0 (ABI 4; spec version 8: the rows that draw categoricals, draws_categoricals): a row with k >= 2 categorical draws is stored
+        # as k rows with k = 1; an array of ones is no array
         kk0 = np.asarray(k).astype(np.int64)
-        reps = np.where((kk0 >= 2) & (kk0 <= K_SMALL), kk0, 1)
+        L0 = np.diff(np.asarray(row_ptr).astype(np.int64))
+        reps = np.where((kk0 >= 2) & (L0 >= 1) & draws_categoricals(kk0, np.maximum(L0, 1)), kk0, 1)
         if int(reps.sum()) > LAYOUT_EXPAND_MAX_RATIO * kk0.size or int(reps.sum()) >= 0xffffffff:
             reps = np.ones_like(reps)          # a heavily collapsed file is not un-collapsed (mmg_types.h: LAYOUT_EXPAND_MAX_RATIO): the rows keep their k
         if (reps > 1).any():

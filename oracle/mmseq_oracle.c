@@ -47,8 +47,13 @@
 #include <omp.h>
 #endif
 
-#define ORC_K_SMALL 64u /* rows with k <= this: k categorical draws */
-#define ORC_K_DRAWS_PER_HIT 16u /* ... and rows with k <= this * (hits - 1); above: binomial chain (spec version 5) */
+#define ORC_K_SMALL 64u /* no row draws more categoricals than this */
+#define ORC_K_DRAWS_PER_HIT 16u /* ... nor more than this * (hits - 1); above either: binomial chain (spec version 8: the smaller of the two) */
+static inline int orc_draws_categoricals(uint32_t k, uint32_t L) /* mmg_types.h: draws_categoricals */
+{
+    const uint64_t per_hit = (uint64_t)ORC_K_DRAWS_PER_HIT * (L - 1u);
+    return k <= 1u || (uint64_t)k <= (per_hit < ORC_K_SMALL ? per_hit : (uint64_t)ORC_K_SMALL);
+}
 
 /* ------------------------------------------------------------------------- */
 /* Philox4x32-10 (Salmon et al., SC'11; Random123 reference constants)        */
@@ -425,7 +430,7 @@ static void keyed_row_allocate(const uint32_t *cols, uint32_t L, uint32_t k, con
     if (L == 1) { cnt[cols[0]] += (int32_t)k; return; }
     double total = 0.0;
     for (uint32_t j = 0; j < L; ++j) total += mu[cols[j]];
-    if (k <= ORC_K_SMALL || (uint64_t)k <= (uint64_t)ORC_K_DRAWS_PER_HIT * (L - 1u)) {
+    if (orc_draws_categoricals(k, L)) {
         orc_stream2 s = stream2_make(seed, chain, ORC_TAG_ROW, row_id, iter);
         for (uint32_t d = 0; d < k; ++d) {
             uint32_t x = stream2_next_word(&s);

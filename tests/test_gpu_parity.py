@@ -284,7 +284,8 @@ def test_full_chain_bit_exact(gpu, orc, R, T, avg, kernel):
 
 
 def test_rows_with_multiplicity_bit_exact(gpu, orc):
-    """k > 1 rows: k <= 64 (MMG_K_SMALL) or k <= 16 (hits - 1) -> repeated categorical draws; above -> conditional-binomial chain."""
+    """k > 1 rows: k <= min(64 (MMG_K_SMALL), 16 (hits - 1)) -> repeated categorical draws; above -> conditional-binomial chain (spec version
+    8: sampled from the list of those rows by k_sample_bigk)."""
     p, mu0, _ = _mk(orc, 5000, 400, 5)
     rng = np.random.default_rng(7)
     k = rng.choice([1, 2, 3, 8, 9, 50, 1000, 20000], size=p.m).astype(np.uint32)
@@ -298,6 +299,55 @@ def test_rows_with_multiplicity_bit_exact(gpu, orc):
     assert int(cnt.sum()) == pk.total_k()
     assert np.array_equal(cnt, ref["cnt"])
     assert np.array_equal(s.trace(0), ref["trace"])
+
+
+@pytest.mark.parametrize("per_wave,side", [(0, 1), (1, 1), (7, 0), (64, 1), (200, 0)])
+def test_rows_on_the_binomial_chain_from_their_list(gpu, orc, per_wave, side):
+    """k_sample_bigk (bigk_kernels.h): the rows on the conditional-binomial chain (k > min(64, 16 (hits - 1)), src/mmseq.cpp:880 on
+    collapsed hit sets) are sampled from a list, a lane per row, every lane a state machine that runs ahead of its neighbours -- and the
+    inversion settles x = 0 from a bound on r0 where it can.  Bit-exact against the oracle's sequential loop for every piece size
+    (1 row per wave ... the whole list in one wave), on the sampler's stream and beside it, for two chains of one sampler: rows of 2 ...
+    300 hits (CSR-walked tiles), far rows, k from 17 to 10^6, weights from 1e-300 to 1e6 (n p from 1e-290 up: every branch of the binomial),
+    rows whose weights are all zero or infinite (uniform split), and the rows that are NOT on the list beside them."""
+    rng = np.random.default_rng(11)
+    T = 30000
+    rows, ks = [], []
+    for lead in range(0, T - 400, 53):
+        for L in (2, 2, 3, 4, 5, 9, 17, 33, 1, 6):
+            rows.append(sorted(rng.choice(np.arange(lead, lead + 200), size=L, replace=False).tolist()))
+            ks.append(int(rng.choice([1, 3, 16, 17, 33, 49, 64, 65, 66, 100, 304, 305, 1000, 20000, 1000000])))
+    rows[40] = list(range(9000, 9300)); ks[40] = 5000                     # 300 hits: a CSR-walked tile
+    rows[41] = [3, 29000]; ks[41] = 777                                    # far row
+    rows[42] = [10, 11, 12, 25000, 25001]; ks[42] = 100000                 # far row, long tail
+    rp = np.cumsum([0] + [len(r) for r in rows]).astype(np.uint64)
+    ci = np.concatenate([np.asarray(r, np.uint32) for r in rows])
+    l = np.linspace(0.5, 2.0, T)
+    k = np.asarray(ks, np.uint32)
+    p = orc.Problem(rp, ci, l, k=k)
+    mu0 = np.exp(rng.normal(0.0, 4.0, size=T))                             # six orders of magnitude inside a row
+    mu0[::5] = 1e-300
+    mu0[1::11] = 1e-12
+    mu0[2000:2200] = 0.0
+    mu0[3000:3100] = np.inf
+    opts = dict(sample_kernel=2, bigk_side_stream=side)
+    if per_wave:
+        opts["bigk_per_wave"] = per_wave
+    with gpu.options(**opts):
+        prob, ps = _dev(gpu, orc, p)
+        Ls = np.diff(ps.row_ptr.astype(np.int64))
+        on_list = (Ls >= 2) & (ps.k > np.minimum(64, 16 * (Ls - 1)))
+        assert 1000 < int(on_list.sum()) < ps.m and prob.info.sample_kernel == 2
+        s = gpu.Sampler(prob, mu0, seed=23, n_chains=2, gibbs_iter=6, trace_len=6)
+        s.sample()
+        for c in range(2):
+            assert np.array_equal(s.counts(c), orc.sample_counts(ps, mu0, seed=23, chain=c, it=0))
+        s.update()
+        s.run(5)
+        for c in range(2):
+            ref = orc.gibbs_keyed(ps, mu0, seed=23, chain=c, n_iter=6, trace_len=6)
+            assert np.array_equal(s.counts(c), ref["cnt"]) and np.array_equal(s.trace(c), ref["trace"])
+            assert int(s.counts(c).astype(np.int64).sum()) == ps.total_k()
+        s.close(); prob.close()
 
 
 @pytest.mark.parametrize("keep_rows", [False, True])
@@ -458,8 +508,8 @@ def test_shards_of_a_stored_problem_with_far_rows_and_tx_order(gpu, orc):
     s.sample()
     whole = s.counts(0)
     assert np.array_equal(whole, orc.sample_counts(orc.Problem(rp, ci, l_ext, k=kk), mu0, seed=19, chain=0, it=0))
-    m_st = rp.size - 1                                         # stored rows: a caller row with 2 <= k <= 64 is k of them
-    assert m_st > p.m and set(np.unique(kk)) == {1, 70}
+    m_st = rp.size - 1                                         # stored rows: a caller row that draws k categoricals is k of them
+    assert m_st > p.m and {1, 70} <= set(np.unique(kk)) <= {1, 2, 5, 70}   # (rows of one hit keep their 2 or 5)
     cut = (m_st // 2) & ~1
     nz = int(rp[cut])
     parts = []
@@ -570,7 +620,7 @@ def test_derived_order_on_graphs_without_a_band(gpu, orc):
 
 
 def test_a_heavily_collapsed_file_is_not_uncollapsed(gpu, orc):
-    """Rows with 2 <= k <= 64 are stored k times (step 0 of the canonical layout) -- unless that would store more than 8 rows per uploaded
+    """Rows that draw k >= 2 categoricals (k <= min(64, 16 (hits - 1))) are stored k times (step 0 of the canonical layout) -- unless that would store more than 8 rows per uploaded
     row: a file whose hit sets are shared by dozens of reads each keeps its multiplicities (memory and work stay with the hit sets, not
     the reads) and the multiplicity kernel draws the same k categoricals per row.  Stored order = the oracle's restatement, chain = the
     oracle's, on both sides of the limit."""
@@ -583,7 +633,7 @@ def test_a_heavily_collapsed_file_is_not_uncollapsed(gpu, orc):
         rp, ci, kk = prob.download(with_k=True)
         c_rp, c_ci, c_k, _ = orc.canonical_layout(p.row_ptr, p.col_idx, k)
         assert np.array_equal(rp, c_rp) and np.array_equal(ci, c_ci)
-        assert (prob.info.m == int(k.sum())) == expanded and (prob.info.m == p.m) == (not expanded)
+        assert prob.info.m == c_rp.size - 1 and (prob.info.m > p.m) == expanded and (prob.info.m == p.m) == (not expanded)
         assert np.array_equal(kk, c_k if c_k is not None else np.ones(rp.size - 1, np.uint32))
         assert prob.info.total_k == int(k.sum())
         s = gpu.Sampler(prob, mu0, seed=4, gibbs_iter=5, trace_len=5)

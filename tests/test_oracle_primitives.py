@@ -135,11 +135,15 @@ def test_canonical_layout_properties(orc):
     rng = np.random.default_rng(0)
     k = rng.choice([1, 1, 2, 9, 70], size=p.m).astype(np.uint32)
     rp, ci, kk, perm = orc.canonical_layout(p.row_ptr, p.col_idx, k)
-    # rows with 2 <= k <= 64 are stored as k rows with k = 1 (ABI 4); the larger multiplicities stay
+    # rows that draw 2 <= k <= min(64, 16 (hits - 1)) categoricals are stored as k rows with k = 1 (ABI 4, spec version 8); the rows of the
+    # conditional-binomial chain and the rows of one hit keep their multiplicity
     m_st = rp.size - 1
-    assert m_st == int(np.where((k >= 2) & (k <= 64), k, 1).sum()) and set(np.unique(kk)) == {1, 70}
+    L = np.diff(p.row_ptr.astype(np.int64))
+    reps = np.where((k >= 2) & (k <= np.minimum(64, 16 * (L - 1))), k, 1)
+    assert ((reps == 1) & (k == 9)).any() and ((reps == 9) & (k == 9)).any()         # (k = 9: stored 9 times, except on rows of one hit)
+    assert m_st == int(reps.sum()) and set(np.unique(kk)) == {1, 2, 9, 70}
     assert int(kk.astype(np.int64).sum()) == int(k.astype(np.int64).sum())
-    assert np.array_equal(np.bincount(perm, minlength=p.m), np.where((k >= 2) & (k <= 64), k, 1))   # perm[stored row] = caller row
+    assert np.array_equal(np.bincount(perm, minlength=p.m), reps)   # perm[stored row] = caller row
     assert np.array_equal(np.diff(rp.astype(np.int64)), np.diff(p.row_ptr.astype(np.int64))[perm])
     key, h = orc.row_keys(rp, orc.sort_hits(rp, ci), kk)   # key and tie word are functions of the SET of hits
     assert (key[1:] >= key[:-1]).all()
@@ -151,7 +155,7 @@ def test_canonical_layout_properties(orc):
     rps, cis, ks = orc.permute_rows(p.row_ptr, p.col_idx, k, sh)
     rp3, ci3, kk3, _ = orc.canonical_layout(rps, cis, ks)
     assert np.array_equal(rp3, rp) and np.array_equal(ci3, ci) and np.array_equal(kk3, kk)
-    _, _, k_none, _ = orc.canonical_layout(p.row_ptr, p.col_idx, np.minimum(k, 9).astype(np.uint32))
+    _, _, k_none, _ = orc.canonical_layout(p.row_ptr, p.col_idx, np.where(L >= 2, np.minimum(k, 9), 1).astype(np.uint32))
     assert k_none is None                                  # every multiplicity expanded: an array of ones is no array
     far = key >> np.uint64(63)
     assert 0 < far.sum() < m_st and (np.diff(far.astype(np.int64)) >= 0).all()

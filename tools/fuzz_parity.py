@@ -30,7 +30,7 @@ def one_case(seed, gpu, orc, verbose=True):
             p.col_idx[rng.integers(b, e)] = p.col_idx[rng.integers(b, e)]
     k = None
     if rng.integers(0, 2):
-        k = rng.choice([1, 1, 1, 2, 3, 8, 9, 40, 70, 150, 700, 5000], size=p.m).astype(np.uint32)   # 70 / 150 / 700: draws or binomial chain by row length
+        k = rng.choice([1, 1, 1, 2, 3, 8, 9, 17, 40, 70, 150, 700, 5000, 300000], size=p.m).astype(np.uint32)   # 17 / 40: draws or binomial chain by row length (spec version 8)
     rp, ci = p.row_ptr.copy(), p.col_idx
     if rng.integers(0, 3) == 0 and p.m > 10:            # a few empty rows
         cut = np.sort(rng.choice(np.arange(1, p.m), size=3, replace=False))
@@ -48,6 +48,8 @@ def one_case(seed, gpu, orc, verbose=True):
     if rng.integers(0, 4) == 0: opts["fuse_chains"] = int(rng.choice([1, 4]))
     if rng.integers(0, 2) == 0: opts["cnt_replicas"] = int(rng.choice([1, 8]))     # one count vector per chain / eight (K2 sums them)
     if rng.integers(0, 3) == 0: opts["derive_order"] = int(rng.choice([0, 1]))     # never / always try an order from the hit graph
+    if rng.integers(0, 3) == 0: opts["bigk_per_wave"] = int(rng.choice([1, 5, 64, 300]))   # list entries per wave of k_sample_bigk (the rows on the binomial chain)
+    if rng.integers(0, 3) == 0: opts["bigk_side_stream"] = 0                          # ... on the sampler's stream instead of beside it
     keep_rows = bool(rng.integers(0, 3) == 0)
     tx_order = None
     if rng.integers(0, 3) == 0:                          # device renumbering: random gene sizes over a random scatter

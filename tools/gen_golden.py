@@ -77,19 +77,21 @@ def gen_tiny_chain():
 
 
 def gen_k_draws_chain():
-    """Spec version 5: rows with K_SMALL < k <= K_DRAWS_PER_HIT * (hits - 1) draw their categoricals one by one; one row on either
-    side of the boundary for three row lengths.  A fixture of its own: keyed_chain_tiny.json has no such row and stays byte for byte what it was."""
-    rows = [[0, 1, 2, 3, 4, 5, 6, 7], [0, 1, 2, 3, 4, 5, 6, 7], [1, 2, 3, 4, 5, 6], [1, 2, 3, 4, 5, 6], [0, 1, 2, 3, 4, 5, 6], [1, 2, 3, 4, 5, 6, 7],
-            [0, 2, 4, 5, 6], [1, 7], [3, 5], [5, 6, 7], [6]]
-    # draws: 112 on 8 hits (= 16 * 7), 80 on 6 (= 16 * 5), 96 on 7 (= 16 * 6), 24, 48; binomial chain: 113 on 8, 81 on 6, 97 on 7, 65 on 5 and on 2 hits
-    k = [112, 113, 80, 81, 96, 97, 65, 24, 65, 48, 500]
+    """Spec version 8: a row draws its k categoricals one by one while k <= min(K_SMALL, K_DRAWS_PER_HIT * (hits - 1)) = min(64, 16 (hits - 1));
+    above, the conditional-binomial chain.  One row on either side of the boundary for five row lengths (2, 3, 4 hits: the per-hit limit;
+    5 and 8 hits: K_SMALL), and a row of one hit.  A fixture of its own: keyed_chain_tiny.json has no row near the boundary and stays
+    byte for byte what it was (spec versions 5 and 8 agree on its rows)."""
+    rows = [[1, 7], [3, 5], [5, 6, 7], [0, 2, 4], [1, 2, 3, 4], [0, 5, 6, 7], [0, 2, 4, 5, 6], [1, 2, 3, 4, 5],
+            [0, 1, 2, 3, 4, 5, 6, 7], [0, 1, 2, 3, 4, 5, 6, 7], [6]]
+    # draws: 16 on 2 hits, 32 on 3, 48 on 4, 64 on 5 and on 8; binomial chain: 17 on 2, 33 on 3, 49 on 4, 65 on 5 and on 8
+    k = [16, 17, 32, 33, 48, 49, 64, 65, 64, 65, 500]
     l = [0.5, 1.5, 0.25, 2.0, 1.0, 0.75, 3.0, 0.1]
     rp = np.cumsum([0] + [len(r) for r in rows]).astype(np.uint64)
     ci = np.concatenate([np.asarray(r, np.uint32) for r in rows])
     p = B.Problem(rp, ci, np.asarray(l), k=np.asarray(k, np.uint32))
     mu0, uh = B.start_values(p)
     r = B.gibbs_keyed(p, mu0, alpha=0.1, beta=0.1, seed=4321, chain=0, n_iter=32, trace_len=16)
-    json.dump(dict(source="oracle/mmseq_oracle.c orc_gibbs_keyed (keyed Philox streams, spec version 5), seed 4321, chain 0, "
+    json.dump(dict(source="oracle/mmseq_oracle.c orc_gibbs_keyed (keyed Philox streams, spec version 8), seed 4321, chain 0, "
                           "alpha=beta=0.1, 32 iterations, 16 kept",
                    row_ptr=[int(v) for v in rp], col_idx=[int(v) for v in ci], k=k, l=hexf(l), mu0=hexf(mu0),
                    unique_hits=[int(v) for v in uh], trace=hexf(r["trace"]), cnt_last=[int(v) for v in r["cnt"]],
