@@ -234,7 +234,7 @@ def trigamma(x):
 
 # ------------------------------------------------------------------------------------ full pipeline
 def expected_run(h, alpha=0.1, beta=0.1, seed=1234, gibbs_iter=1024, max_em_iter=1000, epsilon=0.1,
-                 percentiles=(5.0, 25.0, 50.0, 75.0, 95.0), trace_len=1024):
+                 percentiles=(5.0, 25.0, 50.0, 75.0, 95.0), trace_len=1024, chain_fn=None):
     """What `mmseq hits out` must produce for hits data `h` (numbers, not text): restates
     src/mmseq.cpp:395-1669 with the keyed-stream chain of oracle/mmseq_oracle.c in the device row order."""
     from . import binding as B
@@ -270,7 +270,10 @@ def expected_run(h, alpha=0.1, beta=0.1, seed=1234, gibbs_iter=1024, max_em_iter
         if len(r) == 1:
             uh[r[0]] += kk
     mu_em, em_iters, ll = B.em(p, mu0, max_iter=max_em_iter, epsilon=epsilon)
-    chain = B.gibbs_keyed(p, mu_em, alpha=alpha, beta=beta, seed=seed, n_iter=gibbs_iter, trace_len=trace_len)
+    # chain_fn: another engine for src/mmseq.cpp:833-918 (tests/test_compare_outputs.py: a plain numpy Gibbs sampler, with the right and
+    # with deliberately wrong weights) -- called as chain_fn(p, mu_em, alpha, beta, seed, gibbs_iter, trace_len) -> {"trace": [n, trace_len]}
+    chain = (chain_fn(p, mu_em, alpha, beta, seed, gibbs_iter, trace_len) if chain_fn
+             else B.gibbs_keyed(p, mu_em, alpha=alpha, beta=beta, seed=seed, n_iter=gibbs_iter, trace_len=trace_len))
     trace = chain["trace"]                                   # [n, trace_len], real scale, observed (first-seen) order
     hdr_index = {name: i for i, name in enumerate(h.names)}
     genes = list(h.genes.items())
