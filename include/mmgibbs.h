@@ -155,6 +155,7 @@ typedef struct mmg_synth_desc {
                              members lie anywhere in the transcriptome but are the same for every read of a gene                */
 } mmg_synth_desc;
 
+#define MMG_ORDER_SKIPPED 0x100
 typedef struct mmg_problem_info {
     uint64_t m, nnz, total_k, row_id_base;
     uint32_t n;
@@ -170,8 +171,12 @@ typedef struct mmg_problem_info {
                               (n_tiles - fast - far - empty) are walked from the CSR                         */
     uint64_t padded_slots; /* hit slots of the sliced-ELL stream incl. padding (>= nnz of the fast tiles) */
     int32_t layout;        /* MMG_LAYOUT_* in force                                       */
-    int32_t tx_renumbered; /* 1: tx_order was given; 2: the library derived an order from the hit graph; 3: tx_order was given and the
-                              library reordered its groups (the genes) by the group-level hit graph */
+    int32_t tx_renumbered; /* low byte -- 1: tx_order was given; 2: the library derived an order from the hit graph; 3: tx_order was given and
+                              the library reordered its groups (the genes) by the group-level hit graph.  | MMG_ORDER_SKIPPED: such an order was
+                              called for (spec versions 6 / 7) but the attempt could not be made -- it needs about 3 x the problem's device memory
+                              free at the time, plus up to 4 GB -- or failed: the problem stands in the caller's order, and its chain is the one of
+                              THAT order.  Under memory pressure a chain is therefore a pure function of (problem, tx_order, seed, chain,
+                              iteration) AND of this flag; callers that need run-to-run identity check it (the CLI warns) */
     int32_t sample_grid;   /* workgroups of the sample kernel: the resident count (waves the runtime reports x CUs) times the
                               number of generations (1..16: tile ranges of about 24 tiles once the problem is large) */
     int32_t cu_count;

@@ -225,7 +225,7 @@ static int verified_first_iteration(mmg_group *g, mmg_sampler *const *samplers, 
     }
     int64_t total = 0, reads = 0;
     for (size_t j = 0; j < count; ++j) total += want[j];
-    for (size_t i = 0; i < G; ++i) reads += (int64_t)v[i].p->total_k * v[i].cfg.n_chains;
+    for (size_t i = 0; i < G; ++i) reads += (int64_t)v[i].p->total_k_hit * v[i].cfg.n_chains; // (the reads of rows WITH hits: an empty row is allocated nowhere)
     if (total != reads)
         return bail(MMG_ERR_STATE, "wire check: the shards' first sweep allocated " + std::to_string(total) + " reads, the shards hold " + std::to_string(reads));
     int rc = all_reduce(g, v, cnt.data(), cnt.data(), count, ncclInt32);

@@ -149,13 +149,13 @@ private:
         (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
         map_base = (const uint8_t *)m;
         map_len = (size_t)st.st_size;
-        par = new pinflate::Stream(map_base, map_len, par_threads, (size_t)env_long("MMSEQ_INFLATE_CHUNK", 4L << 20));
+        par = new pinflate::Stream(map_base, map_len, par_threads, (size_t)env_long("MMSEQ_INFLATE_CHUNK", 4L << 20), /* start_now = */ false);
         if (par->longest_stretch_bytes() > (256u << 20)) { // stored / fixed blocks for hundreds of MB (incompressible data): one decode would hold gigabytes of symbols
-            delete par;
+            delete par;                                     // (no worker has started: nothing to wait for)
             par = nullptr;
             munmap((void *)map_base, map_len);
             map_base = nullptr;
-        }
+        } else par->start();
     }
     bool fill()
     {

@@ -918,12 +918,19 @@ int main(int argc, char **argv)
         pd.row_id_base = 0; pd.layout = MMG_LAYOUT_CANONICAL; pd.tx_order = tx_order.data();
         if (device_warmup.joinable()) device_warmup.join();
         MMG_TRY(mmg_problem_create(&pd, device, &prob));
+        {
+            mmg_problem_info inf0;
+            MMG_TRY(mmg_problem_info_get(prob, &inf0));
+            if (inf0.tx_renumbered & MMG_ORDER_SKIPPED)
+                cerr << "Warning: not enough free device memory to try a gene order derived from the hit graph; the run uses the hits file's gene order "
+                        "(slower on reads that hit paralogues, and the traces differ from a run that had the memory)" << endl;
+        }
         if (stage.on) {
             mmg_problem_info inf;
             MMG_TRY(mmg_problem_info_get(prob, &inf));
             fprintf(stderr, "[timing] sample kernel %d (2 sliced-ELL stream, 0 CSR tiles), %llu of %llu tiles on the register path, %llu with far lists, %.1f MB on the device%s\n",
                     inf.sample_kernel, (unsigned long long)inf.fast_tiles, (unsigned long long)inf.n_tiles, (unsigned long long)inf.far_tiles, inf.device_bytes / 1e6,
-                    inf.tx_renumbered == 3 ? "; the genes reordered by the gene-level hit graph (reads that also hit paralogues)" : "");
+                    (inf.tx_renumbered & 0xff) == 3 ? "; the genes reordered by the gene-level hit graph (reads that also hit paralogues)" : "");
         }
     }
 
@@ -1176,6 +1183,7 @@ int main(int argc, char **argv)
             t_sync += c2 - c1; t_advance += omp_get_wtime() - c2;
         }
         for (auto sp : smps) MMG_TRY(mmg_sampler_sync(sp));
+        check_workers();
         cout << "Gibbs iteration " << gibbs_iter - 1 << "       \r" << endl;
         if (stage.on) fprintf(stderr, "[timing] Gibbs loop: enqueue %.3f s, wait for the device %.3f s, derived rows %.3f s\n", t_enqueue, t_sync, t_advance);
         stage.mark("Gibbs (trace files written alongside)");
@@ -1206,6 +1214,14 @@ int main(int argc, char **argv)
     // writers are done, behind the tables)
     auto release_device = [&]() {
         w_trace.join(); w_ident.join(); w_gene.join(); w_prop.join();
+        // (the writers fetch the last 1/64 of the rows behind the loop's last check: a failure there -- a HIP error in a row fetch --
+        // would leave a valid but truncated trace file; it ends the run like any other)
+        if (g_worker_failed.load()) {
+            std::string msg;
+            { std::lock_guard<std::mutex> lk(g_worker_mu); msg = g_worker_msg; }
+            g_stop_workers = nullptr; // (joined above)
+            main_thread_exit(msg);
+        }
         mmg_summary_destroy(summ);
         for (auto sp : smps) mmg_sampler_destroy(sp);
         for (auto pp : dprob) mmg_problem_destroy(pp);

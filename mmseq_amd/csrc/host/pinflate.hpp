@@ -235,7 +235,8 @@ struct Chunk {
 
 // decode from c.start_bit; known_empty_window: chunk 0 (a reference before the start is an error, as in zlib: "invalid distance too far back").
 // targets: ascending candidate starts behind this chunk's; the decode ends on the first of them it meets exactly at an end of block.
-static inline void decode_chunk(const uint8_t *base, const uint8_t *end, Chunk &c, bool known_empty_window, const std::vector<uint64_t> &starts, size_t first_target)
+static inline void decode_chunk(const uint8_t *base, const uint8_t *end, Chunk &c, bool known_empty_window, const std::vector<uint64_t> &starts, size_t first_target,
+                                const std::atomic<bool> *stop = nullptr)
 {
     static thread_local LitCode lit, fixed_lit;
     static thread_local DistCode dist, fixed_dist;
@@ -258,19 +259,24 @@ static inline void decode_chunk(const uint8_t *base, const uint8_t *end, Chunk &
     size_t cap = 1u << 20, o = 0;
     if (first_target < starts.size() && starts[first_target] != ~0ull) cap = std::max<size_t>(cap, (size_t)((starts[first_target] - c.start_bit) / 8) * 3);
     uint16_t *out = (uint16_t *)std::malloc(cap * 2);
-    // (a chunk is held in memory whole, as 16-bit symbols: one that inflates beyond MAX_SYMBOLS -- deflate reaches 1032 : 1 on runs of one
-    // byte -- is refused rather than allowed to take the machine's memory; zlib on one thread streams such a file through fixed buffers)
+    // (a chunk is held in memory whole, as 16-bit symbols: one that inflates beyond MAX_SYMBOLS = 2^30 of them, 2 GB -- deflate reaches
+    // 1032 : 1 on runs of one byte -- is refused rather than allowed to take the machine's memory, and so is one the allocator refuses;
+    // zlib on one thread streams such a file through fixed buffers)
     constexpr size_t MAX_SYMBOLS = (size_t)1 << 30;
-    bool too_big = false;
+    bool too_big = out == nullptr;
     auto grow = [&](size_t need) {
         while (o + need > cap) cap *= 2;
-        if (cap > MAX_SYMBOLS * 2) { too_big = true; cap = o + need + 1024; }
-        out = (uint16_t *)std::realloc(out, cap * 2);
+        if (cap > MAX_SYMBOLS) { too_big = true; return; }
+        uint16_t *bigger = (uint16_t *)std::realloc(out, cap * 2);
+        if (!bigger) { too_big = true; return; } // (out stays valid and is freed with the chunk)
+        out = bigger;
     };
     auto finish = [&]() { c.sym_buf = out; c.sym_len = o; c.end_bit = in.bitpos(); };
     size_t tgt = first_target;
     auto fail = [&]() { c.failed = true; finish(); };
+    if (too_big) { c.too_big = true; return fail(); }
     for (;;) {
+        if (stop && stop->load(std::memory_order_relaxed)) return fail(); // the stream is being torn down: nobody will read this chunk
         // at a block boundary: have we arrived where the next chunk starts?
         const uint64_t pos = in.bitpos();
         while (tgt < starts.size() && (starts[tgt] == ~0ull || starts[tgt] < pos)) ++tgt;
@@ -351,7 +357,9 @@ static inline void decode_chunk(const uint8_t *base, const uint8_t *end, Chunk &
 // a time (zero copy: the buffer stays valid until the next call).  error() is non-empty after a failure (then next() returns false).
 class Stream {
 public:
-    Stream(const uint8_t *data, size_t size, int threads, size_t chunk_bytes) : base(data), end(data + size), T(threads < 1 ? 1 : threads)
+    // start_now = false: only the candidate block starts are searched (cheap); the decode begins with start() -- a caller that may still
+    // turn the stream down (longest_stretch_bytes) does so before any worker holds gigabytes of symbols
+    Stream(const uint8_t *data, size_t size, int threads, size_t chunk_bytes, bool start_now = true) : base(data), end(data + size), T(threads < 1 ? 1 : threads)
     {
         if (size < 6 || (data[0] & 0x0f) != 8 || ((data[0] << 8 | data[1]) % 31) != 0 || (data[1] & 0x20)) { err = "not a zlib stream"; done_all = true; return; }
         if (chunk_bytes < 64) chunk_bytes = 64;
@@ -375,11 +383,16 @@ public:
         for (size_t i = 0; i < chunks.size(); ++i) chunks[i].start_bit = starts[i];
         for (size_t i = 1; i < chunks.size(); ++i) if (starts[i] == ~0ull) chunks[i].state = 7; // no candidate: the chunk before runs through
         chunks[0].window_in.assign(32768, 0);
+        if (start_now) start();
+    }
+    void start()
+    {
+        if (!workers.empty() || done_all) return;
         for (int t = 0; t < T; ++t) workers.emplace_back([this] { work(); });
     }
     ~Stream()
     {
-        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        { std::lock_guard<std::mutex> lk(mu); stop = true; stop_flag.store(true); }
         cv.notify_all();
         for (auto &w : workers) w.join();
         for (Chunk &c : chunks) std::free(c.sym_buf);
@@ -514,7 +527,7 @@ private:
                 Chunk &c = chunks[todo];
                 c.state = 1;
                 lk.unlock();
-                decode_chunk(base, end, c, todo == 0, starts, todo + 1);
+                decode_chunk(base, end, c, todo == 0, starts, todo + 1, &stop_flag);
                 lk.lock();
                 c.state = 2;
                 chain();
@@ -553,6 +566,7 @@ private:
     uint64_t expect_bit = 16;
     size_t chain_at = 0, decode_at = 0, resolve_from = 0, read_at = 0, adler_at = 0, last_chunk = 0, held = (size_t)-1;
     bool stream_ended = false, stop = false, done_all = false;
+    std::atomic<bool> stop_flag{false}; // `stop` for the decoders, which run without the lock (polled once per deflate block)
     uint32_t total_adler = 1;
     std::string err;
     std::mutex mu;

@@ -12,6 +12,7 @@
 struct mmg_problem {
     int device = 0;
     uint64_t m = 0, nnz = 0, total_k = 0, row_id_base = 0, device_bytes = 0;
+    uint64_t total_k_hit = 0;                   // the reads of the rows with at least one hit: what a sweep allocates (an empty row gets no count)
     uint32_t n = 0, max_row_len = 0;
     bool idx64 = false;
     int cu_count = 256;
@@ -74,6 +75,7 @@ struct mmg_problem {
     bool order_derived = false;                 // the renumbering came from the hit graph (order.hip), not from the caller's tx_order
     bool k1_fixed_walk = false;    // the k = 1 sample kernel's straight-line instantiation (fewer than 5 groups per register-path tile on average)
     bool groups_reordered = false; // tx_order given and the library reordered its groups (spec version 7)
+    bool order_skipped = false;    // an order from the hit graph was called for but not tried (device memory) or could not be built: the caller's order stands
     bool renumbered() const { return !h_int_of_ext.empty(); }
 };
 

@@ -179,7 +179,7 @@ struct SynthArgs {
 // the family bijection of the gene-block generator: a multiplier coprime to n_genes derived from the seed, and its inverse
 MMG_TYPES_HD inline void synth_family_params(uint64_t seed, uint32_t n_genes, uint32_t *a, uint32_t *ainv)
 {
-    if (n_genes < 2) { *a = 1; *ainv = 1 % (n_genes ? n_genes : 1); return; }
+    if (n_genes < 3) { *a = 1; *ainv = 1 % (n_genes ? n_genes : 1); return; } // (2 genes: no multiplier in [2, 2] is coprime to 2 -- the search below would not end: the identity)
     uint64_t x = (seed + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
     x ^= x >> 31;
     uint64_t m = 2 + x % (n_genes - 1 ? n_genes - 1 : 1);

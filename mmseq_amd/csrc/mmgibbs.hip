@@ -573,14 +573,22 @@ extern "C" int mmg_problem_create(const mmg_problem_desc *d, int device, mmg_pro
             // 4 GB); without that much free, and on any failure below, p stays.
             size_t free_b = 0, total_b = 0;
             const size_t need = 3 * (size_t)p->device_bytes + std::min<size_t>((size_t)4 << 30, 32 * (size_t)p->nnz + ((size_t)64 << 20));
+            // (What stands then is the problem in the caller's order: the chain of such a problem depends on whether the attempt could be
+            // made.  mmg_problem_info.tx_renumbered carries MMG_ORDER_SKIPPED in that case; MMG_OPT_DERIVE_ORDER = 1 -- "always" -- fails.)
+            const bool forced = opt(MMG_OPT_DERIVE_ORDER) == 1;
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need) {
                 (void)hipGetLastError();
+                if (forced) { problem_free(p); return fail(MMG_ERR_HIP, "transcript order from the hit graph: needs " + std::to_string(need >> 20) + " MiB of free device memory, " + std::to_string(free_b >> 20) + " MiB are free"); }
+                p->order_skipped = true;
                 *out = p;
                 return MMG_OK;
             }
             std::vector<uint64_t> edges;
             hipError_t e = order_cooccurrence_edges(p->idx64, p->m, p->nnz, p->d_row_ptr, p->d_col, edges, 0); // (no tx_order: device ids are the caller's)
-            if (e != hipSuccess) { (void)hipGetLastError(); edges.clear(); }
+            if (e != hipSuccess) {
+                if (forced) { problem_free(p); return fail(MMG_ERR_HIP, std::string("transcript order from the hit graph: ") + hipGetErrorString(e)); }
+                (void)hipGetLastError(); edges.clear(); p->order_skipped = true;
+            }
             // (a graph in which the average transcript shares rows with more than 1024 others has no band to find: hits drawn all over
             // the transcriptome -- the level structures of 10^8 edges would only cost host time before the result is discarded)
             if (!edges.empty() && edges.size() <= (uint64_t)d->n * 1024) {
@@ -590,7 +598,8 @@ extern "C" int mmg_problem_create(const mmg_problem_desc *d, int device, mmg_pro
                 std::vector<uint64_t> keys(pos.begin(), pos.end());
                 mmg_problem *q = nullptr;
                 rc = problem_create_checked(d, device, keys.data(), &q);
-                if (rc) { (void)hipGetLastError(); q = nullptr; rc = MMG_OK; } // (problem_create_checked frees what it built)
+                if (rc && forced) { problem_free(p); return rc; }
+                if (rc) { (void)hipGetLastError(); q = nullptr; rc = MMG_OK; p->order_skipped = true; } // (problem_create_checked frees what it built)
                 if (q && modelled_sweep_cost(q) < modelled_sweep_cost(p) - modelled_sweep_cost(p) / 5) { problem_free(p); p = q; p->order_derived = true; }
                 else if (q) problem_free(q);
             }
@@ -611,7 +620,14 @@ extern "C" int mmg_problem_create(const mmg_problem_desc *d, int device, mmg_pro
             const uint32_t nG = (uint32_t)uniq.size();
             size_t free_b = 0, total_b = 0;
             const size_t need = 3 * (size_t)p->device_bytes + std::min<size_t>((size_t)4 << 30, 32 * (size_t)p->nnz + ((size_t)64 << 20));
-            if (nG > 1 && nG < d->n && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= need) {
+            const bool forced = opt(MMG_OPT_DERIVE_ORDER) == 1;
+            const bool have_mem = hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= need;
+            if (nG > 1 && nG < d->n && !have_mem) {
+                (void)hipGetLastError();
+                if (forced) { problem_free(p); return fail(MMG_ERR_HIP, "group order from the hit graph: needs " + std::to_string(need >> 20) + " MiB of free device memory, " + std::to_string(free_b >> 20) + " MiB are free"); }
+                p->order_skipped = true;
+            }
+            if (nG > 1 && nG < d->n && have_mem) {
                 std::vector<uint32_t> group_of_ext(d->n), label(d->n);
                 for (uint32_t t = 0; t < d->n; ++t) group_of_ext[t] = (uint32_t)(std::lower_bound(uniq.begin(), uniq.end(), gkeys[t]) - uniq.begin());
                 for (uint32_t i = 0; i < d->n; ++i) label[i] = group_of_ext[p->h_ext_of_int[i]];   // device column id -> group
@@ -621,7 +637,10 @@ extern "C" int mmg_problem_create(const mmg_problem_desc *d, int device, mmg_pro
                 if (e == hipSuccess) e = hipMemcpy(d_label, label.data(), (size_t)d->n * 4, hipMemcpyHostToDevice);
                 if (e == hipSuccess) e = order_cooccurrence_edges(p->idx64, p->m, p->nnz, p->d_row_ptr, p->d_col, edges, 0, d_label);
                 if (d_label) (void)hipFree(d_label);
-                if (e != hipSuccess) { (void)hipGetLastError(); edges.clear(); }
+                if (e != hipSuccess) {
+                    if (forced) { problem_free(p); return fail(MMG_ERR_HIP, std::string("group order from the hit graph: ") + hipGetErrorString(e)); }
+                    (void)hipGetLastError(); edges.clear(); p->order_skipped = true;
+                }
                 if (!edges.empty() && edges.size() <= (uint64_t)nG * 1024) {
                     std::vector<uint32_t> posg;
                     order_from_edges(nG, edges, posg);
@@ -630,11 +649,12 @@ extern "C" int mmg_problem_create(const mmg_problem_desc *d, int device, mmg_pro
                     for (uint32_t t = 0; t < d->n; ++t) keys[t] = ((uint64_t)posg[group_of_ext[t]] << 32) | p->h_int_of_ext[t];
                     mmg_problem *q = nullptr;
                     rc = problem_create_checked(d, device, keys.data(), &q);
-                    if (rc) { (void)hipGetLastError(); q = nullptr; rc = MMG_OK; }
+                    if (rc && forced) { problem_free(p); return rc; }
+                    if (rc) { (void)hipGetLastError(); q = nullptr; rc = MMG_OK; p->order_skipped = true; }
                     if (q && modelled_sweep_cost(q) < modelled_sweep_cost(p) - modelled_sweep_cost(p) / 5) { problem_free(p); p = q; p->groups_reordered = true; }
                     else if (q) problem_free(q);
                 }
-            } else (void)hipGetLastError();
+            }
         }
     }
     *out = p;
@@ -650,7 +670,11 @@ static int problem_create_checked(const mmg_problem_desc *d, int device, const u
     p->device = device;
     p->m = d->m; p->n = d->n; p->nnz = nnz; p->row_id_base = d->row_id_base; p->layout = (int)d->layout;
     p->h_l.assign(d->l, d->l + d->n);
-    if (d->k) { for (uint64_t r = 0; r < d->m; ++r) p->total_k += d->k[r]; } else p->total_k = d->m;
+    for (uint64_t r = 0; r < d->m; ++r) {
+        const uint64_t kr = d->k ? d->k[r] : 1;
+        p->total_k += kr;
+        if (d->row_ptr[r + 1] > d->row_ptr[r]) p->total_k_hit += kr;
+    }
     uint64_t *d_rp64 = nullptr;
     auto bail = [&](int code) { if (d_rp64) (void)hipFree(d_rp64); problem_free(p); return code; };
 #define C_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return bail(fail(MMG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); } while (0)
@@ -753,7 +777,15 @@ extern "C" int mmg_problem_shard(const mmg_problem *full, uint64_t lo, uint64_t 
         std::vector<uint32_t> hk(p->m); // total_k of the shard (one pass over its multiplicities)
         SH_TRY(hipMemcpy(hk.data(), p->d_k, p->m * sizeof(uint32_t), hipMemcpyDeviceToHost));
         for (uint32_t v : hk) p->total_k += v;
-    } else p->total_k = p->m;
+        std::vector<uint64_t> hrp(p->m + 1); // ... and of its rows with a hit (the wire check of a group compares a sweep's counts with them)
+        SH_TRY(hipMemcpy(hrp.data(), d_rp64, (p->m + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        for (uint64_t r = 0; r < p->m; ++r) if (hrp[r + 1] > hrp[r]) p->total_k_hit += hk[r];
+    } else {
+        p->total_k = p->m;
+        std::vector<uint64_t> hrp(p->m + 1);
+        if (p->m) SH_TRY(hipMemcpy(hrp.data(), d_rp64, (p->m + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        for (uint64_t r = 0; r < p->m; ++r) p->total_k_hit += hrp[r + 1] > hrp[r];
+    }
     SH_TRY(hipMalloc((void **)&p->d_l, p->n * sizeof(double)));
     {
         std::vector<double> l_int;
@@ -1014,7 +1046,7 @@ extern "C" int mmg_problem_create_synthetic(const mmg_synth_desc *d, int device,
     if (!(cdf[d->n - 1] > 0.0)) return fail(MMG_ERR_ARG, "synthetic abundance table is all zero");
     mmg_problem *p = new mmg_problem();
     p->device = device;
-    p->m = d->rows; p->n = d->n; p->row_id_base = d->row0; p->total_k = d->rows;
+    p->m = d->rows; p->n = d->n; p->row_id_base = d->row0; p->total_k = d->rows; p->total_k_hit = d->rows; // (a generated row has at least one hit)
     p->layout = d->sorted ? (int)MMG_LAYOUT_CANONICAL : (int)MMG_LAYOUT_KEEP_ROWS;
     const double N = (double)(d->mapped_reads ? d->mapped_reads : d->rows);
     p->h_l.resize(d->n);
@@ -1075,7 +1107,7 @@ extern "C" int mmg_problem_info_get(const mmg_problem *p, mmg_problem_info *info
     info->far_tiles = p->n_far_tiles;
     info->padded_slots = p->padded_slots;
     info->layout = p->layout;
-    info->tx_renumbered = p->renumbered() ? (p->order_derived ? 2 : (p->groups_reordered ? 3 : 1)) : 0;
+    info->tx_renumbered = (p->renumbered() ? (p->order_derived ? 2 : (p->groups_reordered ? 3 : 1)) : 0) | (p->order_skipped ? MMG_ORDER_SKIPPED : 0);
     info->sample_grid = p->use_sell ? p->grid_sell : p->grid_sample;
     info->cu_count = p->cu_count;
     return MMG_OK;

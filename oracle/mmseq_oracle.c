@@ -1096,7 +1096,7 @@ uint32_t orc_synth_row_len(uint64_t seed, uint64_t row, const double *len_cdf)
  * derived from the seed, and its inverse (mmg_types.h: synth_family_params restates this). */
 void orc_synth_family_params(uint64_t seed, uint32_t n_genes, uint32_t *a, uint32_t *ainv)
 {
-    if (n_genes < 2) { *a = 1; *ainv = 1 % (n_genes ? n_genes : 1); return; }
+    if (n_genes < 3) { *a = 1; *ainv = 1 % (n_genes ? n_genes : 1); return; } /* (2 genes: no multiplier in [2, 2] is coprime to 2: the identity) */
     uint64_t x = (seed + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
     x ^= x >> 31;
     const uint64_t span = n_genes - 1 ? n_genes - 1 : 1;

@@ -129,6 +129,22 @@ def test_a_groups_first_exchanges_are_verified_against_the_hosts_own_reduction(g
         mu_g, ll_g = grp.em([prob], mu0, 5)                       # every exchange of the EM (column counts, exponents, accumulators) checked once
         assert np.array_equal(mu_g, mu_o) and ll_g == ll_o
         s.close(); grp.close()
+        # empty rows (allowed: row_ptr only non-decreasing) carry reads that no sweep allocates -- the check's "every read counted once"
+        # clause counts the reads of the rows WITH hits -- next to multiplicities on both sides of the chain's boundary
+        rng = np.random.default_rng(3)
+        cut = np.sort(rng.choice(np.arange(1, p.m), size=40, replace=False))
+        rp_e = np.insert(p.row_ptr, cut, p.row_ptr[cut])
+        k_e = rng.choice([1, 1, 2, 7, 70, 3000], size=rp_e.size - 1).astype(np.uint32)
+        prob_e = gpu.Problem.from_csr(rp_e, p.col_idx, p.l, k=k_e)
+        assert prob_e.info.total_k == int(k_e.astype(np.int64).sum())
+        d_rp, d_ci, d_k = prob_e.download(with_k=True)
+        pe = orc.Problem(d_rp, d_ci, p.l, k=d_k)
+        ref_e = orc.gibbs_keyed(pe, mu0, seed=6, chain=0, n_iter=4, trace_len=4)
+        grp = gpu.Group([0])
+        se = gpu.Sampler(prob_e, mu0, seed=6, gibbs_iter=4, trace_len=4)
+        grp.run_sharded([se], 4)
+        assert np.array_equal(se.trace(0), ref_e["trace"]) and int(se.counts(0).astype(np.int64).sum()) < prob_e.info.total_k
+        se.close(); grp.close(); prob_e.close()
     with gpu.options(wire_check=2):
         grp = gpu.Group([0])
         s = gpu.Sampler(prob, mu0, seed=5, gibbs_iter=8, trace_len=8)
