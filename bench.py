@@ -654,6 +654,10 @@ def main():
             roof["em_sweep_ms"] = g("em", "ms_per_sweep")
             roof["em_hbm_frac"] = (other.get("em") or {}).get("frac")
             roof["real8_chain_it_s"] = g("real8", "chain_it_s")
+            # the regime every real (collapsed) hits file runs in: hit sets with multiplicities (src/mmseq.cpp:409-440, the draw :880)
+            roof["heavy_ms"] = g("heavy", "ms_per_step")
+            roof["collapsed_ms"] = g("collapsed", "ms_per_step")
+            roof["collapsed_alg_frac"] = g("collapsed", "alg_frac")
             roof["far20_ms"] = g("far20", "ms_per_step")
             roof["gene0_ms"] = g("gene0", "ms_per_step")
             roof["far20p_ms"] = g("far20p", "ms_per_step")

@@ -55,7 +55,7 @@ void launch_start_values(bool idx64, const void *row_ptr, const uint32_t *col, c
                          uint64_t *acc3, int32_t *unique_hits, hipStream_t s)
 {
     if (!m) return;
-    const unsigned g = (unsigned)((m + 255) / 256);
+    const unsigned g = (unsigned)((m + SV_ROWS - 1) / SV_ROWS);
     if (idx64) hipLaunchKernelGGL(k_start_values<uint64_t>, dim3(g), dim3(256), 0, s, (const uint64_t *)row_ptr, col, k, m, n, acc3, unique_hits);
     else hipLaunchKernelGGL(k_start_values<uint32_t>, dim3(g), dim3(256), 0, s, (const uint32_t *)row_ptr, col, k, m, n, acc3, unique_hits);
 }
