@@ -156,17 +156,16 @@ static hipError_t upload_ranges(const std::vector<uint64_t> &chunk, const std::v
     return e;
 }
 
-// List entries per workgroup of k_sample_bigk (one wave; a lane that finishes a row fetches the next of the piece).  Long pieces keep the
-// lanes busy (the last rows of a piece run in a thinning wave), but every SIMD should have waves to interleave: about BIGK_WAVES_PER_SIMD
-// pieces per SIMD of the device, between 64 and 512 entries each: a full wave per piece even when that leaves SIMDs without one (the phases
-// of a thin wave run for a handful of lanes each: what a launch costs is the instructions per SIMD, and those go with the runs).
-constexpr uint64_t BIGK_WAVES_PER_SIMD = 3;
+// List entries per workgroup of k_sample_bigk (one wave): 64 -- a row per lane, no second helping.  Measured (profiles/r06_bigk_ab.md):
+// longer pieces, whose lanes fetch the next row when they finish one, lose to it at every list length (2 M rows: 1.17 ms at 64, 1.18 /
+// 1.21 / 1.36 at 128 / 256 / 512; 262 k rows: 0.33 ms at 64, 0.36 / 0.40 / 0.47 at 96 / 128 / 192) -- the canonical order already puts rows
+// of equal length side by side, and many short waves balance the SIMDs better than few long ones; thinner waves (16 rows) run every phase
+// for a handful of lanes.  MMG_OPT_BIGK_PER_WAVE overrides (tests run 1 ... 300 entries per wave).
 static uint32_t bigk_piece(uint64_t n_list, int cu_count)
 {
+    (void)n_list; (void)cu_count;
     if (opt(MMG_OPT_BIGK_PER_WAVE) >= 1) return (uint32_t)opt(MMG_OPT_BIGK_PER_WAVE);
-    const uint64_t waves = (uint64_t)cu_count * 4 * BIGK_WAVES_PER_SIMD;
-    const uint64_t per = (n_list + waves - 1) / waves;
-    return (uint32_t)std::min<uint64_t>(512, std::max<uint64_t>(64, per));
+    return 64;
 }
 
 // Sliced-ELL stream: tiles of <= 64 rows that never cross a (near, band) boundary of the canonical order, one window per tile.
