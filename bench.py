@@ -231,7 +231,7 @@ def cpu_baseline(args, prob, mu0, device=0):
 
 
 def side_measurement(name, rows, transcripts, avg_hits, chains=1, uniform=False, sort=True, far_fraction=0.0, steps=48, warmup=8,
-                     seed=1234, device=0, note="", multiplicities=False, scatter=False, genes=None):
+                     seed=1234, device=0, note="", multiplicities=False, scatter=False, genes=None, families=False):
     """One more workload, same protocol (inputs resident, HIP events on the launch stream), shorter: ms per sweep and which kernel ran.
     multiplicities: the rows get a k array with the distribution a collapsed 50 M-read file of this generator has (93.6 % k = 1,
     5.3 % k = 2, ... 0.12 % k in 9..36: tools/collapse_probe.py) -- what every real hits file produces (src/mmseq.cpp:409-418)."""
@@ -250,8 +250,15 @@ def side_measurement(name, rows, transcripts, avg_hits, chains=1, uniform=False,
         l = prob.l()
         prob.close()
         t_ids = np.arange(transcripts, dtype=np.uint64)
+        tx_order = ((t_ids // np.uint64(genes[0])) << np.uint64(32)) | t_ids
+        fam_info = None
+        if families:
+            # paralogue families with a power-law size distribution (32 ... 5 000 transcripts, members scattered over the caller's gene order,
+            # a read's second gene a NEIGHBOUR in its family) and 1 % of the reads on 50 hub transcripts: mmseq_amd/families.py
+            from mmseq_amd import families as fam
+            rp, ci, tx_order, fam_info = fam.power_law_families(rp, ci, transcripts, genes[0], seed=seed)
         t1 = time.perf_counter()
-        prob = Problem.from_csr(rp, ci, l, device=device, tx_order=((t_ids // np.uint64(genes[0])) << np.uint64(32)) | t_ids)
+        prob = Problem.from_csr(rp, ci, l, device=device, tx_order=tx_order)
         scatter_create_s = time.perf_counter() - t1
         del rp, ci
     if scatter:
@@ -333,6 +340,8 @@ def side_measurement(name, rows, transcripts, avg_hits, chains=1, uniform=False,
     if scatter or genes:
         out["tx_renumbered"] = inf.tx_renumbered
         out["create_s"] = round(scatter_create_s, 2)
+    if genes and families:
+        out["families"] = fam_info
     smp.close()
     prob.close()
     return out
@@ -374,6 +383,8 @@ SIDE = [
      dict(rows=R3, transcripts=T3, avg_hits=H3, genes=(32, 3), steps=32)),
     ("far20p", "the same with 20 % of the reads also hitting a gene of their paralogue family (3 genes, anywhere in the caller's gene order): the library reorders the genes",
      dict(rows=R3, transcripts=T3, avg_hits=H3, genes=(32, 3), far_fraction=0.2, steps=32)),
+    ("families_pl", "the same gene blocks with paralogue families of power-law size (32 ... 5 000 transcripts, scattered over the caller's gene order; 20 % of their reads also hit a neighbouring member) and 1 % of the reads on 50 hub transcripts",
+     dict(rows=R3, transcripts=T3, avg_hits=H3, genes=(32, 0), families=True, steps=32)),
     ("uniform", "50M x 200k, hits uniform over all transcripts (SURVEY App. D worst case)", dict(rows=R3, transcripts=T3, avg_hits=H3, uniform=True, steps=8, warmup=2)),
     ("keeprows", "50M x 200k, rows kept in generator order (MMG_LAYOUT_KEEP_ROWS)", dict(rows=R3, transcripts=T3, avg_hits=H3, sort=False, steps=8, warmup=2)),
     ("scatter", "50M x 200k, transcripts numbered at random (first-seen numbering), rows in generator order, NO tx_order: order derived from the hit graph",
@@ -662,6 +673,8 @@ def main():
             roof["gene0_ms"] = g("gene0", "ms_per_step")
             roof["far20p_ms"] = g("far20p", "ms_per_step")
             roof["far20p_far_tiles"] = g("far20p", "far_tiles")
+            roof["families_pl_ms"] = g("families_pl", "ms_per_step")
+            roof["families_pl_far_tiles"] = g("families_pl", "far_tiles")
             roof["uniform_ms"] = g("uniform", "ms_per_step")
             roof["keeprows_ms"] = g("keeprows", "ms_per_step")
             roof["scatter_no_tx_order_ms"] = g("scatter", "ms_per_step")

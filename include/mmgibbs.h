@@ -74,7 +74,11 @@ extern "C" {
  *      MMG_K_SMALL < k <= MMG_K_DRAWS_PER_HIT * (hits - 1), with k > MMG_K_DRAWS_PER_HIT * (hits - 1) on rows of 2-4 hits, or with
  *      k >= 2 on rows of one hit differ from version 7.  tests/golden/keyed_chain_tiny.json has no such row and is byte for byte what
  *      it was; keyed_chain_k_draws.json was regenerated for the new boundary (tools/gen_golden.py).  The conditional binomials themselves
- *      (mmg_math.h: binomial) are unchanged, uniform for uniform.  MMG_OPT_BIGK_PER_WAVE, MMG_OPT_BIGK_SIDE_STREAM. */
+ *      (mmg_math.h: binomial) are unchanged, uniform for uniform.  MMG_OPT_BIGK_PER_WAVE, MMG_OPT_BIGK_SIDE_STREAM.
+ *      Also version 8: in the GROUP-level hit graph of version 7 a group that shares rows with more than max(32, 8 x the median) other groups
+ *      is a hub (version 7: max(256, ...), the transcript-level rule) and stays out of the traversal -- a gene whose repeat-bearing UTR
+ *      collects reads of hundreds of genes no longer ties the paralogue families into one component.  Stored order and chain of problems
+ *      with such groups differ from version 7. */
 /* Layout.  The model does not care about the order of rows or the numbering of transcripts (src/mmseq.cpp:399-418 uses
  * first-seen order for both); the kernels do: they keep a window of consecutive transcripts in LDS and want the 64 rows of a
  * wave to have equal lengths.  mmg_problem_create therefore stores the rows in a CANONICAL order of its own (sorted on the

@@ -69,7 +69,7 @@ double host_start_value(uint64_t a0, uint64_t a1, uint64_t a2, double l);
 hipError_t order_cooccurrence_edges(bool idx64, uint64_t m, uint64_t nnz, const void *d_rp, const uint32_t *d_col, std::vector<uint64_t> &edges, hipStream_t s,
                                     const uint32_t *d_label = nullptr);
 // pos[t] = position of transcript t in the derived order (level structures from pseudo-peripheral vertices; host code)
-void order_from_edges(uint32_t n, const std::vector<uint64_t> &edges, std::vector<uint32_t> &pos);
+void order_from_edges(uint32_t n, const std::vector<uint64_t> &edges, std::vector<uint32_t> &pos, uint32_t hub_floor = 256);
 
 // ---- layout.hip: the canonical row order (mmg_types.h) on the device
 // Row keys of the CSR in its current order.  d_key: m u64 (caller frees).

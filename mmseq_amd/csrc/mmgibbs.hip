@@ -642,7 +642,7 @@ extern "C" int mmg_problem_create(const mmg_problem_desc *d, int device, mmg_pro
                 }
                 if (!edges.empty() && edges.size() <= (uint64_t)nG * 1024) {
                     std::vector<uint32_t> posg;
-                    order_from_edges(nG, edges, posg);
+                    order_from_edges(nG, edges, posg, 32); // (groups: a gene linked to more than 32 others is a hub, spec version 8)
                     std::vector<uint64_t>().swap(edges);
                     std::vector<uint64_t> keys(d->n);
                     for (uint32_t t = 0; t < d->n; ++t) keys[t] = ((uint64_t)posg[group_of_ext[t]] << 32) | p->h_int_of_ext[t];

@@ -118,26 +118,28 @@ hipError_t order_cooccurrence_edges(bool idx64, uint64_t m, uint64_t nnz, const 
 }
 
 // Position of every transcript in the derived order: pos[t] for t < n (a permutation of 0..n-1).  edges: sorted unique u << 32 | v.
-//   hubs       a transcript that shares rows with far more others than is usual (more than max(256, 8 x the median degree of the linked
+//   hubs       a transcript that shares rows with far more others than is usual (more than max(hub_floor, 8 x the median degree of the linked
 //              transcripts): a repeat element, a ubiquitous paralogue) would tie every gene family into one component whose level
-//              structure fans out from it; it is left out of the traversal and placed behind everything (its rows get a far hit)
+//              structure fans out from it; it is left out of the traversal and placed behind everything (its rows get a far hit).
+//              hub_floor: 256 for a graph of transcripts (the isoforms and window neighbours of a transcript are a hundred-odd), 32 for a
+//              graph of GROUPS (a gene that shares reads with more than 32 other genes is no family member: spec version 8)
 //   a level    is ordered by (position of the FIRST parent in the level before it, number of parents: most first, degree, index): the
 //              children of one parent stay together -- gene families, trees -- and in a band every vertex has its own first parent
 //              (the vertex 64 before it), which puts the level in the order of the band
-void order_from_edges(uint32_t n, const std::vector<uint64_t> &edges, std::vector<uint32_t> &pos)
+void order_from_edges(uint32_t n, const std::vector<uint64_t> &edges, std::vector<uint32_t> &pos, uint32_t hub_floor)
 {
     std::vector<uint64_t> ptr(n + 1, 0);
     for (uint64_t k : edges) ptr[(k >> 32) + 1]++;
     for (uint32_t v = 0; v < n; ++v) ptr[v + 1] += ptr[v];
     auto deg = [&](uint32_t v) { return (uint32_t)(ptr[v + 1] - ptr[v]); };
     auto nb = [&](uint64_t i) { return (uint32_t)edges[i]; };          // edges are sorted by u: the adjacency list of u is a slice
-    uint32_t hub_deg = 256;
+    uint32_t hub_deg = hub_floor;
     {
         std::vector<uint32_t> dd;
         for (uint32_t v = 0; v < n; ++v) if (deg(v)) dd.push_back(deg(v));
         if (!dd.empty()) {
             std::nth_element(dd.begin(), dd.begin() + dd.size() / 2, dd.end());
-            hub_deg = std::max<uint32_t>(256u, 8u * dd[dd.size() / 2]);
+            hub_deg = std::max<uint32_t>(hub_floor, 8u * dd[dd.size() / 2]);
         }
     }
     std::vector<uint32_t> stamp(n, 0), level, next, order;

@@ -124,6 +124,49 @@ def test_reads_that_also_hit_a_paralogue_family_get_a_gene_order_that_brings_the
     uni.close(); again.close(); s.close(); prob.close()
 
 
+def test_power_law_families_and_hub_transcripts_get_a_gene_order_that_keeps_neighbours_together(gpu, orc):
+    """A hit graph with the tail of a real transcriptome (mmseq_amd/families.py; src/bam2hits.cpp:271-300 keeps up to 100 alignments per
+    read): paralogue families of power-law size -- up to 5 000 transcripts, far more than an LDS window -- scattered over the caller's gene
+    order, a read's second gene a neighbour in its family's chain, and 1 % of the reads on hub transcripts that share rows with hundreds of
+    genes.  Spec version 7's gene order from the group-level hit graph lays a large family out as a run of windows (breadth-first levels
+    from a pseudo-peripheral member; the hubs are left out of the traversal): nearly all paralogue rows become near rows, the decision
+    is reported (tx_renumbered 3), and the chain on the stored rows is the oracle's bit for bit."""
+    from mmseq_amd import families as fam
+    R, T, G = 60000, 12000, 16
+    gen = gpu.Problem.synthetic(R, T, 6.0, seed=77, sort=False, gene_size=G)
+    rp, ci = gen.download()
+    l = gen.l()
+    gen.close()
+    rp2, ci2, tx_order, info = fam.power_law_families(rp, ci, T, G, seed=5, max_family_transcripts=5000, n_hubs=3)   # (3 hubs at this size: 200 reads each)
+    assert info["largest_family_transcripts"] >= 1000 and 0.1 < info["paralogue_reads"] < 0.25 and 0.005 < info["hub_reads"] < 0.02
+    def far_rows(pr):
+        # share of the stored rows that do not fit one window in the DEVICE numbering (mmg_types.h: near).  (The tile counts of
+        # mmg_problem_info say little at this size: every band with a far row has a far tile, however few rows it holds.)
+        d_rp, d_ci = pr.download()
+        dev = pr.tx_perm()[d_ci].astype(np.int64)
+        st = d_rp[:-1].astype(np.int64)
+        lo, hi = np.minimum.reduceat(dev, st), np.maximum.reduceat(dev, st)
+        return float((hi - (lo & ~63) >= 240).mean())
+    with gpu.options(derive_order=0):
+        plain = gpu.Problem.from_csr(rp2, ci2, l, tx_order=tx_order)        # the caller's gene order: a paralogue read spans the transcriptome
+        i0, far0 = plain.info, far_rows(plain)
+        plain.close()
+    prob = gpu.Problem.from_csr(rp2, ci2, l, tx_order=tx_order)
+    inf, far1 = prob.info, far_rows(prob)
+    assert (i0.tx_renumbered & 0xff) == 1 and far0 > 0.12
+    assert (inf.tx_renumbered & 0xff) == 3 and inf.sample_kernel == 2 and far1 < 0.04, (far0, far1, inf.far_tiles, i0.far_tiles, inf.n_tiles)
+    q_rp, q_ci = prob.download()
+    p = orc.Problem(q_rp, q_ci, l)
+    mu0, _ = prob.start_values()
+    assert np.array_equal(mu0, orc.start_values_exact(p))
+    s = gpu.Sampler(prob, mu0, seed=3, n_chains=2, gibbs_iter=6, trace_len=6)
+    s.run(6)
+    for c in range(2):
+        ref = orc.gibbs_keyed(p, mu0, seed=3, chain=c, n_iter=6, trace_len=6)
+        assert np.array_equal(s.counts(c), ref["cnt"]) and np.array_equal(s.trace(c), ref["trace"])
+    s.close(); prob.close()
+
+
 def test_first_seen_numbering_with_tx_order_takes_the_fast_kernel(gpu, orc):
     """The reference numbers transcripts in first-seen order (src/mmseq.cpp:399-408), which scatters the isoforms of a gene over
     the index range.  Uploaded like that the rows span the whole range and only the CSR kernel applies; with tx_order (gene
