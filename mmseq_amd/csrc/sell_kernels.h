@@ -184,6 +184,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
     // counts at the stride of the weights (slot i at byte 8 i, the upper word unused): the offset that gathered a weight addresses
     // its count, no shift
     __shared__ int32_t s_cnt[REP * 2 * (WIN + 1)];
+    // Counts of picks OUTSIDE the window (the far hit of a far row, a CSR-walked row's hits elsewhere): a small keyed table for the
+    // workgroup's whole range, flushed with one global atomic per key at the end.  Without it every such pick is a global atomic of its
+    // own, and the popular far targets -- a transcript whose repeat-bearing UTR collects reads of hundreds of genes -- take thousands of
+    // them per sweep at ONE address each, which the memory side serialises: 1 % of the reads on 50 hub transcripts cost K1 +32 %
+    // (tools/families_probe.py; profiles/r06_families_probe.txt).  A key keeps the slot it finds empty (two candidates); a pick whose slots hold other keys
+    // goes to the global vector directly, as before.  (One wave per workgroup: no race beyond the atomics themselves.)
+    constexpr uint32_t FAR_SLOTS = 128, FAR_EMPTY = 0xffffffffu;
+    __shared__ uint32_t s_fkey[FAR_SLOTS];
+    __shared__ int32_t s_fcnt[FAR_SLOTS];
     const uint32_t lane = threadIdx.x;
     // grid.y = chain: the tile lists that only some rows are on (multiplicities, far rows) are walked for every chain of a sampler
     // in one launch -- their launches are bound by a few long rows, eight of them side by side fill the GPU eight times better
@@ -203,6 +212,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
     const SellTile *__restrict__ T = tiles + t_begin;
 
     for (int i = lane; i < REP * 2 * (WIN + 1); i += 64) s_cnt[i] = 0;
+    for (uint32_t i = lane; i < FAR_SLOTS; i += 64) { s_fkey[i] = FAR_EMPTY; s_fcnt[i] = 0; }
+    auto far_add = [&](uint32_t col, int32_t x) {
+        // two candidate slots per key (the cold far targets of paralogue rows come first and sit in the table too: with one slot per key a
+        // sixth of the hot ones found theirs taken)
+        const uint32_t slot = (col * 0x9E3779B1u) >> 25; // 7 bits
+        uint32_t old = atomicCAS(&s_fkey[slot], FAR_EMPTY, col);
+        if (old == FAR_EMPTY || old == col) { atomicAdd(&s_fcnt[slot], x); return; }
+        const uint32_t slot2 = ((col * 0x85EBCA6Bu) >> 25) ^ 64u;
+        old = atomicCAS(&s_fkey[slot2], FAR_EMPTY, col);
+        if (old == FAR_EMPTY || old == col) atomicAdd(&s_fcnt[slot2], x);
+        else global_count_add(gcnt, col, x);
+    };
     const uint32_t rep_off = (lane % REP) * (uint32_t)((WIN + 1) * 8);
     if (lane == 0) s_mu[WIN] = 0.0;
 
@@ -515,7 +536,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
         };
         auto off_of = [&](uint32_t j) -> uint32_t { return ((group_of(j >> 2) >> (8u * (j & 3u))) & 0xffu) << 3; };
         auto add = [&](uint32_t off, int32_t x) {
-            if (FAR && off == FAR_PICK) global_count_add(gcnt, farc, x);
+            if (FAR && off == FAR_PICK) far_add(farc, x);
             else atomicAdd((int32_t *)((char *)s_cnt + rep_off + off), x);
         };
         const uint32_t kk = HAS_K ? bf.kk : 1u;
@@ -645,7 +666,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
             auto add = [&](uint32_t col, int32_t x) {
                 const uint32_t dd = col - wbase;
                 if (dd < (uint32_t)WIN) atomicAdd(&s_cnt[2 * dd], x);
-                else global_count_add(gcnt, col, x);
+                else far_add(col, x);
             };
             RowViewGlobalWin<WIN> v{col_idx + st, L, wbase, s_mu, gmu};
             allocate_row<HAS_K, false>(v, add, HAS_K ? kmult[d.r0 + lane] : 1u, a, a.row_id_base + d.r0 + lane);
@@ -661,7 +682,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
             auto add = [&](uint32_t col, int32_t x) {
                 const uint32_t dd = col - wbase;
                 if (dd < (uint32_t)WIN) atomicAdd(&s_cnt[2 * dd], x);
-                else global_count_add(gcnt, col, x);
+                else far_add(col, x);
             };
             const RowViewFarTile v{(const uint32_t *)blk + lane, (const uint32_t *)(fb + 64) + lane, Ln, Ln + fb[lane], wbase, s_mu, gmu};
             allocate_row<HAS_K, false>(v, add, HAS_K ? kmult[d.r0 + lane] : 1u, a, a.row_id_base + d.r0 + lane);
@@ -723,6 +744,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_K ? 5 : 
     }
     __syncthreads();
     flush_window(cur_base);
+    for (uint32_t i = lane; i < FAR_SLOTS; i += 64) {
+        const int32_t v = s_fcnt[i];
+        if (v) global_count_add(gcnt, s_fkey[i], v);
+    }
 }
 
 } // namespace mmg

@@ -48,7 +48,7 @@ def family_tables(T, gene_size, seed, alpha=1.2, max_family_transcripts=5000):
 
 
 def power_law_families(row_ptr, col_idx, T, gene_size, seed=1234, paralogue=0.2, hub=0.01, n_hubs=50, alpha=1.2, max_family_transcripts=5000,
-                       chunk_rows=4_000_000):
+                       chunk_rows=4_000_000, max_distance=None):
     """Adds paralogue and hub hits to rows whose hits lie inside one gene each (see the module text).  Returns (row_ptr u64, col_idx u32,
     tx_order u64, info): info = family sizes in genes, the share of reads that got a paralogue hit and a hub hit."""
     rp = np.asarray(row_ptr).astype(np.int64)
@@ -73,7 +73,9 @@ def power_law_families(row_ptr, col_idx, T, gene_size, seed=1234, paralogue=0.2,
         u = crng.random((4, n))
         par = (Lc > 0) & (fs > 1) & (u[0] < paralogue)
         # the other gene: distance 1 + Geometric(1/2) along the family's chain, towards the side that has room (reflected at the ends)
-        d = 1 + crng.geometric(0.5, size=n) - 1
+        d = crng.geometric(0.5, size=n)
+        if max_distance:
+            d = np.minimum(d, max_distance)
         d = np.minimum(d, fs - 1)
         p0 = pos_of_gene[g0]
         up = u[1] < 0.5

@@ -29,7 +29,7 @@ else:
 prob = Problem.from_csr(rp, ci, l, k=k)
 rp2, ci2, k2 = prob.download(with_k=True)
 L = np.diff(rp2).astype(np.int64)
-big = (L >= 2) & (k2 > 64) & (k2.astype(np.int64) > 16 * (L - 1))
+big = (L >= 2) & (k2.astype(np.int64) > np.minimum(64, 16 * (L - 1)))      # mmg_types.h: bigk_row (spec version 8)
 steps = int((L[big] - 1).sum())
 mu0, _ = prob.start_values()
 s = Sampler(prob, mu0, n_chains=1, gibbs_iter=1024, trace_len=1024, keep_trace=False, timing=1)
