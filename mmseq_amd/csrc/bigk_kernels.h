@@ -14,7 +14,7 @@
 //     BSET   the constants of BTRS;  TRY  one attempt: two uniforms, the candidate, the squeeze
 //     SLOW   the exact acceptance test of an attempt that missed the squeeze
 //     IFULL  the inversion whose uniform may exceed r0: logarithm, exponential, the sequential search
-// A trip of the wave's loop counts the lanes waiting in every phase and runs the phases that hold a third of them or more (the fullest
+// A trip of the wave's loop counts the lanes waiting in every phase and runs the phases that hold a fifth of them or more (the fullest
 // one in any case): the frequent cheap work stays in step, the rare expensive paths wait until they are worth a run.  Lanes are
 // different rows with their own keyed stream (mmg_math.h: Stream2), so a lane may run ahead of its neighbours: the work a lane does, and
 // the uniforms it consumes, are exactly what the sequential loop does for its row -- the same bits as allocate_row / orc_gibbs_keyed --
@@ -36,13 +36,14 @@ __device__ unsigned long long g_bigk_stats[16];
 
 enum : uint32_t { BK_FETCH = 0, BK_STEP = 1, BK_BSET = 2, BK_TRY = 3, BK_SLOW = 4, BK_IFULL = 5, BK_IDLE = 6 };
 // A phase runs in a trip of the wave's loop when it holds at least BK_SHARE_NUM / BK_SHARE_DEN of the lanes that have work (or is the
-// fullest one): a third.  1 / 64 is "every phase that has a lane, every trip" (the shortest dependent chain per row: what a wave with few
-// rows wants), 1 / 1 is "the fullest phase only" (the fewest instructions per row).
+// fullest one): a fifth.  1 / 64 is "every phase that has a lane, every trip" (the shortest dependent chain per row), 1 / 1 is "the fullest
+// phase only" (the fewest instructions per row).  Measured at 64 rows per wave (profiles/r06_bigk_ab.md): 1/2 1.223, 1/3 1.175, 1/5 1.129,
+// 1/8 1.198 ms on 2 M rows of k = 1000; the hit sets of a collapsed file 0.159 / 0.151 / 0.146 / 0.144 ms per sweep.
 #ifndef BK_SHARE_NUM
 #define BK_SHARE_NUM 1
 #endif
 #ifndef BK_SHARE_DEN
-#define BK_SHARE_DEN 3
+#define BK_SHARE_DEN 5
 #endif
 
 template <typename IdxT>
