@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MMG_ABI_VERSION 7
+#define MMG_ABI_VERSION 8
 /* Version history of the SPEC behind the entry points: under one version a chain is a pure function of (problem, tx_order, seed,
  * chain, iteration); a bump means the same inputs may yield different bits (golden fixtures and the oracle move with it).
  *   3  (round 2) rows with 2 <= k <= 64 draw k categoricals (before: k <= 8), sorted by k inside their class.  The constant moved

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libmmgibbs.so does not export %s" % name
     assert sorted(_lib.SYMBOLS) == declared, "python binding table out of sync with include/mmgibbs.h"
-    assert lib.mmg_abi_version() == 7
+    assert lib.mmg_abi_version() == 8
 
 
 def test_struct_layouts_match_header():
