@@ -79,7 +79,7 @@ hipError_t layout_row_keys(uint64_t m, const uint64_t *d_rp, const uint32_t *d_c
 // old ones are freed), d_key holds the sorted keys.  col_pad: extra u32 slots allocated (zeroed) behind col.  m < 2^32.
 hipError_t layout_canonical_sort(uint64_t m, uint64_t nnz, uint64_t **d_rp, uint32_t **d_col, uint32_t **d_k, uint64_t *d_key,
                                  size_t col_pad, hipStream_t s);
-// Canonical layout, step 0: a row with 2 <= k <= K_SMALL becomes k rows with k = 1 (mmg_types.h).  *d_rp / *d_col / *d_k are replaced when
+// Canonical layout, step 0: a row that draws k >= 2 categoricals becomes k rows with k = 1 (mmg_types.h: draws_categoricals).  *d_rp / *d_col / *d_k are replaced when
 // any row expands; *m, *nnz follow; *d_k is freed and set to nullptr when no multiplicity other than 1 is left.
 hipError_t layout_expand_rows(uint64_t *m, uint64_t *nnz, uint64_t **d_rp, uint32_t **d_col, uint32_t **d_k, size_t col_pad, hipStream_t s);
 // Start rows of the maximal runs of equal (near, band) in d_key (ascending; first entry 0).  Empty if there are more than

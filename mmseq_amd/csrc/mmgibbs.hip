@@ -494,7 +494,7 @@ static int problem_build(mmg_problem *p, uint64_t *d_rp64)
 #define B_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return bail(fail(MMG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); } while (0)
     std::vector<uint64_t> seg;
     if (p->m && p->layout == (int)MMG_LAYOUT_CANONICAL && p->d_k) {
-        // a row with 2 <= k <= K_SMALL is stored as k rows with k = 1: identical reads then run on the register path like any
+        // a row that draws k >= 2 categoricals (mmg_types.h: draws_categoricals) is stored as k rows with k = 1: identical reads then run on the register path like any
         // other read, instead of through the multiplicity kernel (mmg_types.h)
         B_TRY(layout_expand_rows(&p->m, &p->nnz, &d_rp64, &p->d_col, &p->d_k, 16, 0));
     }

@@ -984,7 +984,7 @@ def test_golden_em_on_device(gpu):
     e = json.load(open(os.path.join(gd, "em_fixed_tiny.json")))
     fh = lambda xs: np.array([float.fromhex(x) for x in xs])
     prob = gpu.Problem.from_csr(np.asarray(g["row_ptr"], np.uint64), np.asarray(g["col_idx"], np.uint32), fh(g["l"]),
-                                k=np.asarray(g["k"], np.uint32), keep_rows=True)  # (the canonical layout stores a row with 2 <= k <= 64 as k
+                                k=np.asarray(g["k"], np.uint32), keep_rows=True)  # (the canonical layout stores a row that draws 2 <= k <= 64 categoricals as k
                                                                                  # rows: k terms 1/d instead of one term k/d, other low bits)
     for r in e["runs"]:
         em = prob.em_stepper(fh(r["mu_start"]))

@@ -145,8 +145,8 @@ def test_degenerate_and_edge_rows(orc):
 
 @pytest.mark.parametrize("name,seed", [("keyed_chain_tiny.json", 1234), ("keyed_chain_k_draws.json", 4321)])
 def test_golden_tiny_chain(orc, name, seed):
-    """keyed_chain_tiny.json: k up to 1000, single hits, small multiplicities, binomial chains.  keyed_chain_k_draws.json (spec version 5):
-    rows on either side of the boundary k <= 16 (hits - 1) between k categorical draws and the conditional-binomial chain."""
+    """keyed_chain_tiny.json: k up to 1000, single hits, small multiplicities, binomial chains.  keyed_chain_k_draws.json (spec version 8):
+    rows on either side of the boundary k <= min(64, 16 (hits - 1)) between k categorical draws and the conditional-binomial chain."""
     g = json.load(open(os.path.join(os.path.dirname(GOLD), name)))
     f = lambda hs: np.array([float.fromhex(h) for h in hs])
     p = orc.Problem(np.array(g["row_ptr"], np.uint64), np.array(g["col_idx"], np.uint32), f(g["l"]),
