@@ -254,8 +254,9 @@ def side_measurement(name, rows, transcripts, avg_hits, chains=1, uniform=False,
         fam_info = None
         if families:
             # paralogue families with a power-law size distribution (32 ... 5 000 transcripts, members scattered over the caller's gene order,
-            # a read's second gene a NEIGHBOUR in its family) and 1 % of the reads on 50 hub transcripts: mmseq_amd/families.py
-            from mmseq_amd import families as fam
+            # a read's second gene a NEIGHBOUR in its family) and 1 % of the reads on 50 hub transcripts: tools/families.py
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+            import families as fam
             rp, ci, tx_order, fam_info = fam.power_law_families(rp, ci, transcripts, genes[0], seed=seed)
         t1 = time.perf_counter()
         prob = Problem.from_csr(rp, ci, l, device=device, tx_order=tx_order)

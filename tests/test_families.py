@@ -1,9 +1,13 @@
-"""mmseq_amd/families.py (host side, numpy): the benchmark's hit graph with a real tail -- paralogue families of power-law size whose
+"""tools/families.py (host side, numpy): the benchmark's hit graph with a real tail -- paralogue families of power-law size whose
 reads also hit a NEIGHBOUR in the family, hub transcripts (src/bam2hits.cpp:271-300: a read keeps up to 100 alignments).  Properties
 the GPU tests and bench.py's `families_pl` rely on."""
 import numpy as np
 
-from mmseq_amd import families as fam
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+import families as fam  # noqa: E402
 
 
 def _base(m, T, G, seed):

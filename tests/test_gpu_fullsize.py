@@ -206,10 +206,12 @@ def test_paralogue_reads_at_full_size_after_the_gene_reorder(gpu, orc):
 def test_power_law_families_with_hubs_at_full_size(gpu, orc):
     """VERDICT round 5, item 3 at BASELINE size: 50 M reads x 200 k transcripts, gene blocks of 32 isoforms, paralogue families of
     power-law size (32 ... 5 000 transcripts: up to twenty LDS windows) scattered over the caller's gene order, 17 % of the reads also
-    hitting a neighbouring member of their family, 1 % of the reads on 50 hub transcripts (mmseq_amd/families.py).  The library reorders
+    hitting a neighbouring member of their family, 1 % of the reads on 50 hub transcripts (tools/families.py).  The library reorders
     the genes by the gene-level hit graph, the hubs left out of the traversal (tx_renumbered 3): at most 5 % of the tiles keep a far list,
     and the first sweep (one chain, and a fused pair) equals the oracle's replay of the stored rows bit for bit."""
-    from mmseq_amd import families as fam
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import families as fam
     R, T, G = 50_000_000, 200_000, 32
     gen = gpu.Problem.synthetic(R, T, 20.0, seed=1234, sort=False, gene_size=G)
     rp, ci = gen.download()

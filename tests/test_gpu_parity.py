@@ -125,13 +125,15 @@ def test_reads_that_also_hit_a_paralogue_family_get_a_gene_order_that_brings_the
 
 
 def test_power_law_families_and_hub_transcripts_get_a_gene_order_that_keeps_neighbours_together(gpu, orc):
-    """A hit graph with the tail of a real transcriptome (mmseq_amd/families.py; src/bam2hits.cpp:271-300 keeps up to 100 alignments per
+    """A hit graph with the tail of a real transcriptome (tools/families.py; src/bam2hits.cpp:271-300 keeps up to 100 alignments per
     read): paralogue families of power-law size -- up to 5 000 transcripts, far more than an LDS window -- scattered over the caller's gene
     order, a read's second gene a neighbour in its family's chain, and 1 % of the reads on hub transcripts that share rows with hundreds of
     genes.  Spec version 7's gene order from the group-level hit graph lays a large family out as a run of windows (breadth-first levels
     from a pseudo-peripheral member; the hubs are left out of the traversal): nearly all paralogue rows become near rows, the decision
     is reported (tx_renumbered 3), and the chain on the stored rows is the oracle's bit for bit."""
-    from mmseq_amd import families as fam
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import families as fam
     R, T, G = 60000, 12000, 16
     gen = gpu.Problem.synthetic(R, T, 6.0, seed=77, sort=False, gene_size=G)
     rp, ci = gen.download()

@@ -1,9 +1,10 @@
-"""What the parts of the power-law family workload (mmseq_amd/families.py) cost K1: config 3 in gene-block mode (32 isoforms per gene),
+"""What the parts of the power-law family workload (tools/families.py) cost K1: config 3 in gene-block mode (32 isoforms per gene),
 uploaded with the CLI's keys, (a) as generated, (b) + hub reads only, (c) + paralogue reads only, (d) both.   families_probe.py [rows]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from mmseq_amd import Problem, Sampler, families as fam
+from mmseq_amd import Problem, Sampler
+import families as fam
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000_000
 T, G = 200_000, 32
 gen = Problem.synthetic(R, T, 20.0, seed=1234, sort=False, gene_size=G)
