@@ -112,7 +112,10 @@ constexpr uint64_t SELL_SLOW_TILE_COST = 48; // a CSR-walked tile
 constexpr uint64_t SHARD_TILE_COST = 1, SHARD_GROUP_COST = 2;
 constexpr uint64_t SHARD_FAR_ENTRY_COST = 24;  // measured (tools/shard_balance.py): a far tile with one entry per lane takes 3 x a register-path tile
 constexpr uint64_t SHARD_SLOW_TILE_COST = 280; // 24 x a register-path tile
-constexpr uint64_t SHARD_DRAW_COST = 12, SHARD_BINOMIAL_COST = 210; // per draw of a tile's largest k / per hit of its binomial chains (as cumk: 2 and 36 halves of a tile)
+constexpr uint64_t SHARD_DRAW_COST = 12; // per draw of a tile's largest k (as cumk: 2 halves of a tile)
+// a row on the conditional-binomial chain is not walked with its tile but from the list (k_sample_bigk): 1.12 ms for 2 M rows of 20 hits against
+// 0.29 ns of device time per register-path tile (11.8 units) -- 5/4 of a unit per hit of such a row
+constexpr uint64_t SHARD_CHAIN_HIT_COST_NUM = 5, SHARD_CHAIN_HIT_COST_DEN = 4;
 // k_sample (CSR tiles) costs 2.8 of these units per 64 hits (7.4 ms for 1.0 G uniform hits): a problem dearer on the stream kernel runs there
 
 // The same with a tapered end: the last `resident` ranges' worth of cost is cut into twice as many ranges of half the cost (the
@@ -263,8 +266,9 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
         const bool hk = has_k_rows(t);
         n_hask += hk;
         cum1[t + 1] = cum1[t] + (hk ? 0 : c);
-        // a draw costs about as much as a register-path tile per 64 rows (2), a step of the binomial chain 36 of them
-        cumk[t + 1] = cumk[t] + (!hk ? 0 : 2 * c + (draws_categoricals(td[t].kmax, td[t].maxlen > 1 ? td[t].maxlen : 2) ? 2 * (uint64_t)td[t].kmax : 36 * (uint64_t)td[t].maxlen));
+        // a draw costs about as much as a register-path tile per 64 rows (2)
+        // (the tile's rows on the binomial chain are skipped here -- the list kernel draws them: what is left draws at most K_SMALL times)
+        cumk[t + 1] = cumk[t] + (!hk ? 0 : 2 * c + 2 * (uint64_t)std::min<uint32_t>(td[t].kmax, K_SMALL));
     }
     // What a sweep over the tiles [0, t) costs, for the cut into read shards (mmg_problem_shard_bounds).  The ranges of ONE launch get by
     // with "2 per register-path tile": several generations of short ranges even out what the model misses.  A shard is one range per
@@ -277,7 +281,9 @@ static int problem_build_sell(mmg_problem *p, const std::vector<uint64_t> &seg_s
         if (td[t].nnz) {
             const uint64_t blk = SHARD_TILE_COST + SHARD_GROUP_COST * (qualifies(td[t]) ? (td[t].maxlen + 3) / 4 : is_far(t) ? (far_nn[t] + 3) / 4 : 0);
             c = qualifies(td[t]) ? blk : is_far(t) ? blk + SHARD_FAR_ENTRY_COST * far_nf[t] : SHARD_SLOW_TILE_COST;
-            if (has_k_rows(t)) c = 2 * c + (draws_categoricals(td[t].kmax, td[t].maxlen > 1 ? td[t].maxlen : 2) ? SHARD_DRAW_COST * (uint64_t)td[t].kmax : SHARD_BINOMIAL_COST * (uint64_t)td[t].maxlen);
+            if (has_k_rows(t)) // draws of the tile's rows that draw; its rows on the chain (at most the knot1 rows with k != 1) by their hits
+                c = 2 * c + SHARD_DRAW_COST * (uint64_t)std::min<uint32_t>(td[t].kmax, K_SMALL) +
+                    (draws_categoricals(td[t].kmax, td[t].maxlen > 1 ? td[t].maxlen : 2) ? 0 : SHARD_CHAIN_HIT_COST_NUM * (uint64_t)td[t].maxlen * td[t].knot1 / SHARD_CHAIN_HIT_COST_DEN);
         }
         p->h_shard_cum[t + 1] = p->h_shard_cum[t] + c;
     }
