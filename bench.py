@@ -288,6 +288,8 @@ def side_measurement(name, rows, transcripts, avg_hits, chains=1, uniform=False,
             for lo_u, hi_u, lo_k, hi_k in ((0.5, 0.8, 2, 8), (0.8, 0.95, 9, 64), (0.95, 0.99, 65, 300), (0.99, 1.0, 300, 20000)):
                 sel = (u >= lo_u) & (u < hi_u)
                 k[sel] = np.exp(rng.uniform(np.log(lo_k), np.log(hi_k + 1), size=int(sel.sum()))).astype(np.uint32).clip(lo_k, hi_k)
+        elif multiplicities == "k1000":
+            k = np.full(rows, 1000, np.uint32)     # every row on the conditional-binomial chain: k_sample_bigk alone, device full
         elif multiplicities == "zipf":
             # what a 50 M-read file collapses to (src/mmseq.cpp:409-440): few million hit sets, k Pareto/Zipf with exponent 1.92 -- 47 % of
             # the hit sets k = 1, 2.3 % above 64, 0.55 % above 304, the tail capped at 10^6 -- about 50 M reads in all
@@ -378,6 +380,7 @@ SIDE = [
     ("real8", "50M x 200k like a real hits file: those multiplicities + 2 % far rows, 8 chains", dict(rows=R3, transcripts=T3, avg_hits=H3, multiplicities=True, far_fraction=0.02, chains=8, steps=16, warmup=4)),
     ("heavy", "a heavily collapsed file: 5M hit sets, multiplicities 1..20000 (total_k reads)", dict(rows=5_000_000, transcripts=T3, avg_hits=H3, multiplicities="heavy", steps=32)),
     ("collapsed", "what a 50M-read file collapses to: 2M hit sets, 1 + Poisson(9) hits, k Zipf (exponent 1.92) up to 10^6, about 50M reads in all", dict(rows=2_000_000, transcripts=T3, avg_hits=10.0, multiplicities="zipf", steps=32)),
+    ("bigk", "the conditional-binomial chain alone: 2M hit sets x 20 hits, k = 1000 on every one (38 M binomials per sweep)", dict(rows=2_000_000, transcripts=T3, avg_hits=H3, multiplicities="k1000", steps=32)),
     ("far2", "50M x 200k, 2 % of the rows with a hit anywhere in the transcriptome", dict(rows=R3, transcripts=T3, avg_hits=H3, far_fraction=0.02, steps=32)),
     ("far20", "50M x 200k, 20 % of the rows with a hit anywhere", dict(rows=R3, transcripts=T3, avg_hits=H3, far_fraction=0.2, steps=24)),
     ("gene0", "50M x 200k like an aligner's output: a read's hits are isoforms of ONE gene (32 isoforms per gene), tx_order = the caller's genes",
@@ -670,6 +673,7 @@ def main():
             roof["heavy_ms"] = g("heavy", "ms_per_step")
             roof["collapsed_ms"] = g("collapsed", "ms_per_step")
             roof["collapsed_alg_frac"] = g("collapsed", "alg_frac")
+            roof["bigk_ms"] = g("bigk", "ms_per_step")
             roof["far20_ms"] = g("far20", "ms_per_step")
             roof["gene0_ms"] = g("gene0", "ms_per_step")
             roof["far20p_ms"] = g("far20p", "ms_per_step")
@@ -680,7 +684,8 @@ def main():
             roof["keeprows_ms"] = g("keeprows", "ms_per_step")
             roof["scatter_no_tx_order_ms"] = g("scatter", "ms_per_step")
             roof["algorithmic_x_peak"] = full_roof["algorithmic_x_peak"]
-            keep = ("id", "chains", "ms_per_step", "chain_it_s", "k1_ms_all_chains", "k2_ms", "kernel", "alg_frac", "far_tiles", "total_k", "error", "ms_per_sweep",
+            # (the driver keeps an 8 KB tail of stdout: the line stays under 7.5 KB -- which kernel ran and the reads are in --full-json's record)
+            keep = ("id", "chains", "ms_per_step", "chain_it_s", "k1_ms_all_chains", "k2_ms", "alg_frac", "far_tiles", "error", "ms_per_sweep",
                     "tx_renumbered", "create_s")
             roof["configs"] = [compact({k: v for k, v in r.items() if k in keep}) for r in side.values()]
             roof["other"] = {k: compact(v, drop=("pmc_source", "pattern_read_peak_gbs", "peak", "unit", "timed_launches", "hbm_counter_frac")) for k, v in other.items()}
