@@ -18,8 +18,9 @@
 // one in any case): the frequent cheap work stays in step, the rare expensive paths wait until they are worth a run.  Lanes are
 // different rows with their own keyed stream (mmg_math.h: Stream2), so a lane may run ahead of its neighbours: the work a lane does, and
 // the uniforms it consumes, are exactly what the sequential loop does for its row -- the same bits as allocate_row / orc_gibbs_keyed --
-// only the order BETWEEN lanes changes.  The expensive test then runs for thirty-odd lanes at a time instead of for one or two, and a
-// lane that finishes its row fetches the next instead of waiting for the slowest row of a tile.
+// only the order BETWEEN lanes changes.  The expensive test then runs for a dozen lanes or more at a time instead of for one or two: about
+// 1 000 vector instructions per 64 binomials (profiles/r06_bigk_ab.md).  A piece is 64 list entries (measured best at every list length:
+// mmgibbs.hip, bigk_piece); a longer piece works -- a lane that finishes its row fetches the next -- and is what the tests run too.
 //
 // Weights are gathered from the global vector (L1 / L2: the rows of a piece are neighbours in the canonical order, i.e. in transcript
 // space); counts go to a 255-wide LDS window that follows the piece through the bands (flushed with one atomic per touched transcript
