@@ -169,6 +169,37 @@ def test_power_law_families_and_hub_transcripts_get_a_gene_order_that_keeps_neig
     s.close(); prob.close()
 
 
+def test_an_order_that_cannot_be_tried_is_flagged_and_an_error_when_forced(gpu, orc):
+    """the order from the hit graph (spec versions 6 / 7) is built beside the problem it may replace and needs about three
+    times its device memory free.  Without that memory the caller's order stands -- a different stored order, hence a different chain,
+    than the same call with memory to spare: mmg_problem_info.tx_renumbered then carries MMG_ORDER_SKIPPED (0x100), and
+    MMG_OPT_DERIVE_ORDER = 1 ("always") turns the silent fallback into an error."""
+    import torch
+    from mmseq_amd._lib import MMGError
+    p, _ = orc.synth_problem(R=30000, T=3000, avg_hits=6, seed=12, sort=False)
+    rng = np.random.default_rng(2)
+    scat = rng.permutation(p.n).astype(np.uint32)            # first-seen numbering: no locality in the caller's ids, no tx_order
+    ci_ext = scat[p.col_idx]
+    l_ext = np.empty(p.n); l_ext[scat] = p.l
+    roomy = gpu.Problem.from_csr(p.row_ptr, ci_ext, l_ext)
+    assert roomy.info.tx_renumbered == 2                       # with memory to spare: derived, no flag
+    roomy.close()
+    torch.cuda.synchronize()
+    free, _ = torch.cuda.mem_get_info()
+    hog = torch.empty(max(free - (56 << 20), 0), dtype=torch.uint8, device="cuda")   # leave 56 MB: enough for the problem, not for the attempt (64 MB + ...)
+    try:
+        tight = gpu.Problem.from_csr(p.row_ptr, ci_ext, l_ext)
+        assert tight.info.tx_renumbered == 0x100 and tight.info.sample_kernel == 0   # the caller's order, flagged
+        tight.close()
+        with gpu.options(derive_order=1):
+            with pytest.raises(MMGError) as e:
+                gpu.Problem.from_csr(p.row_ptr, ci_ext, l_ext)
+        assert "free device memory" in str(e.value)
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+
+
 def test_first_seen_numbering_with_tx_order_takes_the_fast_kernel(gpu, orc):
     """The reference numbers transcripts in first-seen order (src/mmseq.cpp:399-408), which scatters the isoforms of a gene over
     the index range.  Uploaded like that the rows span the whole range and only the CSR kernel applies; with tx_order (gene
