@@ -46,6 +46,9 @@ enum : uint32_t { BK_FETCH = 0, BK_STEP = 1, BK_BSET = 2, BK_TRY = 3, BK_SLOW = 
 #ifndef BK_SHARE_DEN
 #define BK_SHARE_DEN 5
 #endif
+#ifndef BK_STEPS_PER_TRIP
+#define BK_STEPS_PER_TRIP 2
+#endif
 
 template <typename IdxT>
 __global__ __launch_bounds__(64) void k_sample_bigk(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
@@ -175,38 +178,68 @@ __global__ __launch_bounds__(64) void k_sample_bigk(const IdxT *__restrict__ row
             }
         }
 
-        // ---- STEP: hit j of the row: p, the outcomes that need no draw, and the inversion that ends at x = 0
-        {
-            const uint32_t nS = count(ph == BK_STEP);
-            if (nS >= thr) {
-                BK_STAT(1, nS);
-                if (ph == BK_STEP) {
-                    double pr = degenerate ? 1.0 / (double)(L - j) : (rem_w > 0.0 ? w_cur / rem_w : 1.0);
-                    if (pr > 1.0) pr = 1.0;
-                    nn = remaining;
-                    flip = false;
-                    // binomial(q, nn, pr) (mmg_math.h), its loops unrolled into the phases
-                    if (!(pr > 0.0)) { x = 0; resolved = true; }
-                    else if (pr >= 1.0) { x = nn; resolved = true; }
-                    else {
-                        double p = pr;
-                        if (p > 0.5) { p = 1.0 - p; flip = true; }
-                        dn = (double)nn;
-                        P = p;
-                        const double np = dn * p;
-                        if (np < 10.0) {
-                            // Inversion: x = 0 iff the uniform does not exceed r0 = exp(n log(1 - p)) as the sequential code computes it.  r0 is
-                            // at least 1 - n p - n 2^-54 - 2^-46 (Bernoulli's inequality; 1 - p rounds to within 2^-54, log and exp to an ulp,
-                            // |n log(1 - p)| < 20): a uniform below that bound less a margin settles x = 0 without the logarithm and the
-                            // exponential -- the common case for the hits of transcripts that carry (next to) nothing.  Same uniform consumed.
-                            const double u = next_unit();
-                            if (u <= 1.0 - np * (1.0 + 0x1p-10) - dn * 0x1p-49 - 0x1p-40) { x = 0; resolved = true; }
-                            else { U = u; ph = BK_IFULL; }
-                        } else ph = BK_BSET;
+        // ---- the steps settled so far in this trip: the count, the next hit or the end of the row
+        auto do_resolve = [&]() {
+            if (__ballot(resolved)) {
+                if (resolved) {
+                    resolved = false;
+                    const uint32_t xr = flip ? nn - x : x;
+                    if (xr) add(c_cur, (int32_t)xr);
+                    remaining -= xr;
+                    rem_w -= w_cur;
+                    ++j;
+                    if (j + 1 < L && remaining > 0) {
+                        ph = BK_STEP;
+                        c_cur = c_nx; w_cur = w_nx;
+                        c_nx = c_n2;
+                        w_nx = gmu[c_nx];                        // (hit j + 1: its id arrived a trip ago)
+                        c_n2 = col_idx[b + min(j + 2, L - 1)];
+                    } else {
+                        if (remaining > 0) add(c_last, (int32_t)remaining);
+                        ph = BK_FETCH;
                     }
                 }
             }
-        }
+        };
+        // ---- STEP: hit j of the row: p, the outcomes that need no draw, and the inversion that ends at x = 0
+        auto do_step = [&]() {
+            {
+                const uint32_t nS = count(ph == BK_STEP);
+                if (nS >= thr) {
+                    BK_STAT(1, nS);
+                    if (ph == BK_STEP) {
+                        double pr = degenerate ? 1.0 / (double)(L - j) : (rem_w > 0.0 ? w_cur / rem_w : 1.0);
+                        if (pr > 1.0) pr = 1.0;
+                        nn = remaining;
+                        flip = false;
+                        // binomial(q, nn, pr) (mmg_math.h), its loops unrolled into the phases
+                        if (!(pr > 0.0)) { x = 0; resolved = true; }
+                        else if (pr >= 1.0) { x = nn; resolved = true; }
+                        else {
+                            double p = pr;
+                            if (p > 0.5) { p = 1.0 - p; flip = true; }
+                            dn = (double)nn;
+                            P = p;
+                            const double np = dn * p;
+                            if (np < 10.0) {
+                                // Inversion: x = 0 iff the uniform does not exceed r0 = exp(n log(1 - p)) as the sequential code computes it.  r0 is
+                                // at least 1 - n p - n 2^-54 - 2^-46 (Bernoulli's inequality; 1 - p rounds to within 2^-54, log and exp to an ulp,
+                                // |n log(1 - p)| < 20): a uniform below that bound less a margin settles x = 0 without the logarithm and the
+                                // exponential -- the common case for the hits of transcripts that carry (next to) nothing.  Same uniform consumed.
+                                const double u = next_unit();
+                                if (u <= 1.0 - np * (1.0 + 0x1p-10) - dn * 0x1p-49 - 0x1p-40) { x = 0; resolved = true; }
+                                else { U = u; ph = BK_IFULL; }
+                            } else ph = BK_BSET;
+                        }
+                    }
+                }
+            }
+        };
+        // Six steps in ten settle inside STEP (no draw, or the inversion's x = 0): those lanes take their next hit in the same trip --
+        // BK_STEPS_PER_TRIP rounds of STEP + settle before the expensive phases get their turn (measured: 1 -> 2 rounds -4 % on the hit sets of a
+        // collapsed file, -5.5 % on 2 M rows of k = 1000; 3 rounds no better: profiles/r06_bigk_ab.md)
+        do_step();
+        for (int rep = 1; rep < BK_STEPS_PER_TRIP; ++rep) { do_resolve(); do_step(); }
 
         // ---- BTRS: the constants of a new step, then one attempt (also for the lanes whose last attempt was rejected)
         {
@@ -282,27 +315,7 @@ __global__ __launch_bounds__(64) void k_sample_bigk(const IdxT *__restrict__ row
             }
         }
 
-        // ---- the steps settled in this trip: the count, the next hit or the end of the row
-        if (__ballot(resolved)) {
-            if (resolved) {
-                resolved = false;
-                const uint32_t xr = flip ? nn - x : x;
-                if (xr) add(c_cur, (int32_t)xr);
-                remaining -= xr;
-                rem_w -= w_cur;
-                ++j;
-                if (j + 1 < L && remaining > 0) {
-                    ph = BK_STEP;
-                    c_cur = c_nx; w_cur = w_nx;
-                    c_nx = c_n2;
-                    w_nx = gmu[c_nx];                        // (hit j + 1: its id arrived a trip ago)
-                    c_n2 = col_idx[b + min(j + 2, L - 1)];
-                } else {
-                    if (remaining > 0) add(c_last, (int32_t)remaining);
-                    ph = BK_FETCH;
-                }
-            }
-        }
+        do_resolve();
     }
 #undef BK_STAT
     if (have_win) flush_window();

@@ -31,7 +31,8 @@ def _child(rank, world, port, q):
     from mmseq_amd import gibbs as G
     from mmseq_amd import dist as mdist
     from oracle import binding as B
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))   # (a stalled rendezvous fails, it does not hang)
     torch.cuda.set_device(0)
     p, _ = B.synth_problem(R=60000, T=1500, avg_hits=6, seed=21)            # canonical order: shards are cut from it and kept
     mu0, _ = B.start_values(p)
@@ -70,10 +71,16 @@ def test_two_ranks_drive_the_library_through_dist_py(orc):
     procs = [ctx.Process(target=_child, args=(r, 2, port, q)) for r in range(2)]
     for pr in procs:
         pr.start()
-    res = sorted(q.get(timeout=240) for _ in range(2))
-    for pr in procs:
-        pr.join(120)
-        assert pr.exitcode == 0
+    try:
+        res = sorted(q.get(timeout=400) for _ in range(2))   # (seconds on a quiet box; the children import torch on a host shared with three other jobs)
+        for pr in procs:
+            pr.join(120)
+            assert pr.exitcode == 0
+    finally:
+        for pr in procs:                                     # a child that is still there must not keep the test session from ending
+            if pr.is_alive():
+                pr.terminate()
+                pr.join(10)
     p, _ = orc.synth_problem(R=60000, T=1500, avg_hits=6, seed=21)
     mu0, _ = orc.start_values(p)
     ref = orc.gibbs_keyed(p, mu0, seed=77, chain=0, n_iter=12, trace_len=12)
