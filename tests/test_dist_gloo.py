@@ -7,7 +7,6 @@ under test here; the kernels themselves are covered by the -m gpu parity tests).
   chains mode: rank r runs chain r; one all_reduce of (sum log mu, sum log^2 mu) at the end.
 """
 import os
-import socket
 import sys
 
 import numpy as np
@@ -16,24 +15,17 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
-def _worker(rank, world, port, q):
+def _worker(rank, world, store, q):
     sys.path.insert(0, ROOT)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
+    os.environ["GLOO_SOCKET_IFNAME"] = "lo"          # (the container's hostname may not resolve)
     os.environ["OMP_NUM_THREADS"] = "2"
     import torch
     import torch.distributed as dist
     from mmseq_amd import dist as mdist
     from oracle import binding as B
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+    # (rendezvous through a file: no port to pick and lose to another job on the host; a stalled rendezvous fails instead of hanging)
+    dist.init_process_group("gloo", init_method="file://" + store, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     p, _ = B.synth_problem(R=6000, T=250, avg_hits=5, seed=21)
     mu0, _ = B.start_values(p)
     n_iter = 6
@@ -60,14 +52,21 @@ def test_two_rank_protocols_reproduce_single_process():
     from oracle import binding as B
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    import tempfile
+    store = os.path.join(tempfile.mkdtemp(prefix="mmseq_gloo_"), "store")
+    procs = [ctx.Process(target=_worker, args=(r, 2, store, q)) for r in range(2)]
     for pr in procs:
         pr.start()
-    res = sorted(q.get(timeout=180) for _ in range(2))
-    for pr in procs:
-        pr.join(60)
-        assert pr.exitcode == 0
+    try:
+        res = sorted(q.get(timeout=300) for _ in range(2))
+        for pr in procs:
+            pr.join(60)
+            assert pr.exitcode == 0
+    finally:
+        for pr in procs:
+            if pr.is_alive():
+                pr.terminate()
+                pr.join(10)
     p, _ = B.synth_problem(R=6000, T=250, avg_hits=5, seed=21)
     mu0, _ = B.start_values(p)
     ref = B.gibbs_keyed(p, mu0, seed=77, chain=0, n_iter=6, trace_len=6)

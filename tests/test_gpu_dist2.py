@@ -4,7 +4,6 @@ ranks share cuda:0 and the process group is gloo (it all-reduces CUDA tensors th
 pool_moments, counts_tensor / moments_tensor views -- is exactly what runs over RCCL on 8 GPUs, only the transport differs.
 Children are fresh processes spawned before any GPU call."""
 import os
-import socket
 import sys
 
 import numpy as np
@@ -14,25 +13,18 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
-def _child(rank, world, port, q):
+def _child(rank, world, store, q):
     sys.path.insert(0, ROOT)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
+    os.environ["GLOO_SOCKET_IFNAME"] = "lo"          # (the container's hostname may not resolve)
     import torch
     import torch.distributed as dist
     from mmseq_amd import gibbs as G
     from mmseq_amd import dist as mdist
     from oracle import binding as B
     import datetime
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))   # (a stalled rendezvous fails, it does not hang)
+    # rendezvous through a FILE (no port to pick: a "free" port chosen by the parent can be taken, on a host that runs other jobs, before
+    # the ranks bind it -- two sessions of this suite hung here while the pool was full); a stalled rendezvous fails, it does not hang
+    dist.init_process_group("gloo", init_method="file://" + store, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
     torch.cuda.set_device(0)
     p, _ = B.synth_problem(R=60000, T=1500, avg_hits=6, seed=21)            # canonical order: shards are cut from it and kept
     mu0, _ = B.start_values(p)
@@ -67,8 +59,9 @@ def test_two_ranks_drive_the_library_through_dist_py(orc):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_child, args=(r, 2, port, q)) for r in range(2)]
+    import tempfile
+    store = os.path.join(tempfile.mkdtemp(prefix="mmseq_dist2_"), "store")
+    procs = [ctx.Process(target=_child, args=(r, 2, store, q)) for r in range(2)]
     for pr in procs:
         pr.start()
     try:
