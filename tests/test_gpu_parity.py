@@ -1053,10 +1053,11 @@ def test_torch_view_of_device_buffers_and_single_rank_collectives(gpu, orc):
     assert counts.dtype == torch.int32 and counts.numel() == 900 and counts.is_cuda
     own = not dist.is_initialized()
     if own:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        import tempfile
         stamp("before init_process_group")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        # (rendezvous through a file: a fixed port can be taken by another job on the host)
+        dist.init_process_group("nccl", init_method="file://" + os.path.join(tempfile.mkdtemp(prefix="mmseq_nccl_"), "store"), rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
         stamp("init_process_group")
     try:
         for _ in range(8):
