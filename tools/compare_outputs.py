@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""compare_outputs.py A_base B_base [--trace-len 1024] [--level ...]
+"""compare_outputs.py A_base B_base [--no-traces]
 
 The check a maintainer with a reference `mmseq` binary runs: two sets of `mmseq` outputs for the SAME hits file -- say A from the
 reference (src/mmseq.cpp), B from this build's drop-in CLI -- held to the parity contract of SURVEY.md App. E.  Pure numpy, CPU only;
