@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64) void k_sample_bigk(const IdxT *__restrict__ row
     uint32_t nn = 0, x = 0;
     double dn = 0.0, P = 0.0, U = 0.0;
     bool flip = false, resolved = false;
-    double A = 0.0, B = 0.0, CC = 0.0, VR = 0.0, R = 0.0, ALPHA = 0.0, M = 0.0; // BTRS constants
+    double A = 0.0, B = 0.0, CC = 0.0, VR = 0.0, ALPHA = 0.0; // BTRS constants a, b, c, vr and sqrt(n p q) (SLOW derives r, alpha and m from them)
     double us = 0.0, kf = 0.0, vv = 0.0;                                       // the attempt waiting for the exact test
 
     auto next_unit = [&]() -> double { // Stream2::next()
@@ -253,10 +253,7 @@ __global__ __launch_bounds__(64) void k_sample_bigk(const IdxT *__restrict__ row
                     const double aa = -0.0873 + 0.0248 * bb + 0.01 * p;
                     const double cc = dn * p + 0.5;
                     const double vr = 0.92 - 4.2 / bb;
-                    const double rr = p / qq;
-                    const double alpha = (2.83 + 5.1 / bb) * spq;
-                    const double mm = dfloor((dn + 1.0) * p);
-                    A = aa; B = bb; CC = cc; VR = vr; R = rr; ALPHA = alpha; M = mm;
+                    A = aa; B = bb; CC = cc; VR = vr; ALPHA = spq; /* (SLOW finishes r, alpha, m: one attempt in seven gets there) */
                     ph = BK_TRY;
                 }
                 if (ph == BK_TRY) {
@@ -302,7 +299,8 @@ __global__ __launch_bounds__(64) void k_sample_bigk(const IdxT *__restrict__ row
             if (nW >= thr) {
                 BK_STAT(3, nW);
                 if (ph == BK_SLOW) {
-                    const double a_ = A, b_ = B, r = R, m = M, alpha = ALPHA;
+                    const double a_ = A, b_ = B, p_ = P;
+                    const double r = p_ / (1.0 - p_), alpha = (2.83 + 5.1 / b_) * ALPHA, m = dfloor((dn + 1.0) * p_);
                     // (every argument below is a ratio of positive finite numbers far from the subnormal range: dlog_pn)
                     const double v = dlog_pn(vv * alpha / (a_ / (us * us) + b_));
                     const double ub = (m + 0.5) * dlog_pn((m + 1.0) / (r * (dn - m + 1.0))) +
