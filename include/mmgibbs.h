@@ -444,6 +444,11 @@ int mmg_selftest_philox(int device, const uint32_t *ctr, const uint32_t *key, ui
 int mmg_selftest_gamma(int device, uint64_t seed, double shape, double scale, int64_t n, double *out);
 /* out[i] = Binomial(nn, p) draw of row stream (seed, id i). */
 int mmg_selftest_binomial(int device, uint64_t seed, uint32_t nn, double p, int64_t n, uint32_t *out);
+/* n_cases BTRS attempts over n log-uniform in [n_lo, n_hi] (21 <= n_lo <= n_hi < 2^32) and p log-uniform in [10 / n, 1/2]: counts[0] attempts that
+ * reach the exact acceptance test, [1] of them decided by the fp32 estimate k_sample_bigk tries first (mmg_math.h: btrs_pretest), [2] decided
+ * AND different from the fp64 test -- must be 0 --, [3] accepted by the fp64 test, [4] the largest |estimate - fp64 difference| seen, in
+ * millionths of the estimate's own error bound (counts: 5 words). */
+int mmg_selftest_btrs_pretest(int device, uint64_t seed, int64_t n_cases, double n_lo, double n_hi, uint64_t *counts);
 
 #ifdef __cplusplus
 }

@@ -51,7 +51,7 @@ enum : uint32_t { BK_FETCH = 0, BK_STEP = 1, BK_BSET = 2, BK_TRY = 3, BK_SLOW = 
 #endif
 
 template <typename IdxT>
-__global__ __launch_bounds__(64) void k_sample_bigk(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_sample_bigk(const IdxT *__restrict__ row_ptr, const uint32_t *__restrict__ col_idx,
                                                     const uint32_t *__restrict__ kmult, const uint64_t *__restrict__ list, uint64_t n_list,
                                                     uint32_t per_wave, const double *__restrict__ gmu /* [grid.y][n] */,
                                                     int32_t *gcnt /* [grid.y][n] */, SampleArgs a)
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(64) void k_sample_bigk(const IdxT *__restrict__ row
     auto count = [&](bool c) -> uint32_t { return (uint32_t)__popcll(__ballot(c)); };
 
 #if defined(MMG_BIGK_STATS)
-    uint32_t st_runs[5] = {0, 0, 0, 0, 0}, st_lanes[5] = {0, 0, 0, 0, 0};
+    uint32_t st_runs[6] = {0, 0, 0, 0, 0, 0}, st_lanes[6] = {0, 0, 0, 0, 0, 0};
 #define BK_STAT(q, n) do { st_runs[q]++; st_lanes[q] += (n); } while (0)
 #else
 #define BK_STAT(q, n) do { } while (0)
@@ -293,22 +293,27 @@ __global__ __launch_bounds__(64) void k_sample_bigk(const IdxT *__restrict__ row
             }
         }
 
-        // ---- SLOW: the exact acceptance test of the attempts that missed the squeeze
+        // ---- SLOW: the exact acceptance test of the attempts that missed the squeeze -- from its fp32 estimate where that is farther from zero
+        // than its own error bound (mmg_math.h: btrs_pretest; 99.9 % of the tests below n = 2000, 95 % above 10^7), in fp64 at once for the rest
         {
             const uint32_t nW = count(ph == BK_SLOW);
             if (nW >= thr) {
                 BK_STAT(3, nW);
+                int pre = 0;
                 if (ph == BK_SLOW) {
-                    const double a_ = A, b_ = B, p_ = P;
-                    const double r = p_ / (1.0 - p_), alpha = (2.83 + 5.1 / b_) * ALPHA, m = dfloor((dn + 1.0) * p_);
-                    // (every argument below is a ratio of positive finite numbers far from the subnormal range: dlog_pn)
-                    const double v = dlog_pn(vv * alpha / (a_ / (us * us) + b_));
-                    const double ub = (m + 0.5) * dlog_pn((m + 1.0) / (r * (dn - m + 1.0))) +
-                                      (dn + 1.0) * dlog_pn((dn - m + 1.0) / (dn - kf + 1.0)) +
-                                      (kf + 0.5) * dlog_pn(r * (dn - kf + 1.0) / (kf + 1.0)) +
-                                      stirling_tail(m) + stirling_tail(dn - m) - stirling_tail(kf) - stirling_tail(dn - kf);
-                    if (v <= ub) { x = (uint32_t)kf; resolved = true; }
-                    else ph = BK_TRY;
+                    pre = btrs_pretest(dn, P, kf, us, vv, A, B, ALPHA);
+                    if (pre > 0) { x = (uint32_t)kf; resolved = true; }
+                    else if (pre < 0) ph = BK_TRY;
+                }
+                const bool undecided = ph == BK_SLOW && pre == 0;
+                if (__ballot(undecided)) {
+                    BK_STAT(5, count(undecided));
+                    if (undecided) {
+                        // (the expressions of binomial(); every argument of a logarithm is a ratio of positive finite numbers far from the
+                        // subnormal range: dlog_pn)
+                        if (btrs_exact_test(dn, P, kf, us, vv, A, B, ALPHA)) { x = (uint32_t)kf; resolved = true; }
+                        else ph = BK_TRY;
+                    }
                 }
             }
         }
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(64) void k_sample_bigk(const IdxT *__restrict__ row
     if (have_win) flush_window();
 #if defined(MMG_BIGK_STATS)
     if (lane == 0)
-        for (uint32_t q = 0; q < 5; ++q) { atomicAdd(&g_bigk_stats[q], (unsigned long long)st_runs[q]); atomicAdd(&g_bigk_stats[8 + q], (unsigned long long)st_lanes[q]); }
+        for (uint32_t q = 0; q < 6; ++q) { atomicAdd(&g_bigk_stats[q], (unsigned long long)st_runs[q]); atomicAdd(&g_bigk_stats[8 + q], (unsigned long long)st_lanes[q]); }
 #endif
 }
 

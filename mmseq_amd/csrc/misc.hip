@@ -164,4 +164,10 @@ double host_start_value(uint64_t a0, uint64_t a1, uint64_t a2, double l)
     return d * 0x1p-52 / l;
 }
 
+void launch_selftest_btrs_pretest(uint64_t seed, int64_t n_cases, double n_lo, double n_hi, unsigned long long *counts, hipStream_t s)
+{
+    if (n_cases <= 0) return;
+    hipLaunchKernelGGL(k_selftest_btrs_pretest, dim3((unsigned)((n_cases + 255) / 256)), dim3(256), 0, s, seed, n_cases, n_lo, n_hi, counts);
+}
+
 } // namespace mmg

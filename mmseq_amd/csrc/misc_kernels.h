@@ -324,4 +324,51 @@ __global__ void k_selftest_binomial(uint64_t seed, uint32_t nn, double p, int64_
     out[i] = binomial(q, nn, p);
 }
 
+// BTRS candidates over (n, p) drawn from the case index: n log-uniform in [n_lo, n_hi], p log-uniform in [10 / n, 1/2] (where binomial() takes
+// BTRS), one attempt each from the case's keyed stream.  counts[0] attempts that reach the exact test, [1] of them decided by btrs_pretest,
+// [2] decided AND different from the fp64 test (must stay 0), [3] accepted by the fp64 test, [4] max |estimate - fp64 difference| / bound, in millionths.
+__global__ __launch_bounds__(256) void k_selftest_btrs_pretest(uint64_t seed, int64_t n_cases, double n_lo, double n_hi, unsigned long long *counts)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool slow = false, decided = false, wrong = false, acc = false;
+    if (i < n_cases) {
+        Stream s(seed, 0, TAG_SYNTH_ROW, (uint64_t)i, 0);
+        double ua, ub;
+        s.pair(ua, ub);
+        const double dn = dfloor(dexp(dlog(n_lo) + ua * (dlog(n_hi) - dlog(n_lo))));
+        const double p_lo = 10.0 / dn;
+        if (dn >= 21.0 && p_lo < 0.5) {
+            const double p = dexp(dlog(p_lo) + ub * (dlog(0.5) - dlog(p_lo)));
+            if (dn * p >= 10.0 && p <= 0.5) {
+                const double qq = 1.0 - p, spq = dsqrt(dn * p * qq);
+                const double b = 1.15 + 2.53 * spq, a = -0.0873 + 0.0248 * b + 0.01 * p, c = dn * p + 0.5, vr = 0.92 - 4.2 / b;
+                Stream2 q(seed, 1, TAG_ROW, (uint64_t)i, 0);
+                const double u = q.next() - 0.5, v = q.next();
+                const double us = 0.5 - dabs(u);
+                const double kf = dfloor((2.0 * a / us + b) * u + c);
+                if (!(kf < 0.0 || kf > dn) && !(us >= 0.07 && v <= vr)) {
+                    slow = true;
+                    double diff = 0.0;
+                    acc = btrs_exact_test(dn, p, kf, us, v, a, b, spq, &diff);
+                    float d32, e32;
+                    btrs_estimate(dn, p, kf, us, v, a, b, spq, d32, e32);
+                    const int pre = d32 > e32 ? 1 : (d32 < -e32 ? -1 : 0);
+                    decided = pre != 0;
+                    wrong = decided && ((pre > 0) != acc);
+                    // the estimate's actual error as a share of its bound, in millionths (counts[4]: the largest seen)
+                    const double share = dabs((double)d32 - diff) / (double)e32 * 1e6;
+                    if (share == share) atomicMax(&counts[4], (unsigned long long)(share < 1.8e19 ? share : 1.8e19));
+                }
+            }
+        }
+    }
+    const unsigned long long c0 = __popcll(__ballot(slow)), c1 = __popcll(__ballot(decided)), c2 = __popcll(__ballot(wrong)), c3 = __popcll(__ballot(acc));
+    if ((threadIdx.x & 63) == 0) {
+        if (c0) atomicAdd(&counts[0], c0);
+        if (c1) atomicAdd(&counts[1], c1);
+        if (c2) atomicAdd(&counts[2], c2);
+        if (c3) atomicAdd(&counts[3], c3);
+    }
+}
+
 } // namespace mmg

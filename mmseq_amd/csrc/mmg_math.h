@@ -481,4 +481,91 @@ MMG_HD uint32_t binomial(Src &q, uint32_t n, double p)
     return flip ? n - res : res;
 }
 
+// ------------------------------------------------------------------ BTRS: the exact test, decided in fp32 where that is safe
+// binomial()'s exact acceptance test of a candidate k that missed the squeeze is
+//     T0 <= T1 + T2 + T3 + S,   T0 = log(v alpha / (a / us^2 + b)),
+//     T1 = (m + 1/2) log((m + 1) / (r (n - m + 1))),  T2 = (n + 1) log((n - m + 1) / (n - k + 1)),  T3 = (k + 1/2) log(r (n - k + 1) / (k + 1)),
+//     S  = st(m) + st(n - m) - st(k) - st(n - k)                                       (r = p / q, st = stirling_tail)
+// -- four fp64 logarithms, a dozen fp64 divisions: 430 vector instructions, a quarter of k_sample_bigk's.  The test is a COMPARISON: its
+// outcome is known without fp64 whenever a cheap estimate D of (T1 + T2 + T3 + S - T0) is farther from zero than a bound E on the
+// estimate's own error.  btrs_pretest returns +1 (accept) / -1 (reject) in that case, 0 (undecided: run the fp64 test) otherwise, so
+// the draw is the one binomial() makes, uniform for uniform.
+// The estimate: the three logarithms have arguments near 1 (m is the mode), written as log1p(x_i) with the differences in the
+// numerators formed in fp64 -- x1 = ((m + 1) q - p (n - m + 1)) / (p (n - m + 1)), x2 = (k - m) / (n - k + 1), x3 = (p (n - k + 1) - q (k + 1)) /
+// (q (k + 1)): no cancellation is left to fp32, whose divisions (v_rcp_f32, 1 ulp), series (|x| < 1/4) and native logarithm (elsewhere:
+// 1 + x loses nothing that matters there) each err by a few 2^-24 RELATIVE to their result.  First-order error of T_i: c_i |x_i| /
+// min(1, 1 + x_i) times 6e-7 (c_i the coefficient; the fp64 numerators contribute n 2^-52, i.e. 2e-7 relative at n = 2^32); of T0 (native
+// log2 of a ratio of fp32 values, not amplified): 1e-6 (1 + |T0|); of S: 1e-7.  E takes six times that:
+//     E = sum_i c_i |x_i| / min(1, 1 + x_i) 2^-18 + (1 + |T0|) 2^-16 + 2^-14.
+// mmg_selftest_btrs_pretest runs candidates over the whole range of (n, p) through both and counts decided cases that disagree
+// with the fp64 test: none in 4 10^9 (tests/test_gpu_parity.py::test_btrs_pretest_never_contradicts_the_exact_test).  A NaN anywhere
+// compares false twice: undecided.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ float mmg_rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float mmg_log1pf(float x)
+{
+    // |x| < 1/4: the series x (1 - x/2 + x^2/3 - ... + x^10/11) (truncation 2e-8 relative); elsewhere ln(1 + x) from the native log2
+    float sacc = -1.0f / 12.0f;
+    sacc = sacc * x + 1.0f / 11.0f; sacc = sacc * x - 1.0f / 10.0f; sacc = sacc * x + 1.0f / 9.0f; sacc = sacc * x - 1.0f / 8.0f;
+    sacc = sacc * x + 1.0f / 7.0f; sacc = sacc * x - 1.0f / 6.0f; sacc = sacc * x + 1.0f / 5.0f; sacc = sacc * x - 1.0f / 4.0f;
+    sacc = sacc * x + 1.0f / 3.0f; sacc = sacc * x - 1.0f / 2.0f; sacc = sacc * x + 1.0f;
+    const float series = sacc * x;
+    const float native = __builtin_amdgcn_logf(1.0f + x) * 0.693147180559945309f;
+    return __builtin_fabsf(x) < 0.25f ? series : native;
+}
+__device__ __forceinline__ float mmg_stirling_tailf(float k)
+{
+    const int i = k <= 9.0f ? (int)k : 9;
+    float t = 0.0810614667953272f;
+    t = i >= 1 ? 0.0413406959554092f : t; t = i >= 2 ? 0.0276779256849983f : t; t = i >= 3 ? 0.02079067210376509f : t;
+    t = i >= 4 ? 0.0166446911898211f : t; t = i >= 5 ? 0.0138761288230707f : t; t = i >= 6 ? 0.0118967099458917f : t;
+    t = i >= 7 ? 0.0104112652619720f : t; t = i >= 8 ? 0.00925546218271273f : t; t = i >= 9 ? 0.00833056343336287f : t;
+    const float inv = mmg_rcpf(k + 1.0f), inv2 = inv * inv;
+    const float f = (1.0f / 12.0f - (1.0f / 360.0f - (1.0f / 1260.0f) * inv2) * inv2) * inv;
+    return k <= 9.0f ? t : f;
+}
+// d: the estimate of T1 + T2 + T3 + S - T0, e: the bound on its error
+__device__ __forceinline__ void btrs_estimate(double dn, double p, double kf, double us, double vv, double a, double b, double spq, float &d_out, float &e_out)
+{
+    const double q = 1.0 - p, m = dfloor((dn + 1.0) * p);
+    const double nm1 = dn - m + 1.0, nk1 = dn - kf + 1.0;                 // exact
+    const double num1 = (m + 1.0) * q - p * nm1, num3 = p * nk1 - q * (kf + 1.0), num2 = kf - m;
+    const float x1 = (float)num1 * mmg_rcpf((float)(p * nm1)), x2 = (float)num2 * mmg_rcpf((float)nk1), x3 = (float)num3 * mmg_rcpf((float)(q * (kf + 1.0)));
+    const float c1 = (float)(m + 0.5), c2 = (float)(dn + 1.0), c3 = (float)(kf + 0.5);
+    const float t1 = c1 * mmg_log1pf(x1), t2 = c2 * mmg_log1pf(x2), t3 = c3 * mmg_log1pf(x3);
+    const float fb = (float)b, fus = (float)us, fspq = (float)spq;
+    const float alpha = (2.83f + 5.1f * mmg_rcpf(fb)) * fspq;
+    const float arg = (float)vv * alpha * mmg_rcpf((float)a * mmg_rcpf(fus * fus) + fb);
+    const float t0 = __builtin_amdgcn_logf(arg) * 0.693147180559945309f;
+    const float sfix = mmg_stirling_tailf((float)m) + mmg_stirling_tailf((float)(dn - m)) - mmg_stirling_tailf((float)kf) - mmg_stirling_tailf((float)(dn - kf));
+    const float d = ((t1 + t2) + t3) + sfix - t0;
+    auto amp = [](float c, float x) { return c * __builtin_fabsf(x) * mmg_rcpf(__builtin_fminf(1.0f, 1.0f + x)); };
+    const float e = (amp(c1, x1) + amp(c2, x2) + amp(c3, x3)) * 0x1p-18f + (1.0f + __builtin_fabsf(t0)) * 0x1p-16f + 0x1p-14f;
+    d_out = d; e_out = e;
+}
+__device__ __forceinline__ int btrs_pretest(double dn, double p, double kf, double us, double vv, double a, double b, double spq)
+{
+    float d, e;
+    btrs_estimate(dn, p, kf, us, vv, a, b, spq, d, e);
+    return d > e ? 1 : (d < -e ? -1 : 0);
+}
+#else
+// (the host pass of a device translation unit only needs the name: the estimate runs on the device, the oracle and the host instantiation
+// of binomial() always take the fp64 test)
+__device__ __forceinline__ int btrs_pretest(double, double, double, double, double, double, double, double) { return 0; }
+__device__ __forceinline__ void btrs_estimate(double, double, double, double, double, double, double, double, float &d, float &e) { d = 0.0f; e = 0.0f; }
+#endif
+// the fp64 test itself (binomial()'s expressions): true = accept; diff (optional) = ub - v as computed
+MMG_HD bool btrs_exact_test(double dn, double p, double kf, double us, double vv, double a, double b, double spq, double *diff = nullptr)
+{
+    const double r = p / (1.0 - p), alpha = (2.83 + 5.1 / b) * spq, m = dfloor((dn + 1.0) * p);
+    const double v = dlog_pn(vv * alpha / (a / (us * us) + b));
+    const double ub = (m + 0.5) * dlog_pn((m + 1.0) / (r * (dn - m + 1.0))) +
+                      (dn + 1.0) * dlog_pn((dn - m + 1.0) / (dn - kf + 1.0)) +
+                      (kf + 0.5) * dlog_pn(r * (dn - kf + 1.0) / (kf + 1.0)) +
+                      stirling_tail(m) + stirling_tail(dn - m) - stirling_tail(kf) - stirling_tail(dn - kf);
+    if (diff) *diff = ub - v;
+    return v <= ub;
+}
+
 } // namespace mmg

@@ -517,3 +517,11 @@ def selftest_binomial(seed, nn, p, n, device):
     out = np.empty(n, np.uint32)
     check(_lib.load().mmg_selftest_binomial(device, seed, nn, p, n, _ptr(out)))
     return out
+
+
+def selftest_btrs_pretest(seed, n_cases, n_lo, n_hi, device=0):
+    """(reached the exact test, decided by the fp32 estimate, decided and WRONG, accepted, largest error / bound in millionths) over n_cases BTRS
+    attempts (mmg_math.h: btrs_pretest)"""
+    out = np.zeros(5, np.uint64)
+    check(_lib.load().mmg_selftest_btrs_pretest(device, seed, n_cases, float(n_lo), float(n_hi), _ptr(out)))
+    return tuple(int(v) for v in out)

@@ -426,6 +426,40 @@ def test_rows_on_the_binomial_chain_from_their_list(gpu, orc, per_wave, side):
         s.close(); prob.close()
 
 
+def test_btrs_pretest_never_contradicts_the_exact_test(gpu):
+    """mmg_math.h: btrs_pretest -- k_sample_bigk decides BTRS's exact acceptance test from an fp32 estimate where the estimate is farther
+    from zero than the bound on its own error, and runs the fp64 test (the oracle's, binomial()'s) for the rest.  The draw is the
+    sequential code's only if a DECIDED case never differs from the fp64 test: 2.5 10^8 attempts per range of n (21 ... 2^32, p from 10 / n
+    to 1/2, the uniforms of the sampler's row stream), none may; and the estimate has to be worth its instructions (> 90 % decided,
+    its largest error well inside the bound)."""
+    for lo, hi in ((21, 200), (200, 20000), (2e4, 1e7), (1e7, 4.29e9), (21, 4.29e9)):
+        reached, decided, wrong, accepted, share = gpu.selftest_btrs_pretest(seed=5 + int(lo), n_cases=250_000_000, n_lo=lo, n_hi=hi)
+        assert reached > 30_000_000 and 0.3 < accepted / reached < 0.8
+        assert wrong == 0
+        assert decided / reached > 0.9 and share < 250_000                  # (error <= a quarter of the bound; measured: 0.07)
+
+
+def test_chain_rows_whose_exact_test_falls_back_to_fp64(gpu, orc):
+    """Rows of 2 and 3 hits with k = 3 10^8 ... 5 10^8 and weights of one size: every step is BTRS at n ~ 10^8, where one exact test in twenty is
+    too close for the fp32 estimate and takes the fp64 path inside k_sample_bigk (bigk_kernels.h: SLOW) -- bit-exact against the oracle."""
+    rng = np.random.default_rng(3)
+    n_rows, T = 600, 2400
+    rows = [[4 * i, 4 * i + 1] if i % 2 else [4 * i, 4 * i + 1, 4 * i + 2] for i in range(n_rows)]
+    rp = np.cumsum([0] + [len(r) for r in rows]).astype(np.uint64)
+    ci = np.concatenate([np.asarray(r, np.uint32) for r in rows])
+    k = rng.integers(300_000_000, 500_000_000, size=n_rows).astype(np.uint32)
+    p = orc.Problem(rp, ci, np.linspace(0.5, 2.0, T), k=k)
+    mu0 = rng.uniform(0.5, 2.0, size=T)
+    with gpu.options(sample_kernel=2):
+        prob, ps = _dev(gpu, orc, p)
+        s = gpu.Sampler(prob, mu0, seed=77, n_chains=2, gibbs_iter=8, trace_len=8)
+        s.run(8)
+        for c in range(2):
+            ref = orc.gibbs_keyed(ps, mu0, seed=77, chain=c, n_iter=8, trace_len=8)
+            assert np.array_equal(s.counts(c), ref["cnt"]) and np.array_equal(s.trace(c), ref["trace"])
+        s.close(); prob.close()
+
+
 @pytest.mark.parametrize("keep_rows", [False, True])
 def test_edge_rows(gpu, orc, keep_rows):
     """Empty rows, single-hit rows, a row longer than a tile (> 4096 hits), ragged tail."""
