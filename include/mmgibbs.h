@@ -450,6 +450,13 @@ int mmg_selftest_binomial(int device, uint64_t seed, uint32_t nn, double p, int6
  * millionths of the estimate's own error bound (counts: 5 words). */
 int mmg_selftest_btrs_pretest(int device, uint64_t seed, int64_t n_cases, double n_lo, double n_hi, uint64_t *counts);
 
+/* Diagnostics: the same for the inversion (n p < 10): n_cases searches, n log-uniform in [n_lo, n_hi] (1 <= n_lo), n p log-uniform in
+ * [1e-6, 10), through the fp32 search k_sample_bigk tries first (mmg_math.h: binv_pretest) and the fp64 search of the sequential code.
+ * counts[0] cases, [1] decided in fp32, [2] decided AND different from the fp64 search -- must be 0 --, [3] cases whose fp64 search ran off
+ * the end (the sequential code draws again), [4] the sum of the outcomes (counts: 5 words).  slack scales the error bound the fp32 search
+ * allows itself: 1 is what the sampler runs; smaller values show how much room the bound has. */
+int mmg_selftest_binv_pretest(int device, uint64_t seed, int64_t n_cases, double n_lo, double n_hi, double slack, uint64_t *counts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -149,6 +149,7 @@ SYMBOLS = {
     "mmg_selftest_gamma": (C.c_int, [C.c_int, C.c_uint64, C.c_double, C.c_double, C.c_int64, C.c_void_p]),
     "mmg_selftest_binomial": (C.c_int, [C.c_int, C.c_uint64, C.c_uint32, C.c_double, C.c_int64, C.c_void_p]),
     "mmg_selftest_btrs_pretest": (C.c_int, [C.c_int, C.c_uint64, C.c_int64, C.c_double, C.c_double, C.c_void_p]),
+    "mmg_selftest_binv_pretest": (C.c_int, [C.c_int, C.c_uint64, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_void_p]),
 }
 
 

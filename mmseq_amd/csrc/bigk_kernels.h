@@ -107,7 +107,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     auto count = [&](bool c) -> uint32_t { return (uint32_t)__popcll(__ballot(c)); };
 
 #if defined(MMG_BIGK_STATS)
-    uint32_t st_runs[6] = {0, 0, 0, 0, 0, 0}, st_lanes[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t st_runs[7] = {0, 0, 0, 0, 0, 0, 0}, st_lanes[7] = {0, 0, 0, 0, 0, 0, 0};
 #define BK_STAT(q, n) do { st_runs[q]++; st_lanes[q] += (n); } while (0)
 #else
 #define BK_STAT(q, n) do { } while (0)
@@ -208,7 +208,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 if (nS >= thr) {
                     BK_STAT(1, nS);
                     if (ph == BK_STEP) {
-                        double pr = degenerate ? 1.0 / (double)(L - j) : (rem_w > 0.0 ? w_cur / rem_w : 1.0);
+                        // (allocate_row: 1 / (hits left) for a degenerate row, w / (weight left) otherwise, 1 when nothing is left -- one division)
+                        const bool whole = !degenerate && !(rem_w > 0.0);
+                        double pr = (degenerate || whole ? 1.0 : w_cur) / (degenerate ? (double)(L - j) : (whole ? 1.0 : rem_w));
                         if (pr > 1.0) pr = 1.0;
                         nn = remaining;
                         flip = false;
@@ -269,26 +271,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             }
         }
 
-        // ---- IFULL: the inversion whose uniform may exceed r0
+        // ---- IFULL: the inversion whose uniform may exceed r0 -- the search in fp32 where no boundary comes closer to the uniform than the
+        // bound on the fp32 sums (mmg_math.h: binv_pretest), the fp64 search at once for the rest
         {
             const uint32_t nI = count(ph == BK_IFULL);
             if (nI >= thr) {
                 BK_STAT(4, nI);
+                int pre = -1;
                 if (ph == BK_IFULL) {
-                    const double p = P;
-                    const double qq = 1.0 - p, s = p / qq, aa = (dn + 1.0) * s;
-                    double r = dexp(dn * dlog_pn(qq)); // 0.5 <= qq < 1
-                    double u = U;
-                    uint32_t xi = 0;
-                    bool ok = true;
-                    while (u > r) {
-                        u -= r;
-                        xi++;
-                        if (xi > nn) { ok = false; break; }
-                        r *= (aa / (double)xi - s);
+                    pre = binv_pretest(dn, P, U);
+                    if (pre >= 0) { x = (uint32_t)pre; resolved = true; }
+                }
+                const bool undecided = ph == BK_IFULL && pre < 0;
+                if (__ballot(undecided)) {
+                    BK_STAT(6, count(undecided));
+                    if (undecided) {
+                        uint32_t xi;
+                        if (binv_exact(dn, P, U, nn, xi)) { x = xi; resolved = true; }
+                        else U = next_unit(); // (the sequential loop starts over with the next uniform)
                     }
-                    if (ok) { x = xi; resolved = true; }
-                    else U = next_unit(); // (the sequential loop starts over with the next uniform)
                 }
             }
         }
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     if (have_win) flush_window();
 #if defined(MMG_BIGK_STATS)
     if (lane == 0)
-        for (uint32_t q = 0; q < 6; ++q) { atomicAdd(&g_bigk_stats[q], (unsigned long long)st_runs[q]); atomicAdd(&g_bigk_stats[8 + q], (unsigned long long)st_lanes[q]); }
+        for (uint32_t q = 0; q < 7; ++q) { atomicAdd(&g_bigk_stats[q], (unsigned long long)st_runs[q]); atomicAdd(&g_bigk_stats[8 + q], (unsigned long long)st_lanes[q]); }
 #endif
 }
 

@@ -170,4 +170,10 @@ void launch_selftest_btrs_pretest(uint64_t seed, int64_t n_cases, double n_lo, d
     hipLaunchKernelGGL(k_selftest_btrs_pretest, dim3((unsigned)((n_cases + 255) / 256)), dim3(256), 0, s, seed, n_cases, n_lo, n_hi, counts);
 }
 
+void launch_selftest_binv_pretest(uint64_t seed, int64_t n_cases, double n_lo, double n_hi, float slack, unsigned long long *counts, hipStream_t s)
+{
+    if (n_cases <= 0) return;
+    hipLaunchKernelGGL(k_selftest_binv_pretest, dim3((unsigned)((n_cases + 255) / 256)), dim3(256), 0, s, seed, n_cases, n_lo, n_hi, slack, counts);
+}
+
 } // namespace mmg

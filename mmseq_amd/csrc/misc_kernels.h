@@ -371,4 +371,42 @@ __global__ __launch_bounds__(256) void k_selftest_btrs_pretest(uint64_t seed, in
     }
 }
 
+// mmg_selftest_binv_pretest: binv_pretest (mmg_math.h) against the fp64 search over the inversion's whole range -- n log-uniform in [n_lo, n_hi],
+// n p log-uniform in [1e-6, 10), p <= 1/2, the uniform of the sampler's row stream.  counts: [0] cases, [1] decided by the fp32 search, [2] decided
+// AND different from the fp64 search (must stay 0), [3] cases whose fp64 search fell off the end (binomial() draws again), [4] the sum of the outcomes.
+__global__ __launch_bounds__(256) void k_selftest_binv_pretest(uint64_t seed, int64_t n_cases, double n_lo, double n_hi, float slack, unsigned long long *counts)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool valid = false, decided = false, wrong = false, fell = false;
+    uint32_t xs = 0;
+    if (i < n_cases) {
+        Stream s(seed, 0, TAG_SYNTH_ROW, (uint64_t)i, 0);
+        double ua, ub;
+        s.pair(ua, ub);
+        const double dn = dfloor(dexp(dlog(n_lo) + ua * (dlog(n_hi) - dlog(n_lo))));
+        const double np = dexp(dlog(1e-6) + ub * (dlog(10.0) - dlog(1e-6)));
+        const double p = np / dn;
+        if (dn >= 1.0 && p > 0.0 && p <= 0.5 && dn * p < 10.0) {
+            valid = true;
+            Stream2 q(seed, 1, TAG_ROW, (uint64_t)i, 0);
+            const double u = q.next();
+            uint32_t x64 = 0;
+            const bool ok = binv_exact(dn, p, u, (uint32_t)dn, x64);
+            fell = !ok;
+            const int pre = binv_pretest(dn, p, u, slack);
+            decided = pre >= 0;
+            wrong = decided && (!ok || (uint32_t)pre != x64);
+            xs = ok ? x64 : 0;
+        }
+    }
+    const unsigned long long c0 = __popcll(__ballot(valid)), c1 = __popcll(__ballot(decided)), c2 = __popcll(__ballot(wrong)), c3 = __popcll(__ballot(fell));
+    if (xs) atomicAdd(&counts[4], (unsigned long long)xs);
+    if ((threadIdx.x & 63) == 0) {
+        if (c0) atomicAdd(&counts[0], c0);
+        if (c1) atomicAdd(&counts[1], c1);
+        if (c2) atomicAdd(&counts[2], c2);
+        if (c3) atomicAdd(&counts[3], c3);
+    }
+}
+
 } // namespace mmg

@@ -54,7 +54,8 @@ void launch_selftest_math(int64_t n, const double *x, double *ol, double *oe, do
 void launch_selftest_philox(const uint32_t *ctr, const uint32_t *key, uint32_t *out, hipStream_t s);
 void launch_selftest_gamma(uint64_t seed, double shape, double scale, int64_t n, double *out, hipStream_t s);
 void launch_selftest_binomial(uint64_t seed, uint32_t nn, double p, int64_t n, uint32_t *out, hipStream_t s);
-void launch_selftest_btrs_pretest(uint64_t seed, int64_t n_cases, double n_lo, double n_hi, unsigned long long *counts /* [4], device */, hipStream_t s);
+void launch_selftest_btrs_pretest(uint64_t seed, int64_t n_cases, double n_lo, double n_hi, unsigned long long *counts /* [5], device */, hipStream_t s);
+void launch_selftest_binv_pretest(uint64_t seed, int64_t n_cases, double n_lo, double n_hi, float slack, unsigned long long *counts /* [5], device */, hipStream_t s);
 // host instantiations of the same inline code (device == -1 paths of the self tests, synthetic transcript tables)
 void host_math(int64_t n, const double *x, double *ol, double *oe, double *os, double *orc);
 void host_philox(const uint32_t *ctr, const uint32_t *key, uint32_t *out);

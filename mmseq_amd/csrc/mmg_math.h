@@ -568,4 +568,51 @@ MMG_HD bool btrs_exact_test(double dn, double p, double kf, double us, double vv
     return v <= ub;
 }
 
+// ------------------------------------------------------------------ inversion: the search decided in fp32 where that is safe
+// binomial()'s inversion finds the first x whose cumulative probability reaches the uniform: r0 = exp(n log q) (an fp64 logarithm and
+// exponential), then r_x = r_(x-1) (a / x - s) with an fp64 division per term.  Again the OUTCOME is a comparison: with the terms r~ and
+// their running sum c~ in fp32 and a bound e_x on the sum's error, x is known whenever  c~_(x-1) + e_(x-1) < u < c~_x - e_x.  binv_pretest
+// returns that x, or -1 (undecided: a boundary closer than the bound, more than 64 terms) -- the fp64 search runs then, on the same uniform.
+// Errors: r0 -- the exponent n log1p(-p) is below 20 in magnitude, fp32 product and log1pf err by 5e-7 of it, v_exp_f32 by an ulp: 1e-5
+// relative; every further term multiplies by s (n + 1 - x) / x with two v_rcp_f32 and four roundings: 4e-7 more per term; the sum adds an ulp of
+// itself per term; the uniform rounds to fp32 within 2^-25.  The bound takes six times that:  e_x = c~_x (2^-14 + x 2^-19) + 2^-22.
+// mmg_selftest_binv_pretest counts decided cases that differ from the fp64 search (none may).
+#if defined(__HIP_DEVICE_COMPILE__)
+// (slack: the selftest's knob -- the bound scaled down until decided cases start to differ shows how much room it has; 1 in the sampler)
+__device__ __forceinline__ int binv_pretest(double dn, double p, double u, float slack = 1.0f)
+{
+    const float fp = (float)p, fq = (float)(1.0 - p), fn = (float)dn, fu = (float)u;
+    float r = __builtin_amdgcn_exp2f(fn * mmg_log1pf(-fp) * 1.44269504088896341f);
+    const float s = fp * mmg_rcpf(fq);
+    float c = r, k = 0.0f, nk = fn, rel = 0x1p-14f;
+    for (int it = 0; it < 64; ++it) {
+        const float e = (c * rel + 0x1p-22f) * slack;
+        if (!(fu > c + e)) return fu < c - e ? (int)k : -1;
+        k += 1.0f;
+        r *= s * nk * mmg_rcpf(k);                                           // s (n + 1 - k) / k
+        nk -= 1.0f;
+        c += r;
+        rel += 0x1p-19f;
+    }
+    return -1;
+}
+#else
+__device__ __forceinline__ int binv_pretest(double, double, double, float = 1.0f) { return -1; }
+#endif
+// the fp64 search itself on one uniform (binomial()'s loop): false = the sum of the terms fell short of the uniform (binomial() starts over)
+MMG_HD bool binv_exact(double dn, double p, double u, uint32_t n, uint32_t &x_out)
+{
+    const double qq = 1.0 - p, s = p / qq, a = (dn + 1.0) * s;
+    double r = dexp(dn * dlog_pn(qq)); // 0.5 <= qq < 1
+    uint32_t x = 0;
+    while (u > r) {
+        u -= r;
+        x++;
+        if (x > n) return false;
+        r *= (a / (double)x - s);
+    }
+    x_out = x;
+    return true;
+}
+
 } // namespace mmg

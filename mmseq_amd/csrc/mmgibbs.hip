@@ -1296,3 +1296,19 @@ extern "C" int mmg_selftest_btrs_pretest(int device, uint64_t seed, int64_t n_ca
     if (e != hipSuccess) return fail(MMG_ERR_HIP, std::string("selftest_btrs_pretest: ") + hipGetErrorString(e));
     return MMG_OK;
 }
+
+extern "C" int mmg_selftest_binv_pretest(int device, uint64_t seed, int64_t n_cases, double n_lo, double n_hi, double slack, uint64_t *counts)
+{
+    if (n_cases < 0 || !counts || !(n_lo >= 1.0) || !(n_hi >= n_lo) || !(n_hi <= 4294967295.0) || !(slack > 0.0)) return fail(MMG_ERR_ARG, "bad argument");
+    int rc = require_device(device);
+    if (rc) return rc;
+    unsigned long long *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, 5 * sizeof(unsigned long long)));
+    hipError_t e = hipMemset(d, 0, 5 * sizeof(unsigned long long));
+    if (e == hipSuccess) { launch_selftest_binv_pretest(seed, n_cases, n_lo, n_hi, (float)slack, d, 0); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(counts, d, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(MMG_ERR_HIP, std::string("selftest_binv_pretest: ") + hipGetErrorString(e));
+    return MMG_OK;
+}

@@ -525,3 +525,11 @@ def selftest_btrs_pretest(seed, n_cases, n_lo, n_hi, device=0):
     out = np.zeros(5, np.uint64)
     check(_lib.load().mmg_selftest_btrs_pretest(device, seed, n_cases, float(n_lo), float(n_hi), _ptr(out)))
     return tuple(int(v) for v in out)
+
+
+def selftest_binv_pretest(seed, n_cases, n_lo, n_hi, slack=1.0, device=0):
+    """(cases, decided by the fp32 search, decided and WRONG, fp64 searches that ran off the end, sum of the outcomes) over n_cases inversions
+    (mmg_math.h: binv_pretest); slack scales the error bound (1: the sampler's)"""
+    out = np.zeros(5, np.uint64)
+    check(_lib.load().mmg_selftest_binv_pretest(device, seed, n_cases, float(n_lo), float(n_hi), float(slack), _ptr(out)))
+    return tuple(int(v) for v in out)

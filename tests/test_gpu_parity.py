@@ -439,6 +439,20 @@ def test_btrs_pretest_never_contradicts_the_exact_test(gpu):
         assert decided / reached > 0.9 and share < 250_000                  # (error <= a quarter of the bound; measured: 0.07)
 
 
+def test_binv_pretest_never_contradicts_the_fp64_search(gpu):
+    """mmg_math.h: binv_pretest -- k_sample_bigk runs the inversion's search (n p < 10) on fp32 terms and sums and takes its x where no
+    boundary of the cumulative sum comes closer to the uniform than the bound on the fp32 sum's error; the fp64 search of the
+    sequential code runs for the rest.  10^8 searches per range of n (n p from 1e-6 to 10): a decided case never differs -- not even
+    with the bound at a sixteenth of the sampler's --, and at least 99.9 % are decided.  (n stops at 10^7 here: a search whose fp64 terms
+    sum short of the uniform walks all n terms before the sequential code draws again, 4 in 10^9 at n ~ 10^9.)"""
+    for lo, hi in ((1, 20), (20, 2000), (2000, 1e7)):
+        for slack in (1.0, 1.0 / 16):
+            cases, decided, wrong, fell, total = gpu.selftest_binv_pretest(seed=9 + int(lo), n_cases=100_000_000, n_lo=lo, n_hi=hi, slack=slack)
+            assert cases > 80_000_000 and 0.1 < total / cases < 1.0
+            assert wrong == 0
+            assert decided / cases > 0.999
+
+
 def test_chain_rows_whose_exact_test_falls_back_to_fp64(gpu, orc):
     """Rows of 2 and 3 hits with k = 3 10^8 ... 5 10^8 and weights of one size: every step is BTRS at n ~ 10^8, where one exact test in twenty is
     too close for the fp32 estimate and takes the fp64 path inside k_sample_bigk (bigk_kernels.h: SLOW) -- bit-exact against the oracle."""

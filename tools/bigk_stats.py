@@ -41,6 +41,6 @@ s.run(N); s.sync()
 lib.mmg_selftest_bigk_stats(out)
 tm = s.timing()
 print("%s: %d rows on the list, %d binomial steps per sweep, K1 %.4f ms" % (what, int(big.sum()), steps, tm["sample_ms"] / tm["sample_launches"]))
-for q, name in enumerate(("FETCH", "STEP", "BTRS", "SLOW", "IFULL", "SLOW64")):
+for q, name in enumerate(("FETCH", "STEP", "BTRS", "SLOW", "IFULL", "SLOW64", "IFULL64")):
     runs, lanes = out[q] / N, out[8 + q] / N
     print("%-6s runs %10.0f  lanes/run %5.1f  lane-runs per step %.3f" % (name, runs, lanes / max(runs, 1), lanes / max(steps, 1)))
