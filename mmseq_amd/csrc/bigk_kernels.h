@@ -12,14 +12,18 @@
 //     FETCH  take the next row of the piece: extents, k, the total of its weights (stored order), the row's keyed stream
 //     STEP   hit j: p = w_j / remaining weight, the outcomes that need no draw, and (n p < 10) the inversion that ends at x = 0
 //     BSET   the constants of BTRS;  TRY  one attempt: two uniforms, the candidate, the squeeze
-//     SLOW   the exact acceptance test of an attempt that missed the squeeze
-//     IFULL  the inversion whose uniform may exceed r0: logarithm, exponential, the sequential search
-// A trip of the wave's loop counts the lanes waiting in every phase and runs the phases that hold a fifth of them or more (the fullest
+//     SLOW   the exact acceptance test of an attempt that missed the squeeze: from an fp32 estimate with a bound on its own error where the
+//            two settle the comparison (mmg_math.h: btrs_pretest), the four fp64 logarithms at once for the rest (1 in 1 000)
+//     IFULL  the inversion whose uniform may exceed r0: the search on fp32 terms where no boundary of the cumulative sum is closer to
+//            the uniform than the bound on the sum (binv_pretest), logarithm, exponential and the fp64 search for the rest (1 in 2 500)
+// A trip of the wave's loop counts the lanes waiting in every phase and runs the phases that hold a tenth of them or more (the fullest
 // one in any case): the frequent cheap work stays in step, the rare expensive paths wait until they are worth a run.  Lanes are
 // different rows with their own keyed stream (mmg_math.h: Stream2), so a lane may run ahead of its neighbours: the work a lane does, and
 // the uniforms it consumes, are exactly what the sequential loop does for its row -- the same bits as allocate_row / orc_gibbs_keyed --
-// only the order BETWEEN lanes changes.  The expensive test then runs for a dozen lanes or more at a time instead of for one or two: about
-// 1 000 vector instructions per 64 binomials (profiles/r06_bigk_ab.md).  A piece is 64 list entries (measured best at every list length:
+// only the order BETWEEN lanes changes.  The expensive test then runs for a dozen lanes or more at a time instead of for one or two, and
+// the two fp32 tests take the outcome of the fp64 code, never its place (the comparison is only taken where fp32 cannot get it wrong:
+// mmg_selftest_btrs_pretest / _binv_pretest count disagreements, none in 10^9 each): about 750 vector instructions per 64 binomials
+// (profiles/r06_bigk_ab.md).  A piece is 64 list entries (measured best at every list length:
 // mmgibbs.hip, bigk_piece); a longer piece works -- a lane that finishes its row fetches the next -- and is what the tests run too.
 //
 // Weights are gathered from the global vector (L1 / L2: the rows of a piece are neighbours in the canonical order, i.e. in transcript
@@ -37,14 +41,16 @@ __device__ unsigned long long g_bigk_stats[16];
 
 enum : uint32_t { BK_FETCH = 0, BK_STEP = 1, BK_BSET = 2, BK_TRY = 3, BK_SLOW = 4, BK_IFULL = 5, BK_IDLE = 6 };
 // A phase runs in a trip of the wave's loop when it holds at least BK_SHARE_NUM / BK_SHARE_DEN of the lanes that have work (or is the
-// fullest one): a fifth.  1 / 64 is "every phase that has a lane, every trip" (the shortest dependent chain per row), 1 / 1 is "the fullest
+// fullest one): a tenth.  1 / 64 is "every phase that has a lane, every trip" (the shortest dependent chain per row), 1 / 1 is "the fullest
 // phase only" (the fewest instructions per row).  Measured at 64 rows per wave (profiles/r06_bigk_ab.md): 1/2 1.223, 1/3 1.175, 1/5 1.129,
-// 1/8 1.198 ms on 2 M rows of k = 1000; the hit sets of a collapsed file 0.159 / 0.151 / 0.146 / 0.144 ms per sweep.
+// 1/8 1.198 ms on 2 M rows of k = 1000; the hit sets of a collapsed file 0.159 / 0.151 / 0.146 / 0.144 ms per sweep.  With the exact test and
+// the full inversion decided in fp32 the expensive phases cost a third of what they did and waiting for lanes pays less: 1/4 0.875,
+// 1/5 0.845, 1/7 0.831, 1/10 0.830, 1/16 0.839, 1/32 0.844, 1/64 0.842 ms.
 #ifndef BK_SHARE_NUM
 #define BK_SHARE_NUM 1
 #endif
 #ifndef BK_SHARE_DEN
-#define BK_SHARE_DEN 5
+#define BK_SHARE_DEN 10
 #endif
 #ifndef BK_STEPS_PER_TRIP
 #define BK_STEPS_PER_TRIP 2
