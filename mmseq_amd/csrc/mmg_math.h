@@ -492,8 +492,9 @@ MMG_HD uint32_t binomial(Src &q, uint32_t n, double p)
 // the draw is the one binomial() makes, uniform for uniform.
 // The estimate: the three logarithms have arguments near 1 (m is the mode), written as log1p(x_i) with the differences in the
 // numerators formed in fp64 -- x1 = ((m + 1) q - p (n - m + 1)) / (p (n - m + 1)), x2 = (k - m) / (n - k + 1), x3 = (p (n - k + 1) - q (k + 1)) /
-// (q (k + 1)): no cancellation is left to fp32, whose divisions (v_rcp_f32, 1 ulp), series (|x| < 1/4) and native logarithm (elsewhere:
-// 1 + x loses nothing that matters there) each err by a few 2^-24 RELATIVE to their result.  First-order error of T_i: c_i |x_i| /
+// (q (k + 1)): no cancellation is left to fp32, whose divisions (v_rcp_f32, 1 ulp), series (|x| < 1/8) and native logarithm (elsewhere:
+// 1 + x loses 5e-7 of the result at most there) each err by a few 2^-24 RELATIVE to their result.  S from the asymptotic series of
+// stirling_tail (m and n - m are 10 at least; k and n - k take the table's entries below 3).  First-order error of T_i: c_i |x_i| /
 // min(1, 1 + x_i) times 6e-7 (c_i the coefficient; the fp64 numerators contribute n 2^-52, i.e. 2e-7 relative at n = 2^32); of T0 (native
 // log2 of a ratio of fp32 values, not amplified): 1e-6 (1 + |T0|); of S: 1e-7.  E takes six times that:
 //     E = sum_i c_i |x_i| / min(1, 1 + x_i) 2^-18 + (1 + |T0|) 2^-16 + 2^-14.
@@ -505,40 +506,44 @@ MMG_HD uint32_t binomial(Src &q, uint32_t n, double p)
 __device__ __forceinline__ float mmg_rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float mmg_log1pf(float x)
 {
-    // |x| < 1/4: the series x (1 - x/2 + x^2/3 - ... + x^10/11) (truncation 2e-8 relative); elsewhere ln(1 + x) from the native log2
-    float sacc = -1.0f / 12.0f;
-    sacc = sacc * x + 1.0f / 11.0f; sacc = sacc * x - 1.0f / 10.0f; sacc = sacc * x + 1.0f / 9.0f; sacc = sacc * x - 1.0f / 8.0f;
+    // |x| < 1/8: the series x (1 - x/2 + x^2/3 - ... - x^7/8) (truncation 7e-9 relative); elsewhere ln(1 + x) from the native log2
+    // (1 + x rounds within 6e-8 of a result of at least 0.117 in magnitude: 5e-7 relative)
+    float sacc = -1.0f / 8.0f;
     sacc = sacc * x + 1.0f / 7.0f; sacc = sacc * x - 1.0f / 6.0f; sacc = sacc * x + 1.0f / 5.0f; sacc = sacc * x - 1.0f / 4.0f;
     sacc = sacc * x + 1.0f / 3.0f; sacc = sacc * x - 1.0f / 2.0f; sacc = sacc * x + 1.0f;
     const float series = sacc * x;
     const float native = __builtin_amdgcn_logf(1.0f + x) * 0.693147180559945309f;
-    return __builtin_fabsf(x) < 0.25f ? series : native;
+    return __builtin_fabsf(x) < 0.125f ? series : native;
 }
-__device__ __forceinline__ float mmg_stirling_tailf(float k)
+// stirling_tail(k) from inv = 1 / (k + 1): the series of mmg_math.h's fp64 function (k >= 10 there), good to 4e-8 from k = 3 on ...
+__device__ __forceinline__ float mmg_stirling_seriesf(float inv)
 {
-    const int i = k <= 9.0f ? (int)k : 9;
-    float t = 0.0810614667953272f;
-    t = i >= 1 ? 0.0413406959554092f : t; t = i >= 2 ? 0.0276779256849983f : t; t = i >= 3 ? 0.02079067210376509f : t;
-    t = i >= 4 ? 0.0166446911898211f : t; t = i >= 5 ? 0.0138761288230707f : t; t = i >= 6 ? 0.0118967099458917f : t;
-    t = i >= 7 ? 0.0104112652619720f : t; t = i >= 8 ? 0.00925546218271273f : t; t = i >= 9 ? 0.00833056343336287f : t;
-    const float inv = mmg_rcpf(k + 1.0f), inv2 = inv * inv;
-    const float f = (1.0f / 12.0f - (1.0f / 360.0f - (1.0f / 1260.0f) * inv2) * inv2) * inv;
-    return k <= 9.0f ? t : f;
+    const float inv2 = inv * inv;
+    return (1.0f / 12.0f - (1.0f / 360.0f - (1.0f / 1260.0f) * inv2) * inv2) * inv;
+}
+// ... and the table's first three entries below (k1 = k + 1)
+__device__ __forceinline__ float mmg_stirling_tailf(float k1, float inv)
+{
+    const float t = k1 < 1.5f ? 0.0810614667953272f : (k1 < 2.5f ? 0.0413406959554092f : 0.0276779256849983f);
+    return k1 < 3.5f ? t : mmg_stirling_seriesf(inv);
 }
 // d: the estimate of T1 + T2 + T3 + S - T0, e: the bound on its error
 __device__ __forceinline__ void btrs_estimate(double dn, double p, double kf, double us, double vv, double a, double b, double spq, float &d_out, float &e_out)
 {
-    const double q = 1.0 - p, m = dfloor((dn + 1.0) * p);
-    const double nm1 = dn - m + 1.0, nk1 = dn - kf + 1.0;                 // exact
-    const double num1 = (m + 1.0) * q - p * nm1, num3 = p * nk1 - q * (kf + 1.0), num2 = kf - m;
-    const float x1 = (float)num1 * mmg_rcpf((float)(p * nm1)), x2 = (float)num2 * mmg_rcpf((float)nk1), x3 = (float)num3 * mmg_rcpf((float)(q * (kf + 1.0)));
-    const float c1 = (float)(m + 0.5), c2 = (float)(dn + 1.0), c3 = (float)(kf + 0.5);
+    const double q = 1.0 - p, m1 = dfloor((dn + 1.0) * p) + 1.0, kf1 = kf + 1.0;
+    const double nm1 = dn + 2.0 - m1, nk1 = dn - kf + 1.0;                                  // n - m + 1, n - k + 1: exact
+    const double pnm = p * nm1, qk = q * kf1;
+    const double num1 = m1 * q - pnm, num3 = p * nk1 - qk, num2 = kf1 - m1;
+    const float fm1 = (float)m1, fk1 = (float)kf1, fnm1 = (float)nm1, fnk1 = (float)nk1;   // m + 1 >= 11 and n - m + 1 >= 11 (n p >= 10, p <= 1/2)
+    const float ink1 = mmg_rcpf(fnk1);
+    const float x1 = (float)num1 * mmg_rcpf((float)pnm), x2 = (float)num2 * ink1, x3 = (float)num3 * mmg_rcpf((float)qk);
+    const float c1 = fm1 - 0.5f, c2 = (float)dn + 1.0f, c3 = fk1 - 0.5f;
     const float t1 = c1 * mmg_log1pf(x1), t2 = c2 * mmg_log1pf(x2), t3 = c3 * mmg_log1pf(x3);
     const float fb = (float)b, fus = (float)us, fspq = (float)spq;
     const float alpha = (2.83f + 5.1f * mmg_rcpf(fb)) * fspq;
     const float arg = (float)vv * alpha * mmg_rcpf((float)a * mmg_rcpf(fus * fus) + fb);
     const float t0 = __builtin_amdgcn_logf(arg) * 0.693147180559945309f;
-    const float sfix = mmg_stirling_tailf((float)m) + mmg_stirling_tailf((float)(dn - m)) - mmg_stirling_tailf((float)kf) - mmg_stirling_tailf((float)(dn - kf));
+    const float sfix = mmg_stirling_seriesf(mmg_rcpf(fm1)) + mmg_stirling_seriesf(mmg_rcpf(fnm1)) - mmg_stirling_tailf(fk1, mmg_rcpf(fk1)) - mmg_stirling_tailf(fnk1, ink1);
     const float d = ((t1 + t2) + t3) + sfix - t0;
     auto amp = [](float c, float x) { return c * __builtin_fabsf(x) * mmg_rcpf(__builtin_fminf(1.0f, 1.0f + x)); };
     const float e = (amp(c1, x1) + amp(c2, x2) + amp(c3, x3)) * 0x1p-18f + (1.0f + __builtin_fabsf(t0)) * 0x1p-16f + 0x1p-14f;
