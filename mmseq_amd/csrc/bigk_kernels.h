@@ -22,7 +22,7 @@
 // the uniforms it consumes, are exactly what the sequential loop does for its row -- the same bits as allocate_row / orc_gibbs_keyed --
 // only the order BETWEEN lanes changes.  The expensive test then runs for a dozen lanes or more at a time instead of for one or two, and
 // the two fp32 tests take the outcome of the fp64 code, never its place (the comparison is only taken where fp32 cannot get it wrong:
-// mmg_selftest_btrs_pretest / _binv_pretest count disagreements, none in 10^9 each): about 720 vector instructions per 64 binomials
+// mmg_selftest_btrs_pretest / _binv_pretest count disagreements, none in 10^10 each): about 720 vector instructions per 64 binomials
 // (profiles/r06_bigk_ab.md).  A piece is 64 list entries (measured best at every list length:
 // mmgibbs.hip, bigk_piece); a longer piece works -- a lane that finishes its row fetches the next -- and is what the tests run too.
 //

@@ -499,7 +499,7 @@ MMG_HD uint32_t binomial(Src &q, uint32_t n, double p)
 // log2 of a ratio of fp32 values, not amplified): 1e-6 (1 + |T0|); of S: 1e-7.  E takes six times that:
 //     E = sum_i c_i |x_i| / min(1, 1 + x_i) 2^-18 + (1 + |T0|) 2^-16 + 2^-14.
 // mmg_selftest_btrs_pretest runs candidates over the whole range of (n, p) through both and counts decided cases that disagree
-// with the fp64 test: none in 9 10^8 tests out of 2.4 10^9 attempts, the largest error 7 % of E (profiles/r06_btrs_pretest.txt;
+// with the fp64 test: none in 2.2 10^10 tests out of 6 10^10 attempts, the largest error 11 % of E (profiles/r06_btrs_pretest.txt;
 // tests/test_gpu_parity.py::test_btrs_pretest_never_contradicts_the_exact_test).  A NaN anywhere
 // compares false twice: undecided.
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -582,7 +582,7 @@ MMG_HD bool btrs_exact_test(double dn, double p, double kf, double us, double vv
 // Errors: r0 -- the exponent n log1p(-p) is below 20 in magnitude, fp32 product and log1pf err by 5e-7 of it, v_exp_f32 by an ulp: 1e-5
 // relative; every further term multiplies by s (n + 1 - x) / x with two v_rcp_f32 and four roundings: 4e-7 more per term; the sum adds an ulp of
 // itself per term; the uniform rounds to fp32 within 2^-25.  The bound takes six times that:  e_x = c~_x (2^-14 + x 2^-19) + 2^-22.
-// mmg_selftest_binv_pretest counts decided cases that differ from the fp64 search: none in 10^9, none with e_x at a sixteenth
+// mmg_selftest_binv_pretest counts decided cases that differ from the fp64 search: none in 4 10^10, none with e_x at a sixteenth
 // (profiles/r06_binv_pretest.txt; tests/test_gpu_parity.py::test_binv_pretest_never_contradicts_the_fp64_search).
 #if defined(__HIP_DEVICE_COMPILE__)
 // (slack: the selftest's knob -- the bound scaled down until decided cases start to differ shows how much room it has; 1 in the sampler)
