@@ -285,7 +285,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 BK_STAT(4, nI);
                 int pre = -1;
                 if (ph == BK_IFULL) {
+#if defined(BK_NO_FP32_TESTS) /* diagnostics build (tools/pretest_fullsize_check.py): the fp64 code only -- the chains must not change */
+                    pre = -1;
+#else
                     pre = binv_pretest(dn, P, U);
+#endif
                     if (pre >= 0) { x = (uint32_t)pre; resolved = true; }
                 }
                 const bool undecided = ph == BK_IFULL && pre < 0;
@@ -308,7 +312,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 BK_STAT(3, nW);
                 int pre = 0;
                 if (ph == BK_SLOW) {
+#if defined(BK_NO_FP32_TESTS)
+                    pre = 0;
+#else
                     pre = btrs_pretest(dn, P, kf, us, vv, A, B, ALPHA);
+#endif
                     if (pre > 0) { x = (uint32_t)kf; resolved = true; }
                     else if (pre < 0) ph = BK_TRY;
                 }
